@@ -1,0 +1,143 @@
+"""Streaming host loop: ring buffer -> window -> rFFT -> |X|, angle -> MODEL -> DC pad ->
+irFFT -> inverse window -> overlap-add.
+
+Counterpart of ``real_time_speech_enhancer`` in
+``/root/reference/dnn_model/interpreter_proposed.py:15-370`` (same framing, same
+windows, same DC handling), written against a *runner* object with the
+reference's signature-runner call surface (``runner(input=..., <130 state
+kwargs>) -> dict``), e.g. :class:`nunet_amd.runner.NutlsRunner`.  The model call
+is the only heavy part and runs on the GPU; this loop is plumbing (numpy).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, List, Tuple
+
+import numpy as np
+
+from . import topology as T
+
+FRAME_LEN = 512    # interpreter_proposed.py:17
+FRAME_STEP = 256   # interpreter_proposed.py:18
+SAMPLE_RATE = 16000
+HOP_SECONDS = FRAME_STEP / SAMPLE_RATE   # 0.016 s, the RTF denominator (interpreter_proposed.py:412)
+
+
+def hann_periodic(n: int = FRAME_LEN) -> np.ndarray:
+    """``tf.signal.hann_window(n)`` (periodic=True).  Evaluated in float32 like TF does, so
+    the taps agree with the tables the reference's phone app hard-codes
+    (mobile_app/.../RTSE_NUTLS_LSTM.java:62) to 1e-7 (e.g. w[1] = 3.76403e-05, where the
+    float64 value would be 3.76491e-05)."""
+    k = np.arange(n, dtype=np.float32)
+    arg = np.float32(2.0 * np.pi) * k / np.float32(n)
+    return (np.float32(0.5) - np.float32(0.5) * np.cos(arg)).astype(np.float32)
+
+
+def analysis_window() -> np.ndarray:
+    """Hann with both end taps forced to 1e-7 (interpreter_proposed.py:20-22)."""
+    w = hann_periodic()
+    w[0], w[-1] = 1e-7, 1e-7
+    return w
+
+
+def inverse_window() -> np.ndarray:
+    """``tf.signal.inverse_stft_window_fn(256, hann_window)(512)``
+    (interpreter_proposed.py:24-26): w / (w^2 + w_shifted_by_hop^2)."""
+    w = hann_periodic().astype(np.float32)
+    den = np.square(w).reshape(FRAME_LEN // FRAME_STEP, FRAME_STEP).sum(axis=0, keepdims=True)
+    den = np.tile(den, (FRAME_LEN // FRAME_STEP, 1)).reshape(-1)
+    return (w / den).astype(np.float32)
+
+
+def zero_state() -> Dict[str, np.ndarray]:
+    """The all-zero ``tflite_out`` seed of interpreter_proposed.py:36-198 (keys are the
+    *output* names: ``*_cur{i}``, ``*_h``, ``*_c``, ``model_out``)."""
+    st = {"model_out": np.zeros((1, 1, T.N_BINS, 1), np.float32)}
+    for base, shp in T.state_specs():
+        if len(shp) == 1:
+            st[base] = np.zeros((1, shp[0]), np.float32)
+        else:
+            st[base.format("cur")] = np.zeros((1,) + shp, np.float32)
+    return st
+
+
+def feeds_from_outputs(prev_out: Dict[str, np.ndarray], sliced_mag: np.ndarray) -> Dict[str, np.ndarray]:
+    """cur -> prev echo the caller performs every frame (interpreter_proposed.py:215-350)."""
+    feeds = {"input": sliced_mag}
+    for base, shp in T.state_specs():
+        if len(shp) == 1:
+            feeds[base] = prev_out[base]
+        else:
+            feeds[base.format("prev")] = prev_out[base.format("cur")]
+    return feeds
+
+
+def frame_magnitudes(noisy_speech: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """All analysis frames of the loop at once: (|X| [n,257], angle [n,257]), float64 like
+    ``np.fft.rfft`` of the float32 windowed buffer (interpreter_proposed.py:203-210)."""
+    audio = np.asarray(noisy_speech)
+    num_blocks = (audio.shape[0] - (FRAME_LEN - FRAME_STEP)) // FRAME_STEP
+    win = analysis_window()
+    in_buffer = np.zeros((FRAME_LEN,), np.float32)
+    mags = np.zeros((num_blocks, FRAME_LEN // 2 + 1))
+    phases = np.zeros((num_blocks, FRAME_LEN // 2 + 1))
+    for idx in range(num_blocks):
+        in_buffer[:-FRAME_STEP] = in_buffer[FRAME_STEP:]
+        in_buffer[-FRAME_STEP:] = audio[idx * FRAME_STEP:(idx + 1) * FRAME_STEP]
+        spec = np.fft.rfft(in_buffer * win)
+        mags[idx], phases[idx] = np.abs(spec), np.angle(spec)
+    return mags, phases
+
+
+def real_time_speech_enhancer(noisy_speech: np.ndarray, runner: Callable[..., Dict[str, np.ndarray]],
+                              dc_mode: str = "edge") -> Tuple[np.ndarray, List[float]]:
+    """Frame-by-frame enhancement of one utterance; returns (waveform, per-frame seconds).
+
+    ``dc_mode``: how bin 0 is re-created after the 256-bin model: ``"edge"`` (the PC loop,
+    interpreter_proposed.py:352-353) or ``"zero"`` (the phone,
+    mobile_app/.../RTSE_NUTLS_LSTM.java:677)."""
+    audio = np.asarray(noisy_speech)
+    win, inv_win = analysis_window(), inverse_window()
+    in_buffer = np.zeros((FRAME_LEN,), np.float32)
+    out_buffer = np.zeros((FRAME_LEN,), np.float32)
+    num_blocks = (audio.shape[0] - (FRAME_LEN - FRAME_STEP)) // FRAME_STEP
+    out_file = np.zeros((len(audio) + (FRAME_LEN - FRAME_STEP)))
+    time_array: List[float] = []
+    model_out = zero_state()
+    for idx in range(num_blocks):
+        t0 = time.time()
+        in_buffer[:-FRAME_STEP] = in_buffer[FRAME_STEP:]
+        in_buffer[-FRAME_STEP:] = audio[idx * FRAME_STEP:(idx + 1) * FRAME_STEP]
+        spec = np.fft.rfft(in_buffer * win)
+        in_mag, in_phase = np.abs(spec), np.angle(spec)
+        sliced_mag = np.reshape(in_mag, (1, 1, -1, 1)).astype(np.float32)[:, :, 1:]
+        model_out = runner(**feeds_from_outputs(model_out, sliced_mag))
+        est = model_out["model_out"]
+        if dc_mode == "edge":
+            est_mag = np.pad(est, ((0, 0), (0, 0), (1, 0), (0, 0)), mode="edge")
+        elif dc_mode == "zero":
+            est_mag = np.pad(est, ((0, 0), (0, 0), (1, 0), (0, 0)))
+        else:
+            raise ValueError("dc_mode must be 'edge' or 'zero'")
+        est_mag = np.squeeze(est_mag)
+        block = np.fft.irfft(est_mag * np.exp(1j * in_phase)).astype(np.float32) * inv_win
+        out_buffer[:-FRAME_STEP] = out_buffer[FRAME_STEP:]
+        out_buffer[-FRAME_STEP:] = 0
+        out_buffer += block
+        out_file[idx * FRAME_STEP:(idx + 1) * FRAME_STEP] = out_buffer[:FRAME_STEP]
+        time_array.append(time.time() - t0)
+    return out_file[FRAME_LEN - FRAME_STEP:], time_array
+
+
+def snr_db(clean: np.ndarray, est: np.ndarray) -> float:
+    n = min(len(clean), len(est))
+    c, e = np.asarray(clean[:n], np.float64), np.asarray(est[:n], np.float64)
+    return float(10.0 * np.log10(np.sum(c * c) / np.sum((c - e) ** 2)))
+
+
+def si_snr_db(clean: np.ndarray, est: np.ndarray) -> float:
+    n = min(len(clean), len(est))
+    c, e = np.asarray(clean[:n], np.float64), np.asarray(est[:n], np.float64)
+    c, e = c - c.mean(), e - e.mean()
+    s = (np.dot(e, c) / np.dot(c, c)) * c
+    return float(10.0 * np.log10(np.sum(s * s) / np.sum((e - s) ** 2)))

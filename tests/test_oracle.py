@@ -1,0 +1,119 @@
+"""CPU tests of the oracle itself (no GPU): oracle B (stage-structured restatement) against
+the committed golden vectors produced by oracle A (op-by-op execution of the reference's
+shipped graph), the reference-derived known answers, and -- in the build container only --
+oracle A re-run live against the same goldens."""
+import os
+
+import numpy as np
+import pytest
+
+from nunet_amd import stream_enhance as SE, topology as T
+from nunet_amd.weights import load_weights
+from oracle.nutls_ref import NutlsRef
+
+from conftest import GOLDEN, REFERENCE_TFLITE
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+def test_weight_container_inventory():
+    w = load_weights()
+    layers = {k.split(".")[0] for k in w}
+    assert len(layers) == 180            # 178 conv-like + lstm pairs share prefixes: see topology
+    n_ln = sum(1 for k in w if k.endswith(".gamma"))
+    assert n_ln == 117                   # 13 in-convs + 52 strided + 52 sub-pixel convs
+    assert sum(1 for k in w if k.endswith(".wx")) == 13
+    assert w["msfe6_en_spconv6.w"].shape == (128, 2, 3, 64)
+    assert w["msfe3_upsampling.w"].shape == (128, 1, 3, 128)
+    assert w["lstm.wx"].shape == (84, 256) and w["dense.w"].shape == (256, 21)
+    assert sum(v.size for v in w.values()) == 2832910
+
+
+def test_topology_matches_reference_signature():
+    # converter_proposed.py:26-187: 1 input + 104 conv states + 26 LSTM states; 205 090 floats
+    assert len(T.input_names()) == 131 and len(T.output_names()) == 131
+    assert T.state_floats_per_stream() == 205090
+    assert "msfe4_ee2_prev3" in T.input_names() and "msfe4_dd3_cur1" in T.output_names()
+    shapes = {b.format("prev"): s for b, s in T.state_specs()}
+    assert shapes["msfe6_ee_prev1"] == (1, 256, 64) and shapes["msfe6_de_prev1"] == (1, 256, 128)
+    assert shapes["msfe4_ee3_prev4"] == (1, 2, 32) and shapes["msfe3_dd_prev1"] == (1, 1, 64)
+
+
+def test_kat_b1_closed_form():
+    """x[k] = 0.5+0.5 sin(0.1k) three frames from zero state."""
+    kat = np.load(os.path.join(GOLDEN, "kat_b1.npz"))
+    # the numbers printed in SURVEY.md B.1 (oracle A, survey session) pin the fixture itself
+    np.testing.assert_allclose(kat["out1"][:6], [0.841054, 0.276825, 0.561412, 0.719467, 0.657214, 0.764735], atol=2e-6)
+    np.testing.assert_allclose(kat["out3"][250:], [0.452088, 0.508922, 0.547724, 0.601137, 0.641985, 0.709822], atol=2e-6)
+    assert abs(float(kat["out2"].sum()) - 130.80884) < 2e-3
+    assert abs(float(kat["state_h3"][1]) - 0.995055) < 2e-6
+    ref = NutlsRef(batch=1)
+    for fr in (1, 2, 3):
+        out = ref.step(kat["x"].reshape(1, 256)).numpy().reshape(-1)
+        assert rms(out, kat["out%d" % fr]) < 1e-6
+        np.testing.assert_allclose(ref.state["state_h"].numpy().reshape(-1), kat["state_h%d" % fr], atol=1e-5)
+        assert abs(float(ref.state["msfe6_ee_prev2"].sum()) - float(kat["ee_cur2_sum%d" % fr])) < 1e-2
+
+
+def test_oracle_b_matches_golden_clip_and_states():
+    clip = np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+    ref = NutlsRef(batch=1)
+    outs = []
+    for i in range(64):
+        outs.append(ref.step(clip["mags_in"][i:i + 1]).numpy().reshape(-1))
+        if i + 1 in (3, 64):
+            st = np.load(os.path.join(GOLDEN, "state_f%d.npz" % (i + 1)))
+            for base, shp in T.state_specs():
+                k_ref = base if len(shp) == 1 else base.format("prev")
+                k_gold = base if len(shp) == 1 else base.format("cur")
+                a, b = ref.state[k_ref].numpy().reshape(-1), st[k_gold].reshape(-1)
+                # LSTM cell states reach |c| ~ 64, so the tolerance is relative
+                np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5, err_msg=k_gold)
+    assert rms(np.stack(outs), clip["mags_out"][:64]) < 1e-6
+
+
+def test_oracle_b_batch_invariance():
+    """Streams are independent: a stream's output does not depend on batch size/position."""
+    clip = np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+    a = NutlsRef(batch=1)
+    b = NutlsRef(batch=3)
+    for i in range(4):
+        x = clip["mags_in"][i + 10]
+        xb = np.stack([clip["mags_in"][i + 50], x, clip["mags_in"][i + 100]])
+        oa = a.step(x[None]).numpy()[0]
+        ob = b.step(xb).numpy()[1]
+        assert rms(oa, ob) < 1e-6
+
+
+def test_oracle_b_signature_call_round_trip():
+    """The named-tensor surface (interpreter_proposed.py:215-350) equals the batched step."""
+    clip = np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+    sig, eng = NutlsRef(batch=1), NutlsRef(batch=1)
+    out = SE.zero_state()
+    for i in range(3):
+        m = clip["mags_in"][i]
+        out = sig.signature_call(**SE.feeds_from_outputs(out, m.reshape(1, 1, 256, 1)))
+        o2 = eng.step(m[None]).numpy().reshape(-1)
+        assert out["model_out"].shape == (1, 1, 256, 1) and out["msfe6_en_h"].shape == (1, 21)
+        assert rms(out["model_out"].reshape(-1), o2) == 0.0
+    with pytest.raises(ValueError):
+        sig.signature_call(input=np.zeros((1, 1, 256, 1), np.float32))
+
+
+@pytest.mark.reference
+def test_oracle_a_live_reproduces_goldens(has_reference):
+    """Build container only: re-execute the shipped flatbuffer and compare with the fixtures."""
+    if not has_reference:
+        pytest.skip("/root/reference not present")
+    from oracle.graph_exec import GraphOracle
+    g = GraphOracle(REFERENCE_TFLITE)
+    assert g.key == "nutls_lstm_sm" and len(g.model.ops) == 3066 and len(g.model.tensors) == 4054
+    clip = np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+    out = SE.zero_state()
+    for i in range(3):
+        out = g(**SE.feeds_from_outputs(out, clip["mags_in"][i].reshape(1, 1, 256, 1)))
+        assert rms(out["model_out"].reshape(-1), clip["mags_out"][i]) < 1e-7
+    with pytest.raises(ValueError):
+        g(input=np.zeros((1, 1, 256, 1), np.float32))
