@@ -1,0 +1,111 @@
+/*
+ * nutls.h -- C ABI of the MI355X-native NUNet-TLS frame-by-frame forward pass.
+ *
+ * This is the drop-in boundary for ONE path of the reference: the per-frame model call
+ *
+ *     runner = interpreter.get_signature_runner('nutls_lstm_sm')          (interpreter_proposed.py:380)
+ *     out    = runner(input=..., msfe6_ee_prev1=..., ..., msfe6_de_c=...)  (interpreter_proposed.py:215-350)
+ *
+ * (phone twin: Interpreter.runSignature(inputs, outputs, "nutls_lstm_sm"),
+ *  mobile_app/.../RTSE_NUTLS_LSTM.java:571), i.e. the function
+ * TFL_SIGNITURE.nutls_lstm of converter_proposed.py:188-867 evaluated by TF-Lite.
+ *
+ * Differences from the reference surface, by design:
+ *   - B independent streams per handle (the reference is batch 1);
+ *   - the 130 recurrent-state tensors (converter_proposed.py:27-186) stay resident in HBM
+ *     between calls; the caller may read / write any of them by its signature name
+ *     (the "cur -> prev" echo of interpreter_proposed.py:215-350 becomes a buffer flip);
+ *   - weights come from a .nutlsw container (tools/convert_tflite_weights.py), not a .tflite.
+ *
+ * Plain pointers and sizes only.  Every entry returns 0 on success or a negative code;
+ * nutls_last_error() returns a thread-local message for the last failure.
+ * One handle = one GPU = one host thread at a time (like a TF-Lite Interpreter).
+ */
+#ifndef NUTLS_H_
+#define NUTLS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nutls_handle nutls_handle;
+
+enum {
+  NUTLS_OK = 0,
+  NUTLS_ERR_ARG = -1,      /* bad argument: unknown state name, size mismatch, null pointer (ValueError in TF-Lite) */
+  NUTLS_ERR_WEIGHTS = -2,  /* malformed weight container or missing tensor */
+  NUTLS_ERR_HIP = -3,      /* HIP runtime failure (message carries hipGetErrorString) */
+  NUTLS_ERR_NO_DEVICE = -4 /* no usable gfx950 device: there is NO CPU fallback */
+};
+
+enum {
+  NUTLS_VARIANT_LSTM = 0   /* NUNet-TLS-LSTM, "proposed" (models/proposed.py) */
+};
+
+#define NUTLS_BINS 256        /* network bins per frame (DC dropped, interpreter_proposed.py:212-213) */
+#define NUTLS_LSTM_UNITS 21   /* models/proposed.py:21 */
+
+/* Replaces: tf.lite.Interpreter(model_path) + allocate_tensors() (interpreter_proposed.py:374-375).
+ * `weights`/`n_bytes`: the .nutlsw container bytes (copied; caller may free after return).
+ * `batch`: number of independent streams B (>= 1).  `device`: HIP device ordinal. */
+int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, int device,
+                 nutls_handle** out);
+
+/* Replaces: del interpreter. */
+int nutls_destroy(nutls_handle* h);
+
+/* Replaces: one runner(...) call for all B streams (interpreter_proposed.py:215-350) with the
+ * cur->prev echo folded in.  mag_in / mag_out: DEVICE pointers to [B, 256] float32
+ * (row = stream; bins 1..256 of |STFT|).  Asynchronous on `stream` (a hipStream_t, may be NULL
+ * for the default stream); state advances by one frame. */
+int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* stream);
+
+/* Same with HOST buffers: H2D copy, step, D2H copy, synchronises before returning. */
+int nutls_step_host(nutls_handle* h, const float* mag_in, float* mag_out);
+
+/* Library-owned device staging buffers [B,256]; stepping on them avoids the D2D copies and lets
+ * the captured hipGraph run with no per-call parameter update. */
+int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out);
+
+/* Capture the launch sequence of a step into hipGraphs (one per state parity) and replay them
+ * from then on.  enable = 0 goes back to plain launches. */
+int nutls_use_graph(nutls_handle* h, int enable);
+
+/* State access by the reference's signature names.  `name` is any of the 130 state inputs
+ * ("msfe6_ee_prev1" ... "msfe6_de_c", converter_proposed.py:27-186); the matching output spelling
+ * ("..._cur1") is accepted as an alias.  Host buffer layout: [B, F, C] (conv states) or [B, 21],
+ * float32, `n_floats` must equal B * per-stream size.  Synchronous. */
+int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
+int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, size_t n_floats);
+
+/* Enumerate the state tensors: count, then name + per-stream dims (F, C) or (21, 1). */
+int nutls_state_count(nutls_handle* h);
+int nutls_state_info(nutls_handle* h, int index, const char** name, int* dim0, int* dim1);
+
+/* Zero the state of one stream (stream_idx >= 0) or of all streams (stream_idx < 0): the
+ * all-zero seed of interpreter_proposed.py:36-198. */
+int nutls_reset(nutls_handle* h, int stream_idx);
+
+/* Copy the last step's value of an internal activation to the host (testing / debugging):
+ * "<stage>.y" (CTFA output [B,F0,64]), "<stage>.up" (decoder up-sampled input [B,F0,128]),
+ * "input_layer" ([B,256,64]). */
+int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
+
+int nutls_batch(nutls_handle* h);
+int nutls_launches_per_step(nutls_handle* h);
+
+/* Time `iters` launches of the dominant kernel family member `which` (0 = largest sub-pixel conv,
+ * 1 = largest encoder strided conv, 2 = whole encoder strided-conv stack) with HIP events on the
+ * library's own stream; writes the average milliseconds per launch (or per stack). */
+int nutls_time_kernel(nutls_handle* h, int which, int iters, float* avg_ms);
+
+const char* nutls_last_error(void);
+const char* nutls_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUTLS_H_ */

@@ -6,6 +6,7 @@ arithmetic runs in the HIP library built from ``csrc/`` behind the C ABI of
 ``include/nutls.h``.  There is no CPU fallback: importing works anywhere, but
 creating an engine without the built library or without a GPU raises.
 """
-from . import topology, weights  # noqa: F401
+from . import topology, weights, stream_enhance  # noqa: F401
+from .runner import NutlsEngine, NutlsRunner, load_library  # noqa: F401
 
-__all__ = ["topology", "weights"]
+__all__ = ["topology", "weights", "stream_enhance", "NutlsEngine", "NutlsRunner", "load_library"]

@@ -1,0 +1,752 @@
+// Host engine behind the C ABI of include/nutls.h: weight upload, HBM-resident recurrent state
+// (ping-pong: the `cur` tensors of frame t are the `prev` tensors of frame t+1, no copy), the
+// per-frame launch plan that wires the kernels of kernels.hip exactly like
+// TFL_SIGNITURE.nutls_lstm (/root/reference/dnn_model/converter_proposed.py:188-867), and
+// optional hipGraph capture of that plan.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/nutls.h"
+#include "nutls_internal.hpp"
+
+namespace nutls {
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess)                                                                   \
+      return fail(NUTLS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));       \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+struct StageDesc {
+  const char* prefix;
+  int depth, f0;
+  const char* conv_tag;
+  const char* spconv_tag;
+  const char* resample;
+  int pair;  // decoder: index into kEncoder of the paired encoder stage; encoder: -1
+};
+// stage order / pairing: converter_proposed.py:221-727 (decoder pairs at :464,500,542,585,627,675)
+static const StageDesc kEncoder[6] = {
+    {"msfe6_en", 6, 256, "msfe6_ee", "msfe6_ed", "msfe6_down_sampling", -1},
+    {"msfe5_en", 5, 128, "msfe5_ee", "msfe5_ed", "msfe5_down_sampling", -1},
+    {"msfe4_en", 4, 64, "msfe4_ee", "msfe4_ed", "msfe4_down_sampling", -1},
+    {"msfe4_en2", 4, 32, "msfe4_ee2", "msfe4_ed2", "msfe4_down_sampling2", -1},
+    {"msfe4_en3", 4, 16, "msfe4_ee3", "msfe4_ed3", "msfe4_down_sampling3", -1},
+    {"msfe3_en", 3, 8, "msfe3_ee", "msfe3_ed", "msfe3_down_sampling", -1},
+};
+static const StageDesc kDecoder[6] = {
+    {"msfe3_de", 3, 8, "msfe3_de", "msfe3_dd", "msfe3_upsampling", 5},
+    {"msfe4_de", 4, 16, "msfe4_de", "msfe4_dd", "msfe4_upsampling", 4},
+    {"msfe4_de2", 4, 32, "msfe4_de2", "msfe4_dd2", "msfe4_upsampling2", 3},
+    {"msfe4_de3", 4, 64, "msfe4_de3", "msfe4_dd3", "msfe4_upsampling3", 2},
+    {"msfe5_de", 5, 128, "msfe5_de", "msfe5_dd", "msfe5_upsampling", 1},
+    {"msfe6_de", 6, 256, "msfe6_de", "msfe6_dd", "msfe6_upsampling", 0},
+};
+static int decoder_of_encoder(int enc) { return 5 - enc; }
+
+struct StateTensor {
+  std::string name_prev, name_cur;
+  int d0, d1;        // per-stream dims: (F, C) for conv states, (21, 1) for LSTM states
+  float* buf[2];     // ping-pong, each [B, d0, d1]
+  size_t per_stream() const { return static_cast<size_t>(d0) * d1; }
+};
+
+struct Launch {
+  enum Kind { CONV, LSTM, CTFA, INLAYER, OUTCONV } kind;
+  ConvKind ck;
+  ConvParams conv;
+  LstmParams lstm;
+  CtfaParams ctfa;
+  InLayerParams inl;
+  OutConvParams outc;
+  std::string name;
+  bool encoder_strided = false;
+};
+
+struct StageStates {
+  std::vector<int> conv;    // state index of conv input i (1-based -> [i-1])
+  std::vector<int> spconv;  // state index of sub-pixel conv input j
+  int h, c;
+};
+
+struct ConvLayerW { float *wpk, *bias, *gamma, *beta; float alpha; };
+struct LstmW { float *wxT, *whT, *bias, *wdT, *bd; int din, dout; };
+struct CtfaW { float *w1T, *b1, *w2T, *b2; };
+
+struct Engine {
+  int B = 0, device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  std::vector<StateTensor> states;
+  std::unordered_map<std::string, int> state_index;
+  StageStates enc_st[6], dec_st[6];
+  int central_h = -1, central_c = -1;
+  std::vector<Launch> plan[2];
+  float *io_in = nullptr, *io_out = nullptr;
+  float *t_inlayer = nullptr, *t_y = nullptr, *t_d = nullptr, *t_up = nullptr;
+  float* upcat[6] = {nullptr};
+  int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
+  bool use_graph = false;
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};
+  std::unordered_map<std::string, std::pair<float*, size_t>> debug;   // name -> (ptr, floats per stream)
+  std::unordered_map<std::string, ConvLayerW> convw;
+  std::unordered_map<std::string, LstmW> lstmw;
+  std::unordered_map<std::string, CtfaW> ctfaw;
+  float *in_w = nullptr, *in_b = nullptr, *in_g = nullptr, *in_bt = nullptr, *out_w = nullptr;
+  float in_alpha = 0.f, out_bias = 0.f;
+
+  ~Engine() {
+    for (int i = 0; i < 2; ++i)
+      if (gexec[i]) (void)hipGraphExecDestroy(gexec[i]);
+    for (void* p : allocs) (void)hipFree(p);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+// ------------------------------------------------------------------------------- helpers ------
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+static int dev_alloc(Engine* e, size_t floats, float** out, bool zero) {
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, floats * sizeof(float)));
+  e->allocs.push_back(p);
+  if (zero) HIP_TRY(hipMemset(p, 0, floats * sizeof(float)));
+  *out = static_cast<float*>(p);
+  return NUTLS_OK;
+}
+
+static int upload(Engine* e, const std::vector<float>& v, float** out) {
+  int rc = dev_alloc(e, v.size() < 4 ? 4 : v.size(), out, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  return NUTLS_OK;
+}
+
+static const HostTensor* find(const WeightMap& w, const std::string& k, std::string* err) {
+  auto it = w.find(k);
+  if (it == w.end()) {
+    *err = "weight tensor missing: " + k;
+    return nullptr;
+  }
+  return &it->second;
+}
+
+static std::vector<float> transpose2d(const HostTensor& t, int rows, int cols) {  // [rows][cols] -> [cols][rows]
+  std::vector<float> o(static_cast<size_t>(rows) * cols);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) o[static_cast<size_t>(c) * rows + r] = t.data[static_cast<size_t>(r) * cols + c];
+  return o;
+}
+
+// Uploads one conv-like layer in MFMA streaming order.
+static int prep_conv(Engine* e, const WeightMap& wm, const std::string& layer, const std::string& key, ConvKind kind,
+                     const std::vector<int>& perm, const std::vector<std::pair<int, int>>& taps) {
+  std::string err;
+  const ConvShape sh = conv_shape(kind);
+  const HostTensor* w = find(wm, layer + ".w", &err);
+  const HostTensor* b = find(wm, layer + ".b", &err);
+  if (!w || !b) return fail(NUTLS_ERR_WEIGHTS, err);
+  if (w->dims.size() != 4 || w->dims[3] != sh.cin || static_cast<int>(perm.size()) != 32 * sh.nt)
+    return fail(NUTLS_ERR_WEIGHTS, "unexpected weight shape for " + layer);
+  ConvLayerW cw{};
+  int rc = upload(e, pack_conv_weights(*w, perm, taps, sh.tt, sh.cin, sh.nt), &cw.wpk);
+  if (rc) return rc;
+  std::vector<float> bp(perm.size());
+  for (size_t i = 0; i < perm.size(); ++i) bp[i] = b->data[perm[i]];
+  if ((rc = upload(e, bp, &cw.bias))) return rc;
+  if (sh.epi_ln) {
+    const HostTensor* g = find(wm, layer + ".gamma", &err);
+    const HostTensor* bt = find(wm, layer + ".beta", &err);
+    const HostTensor* al = find(wm, layer + ".alpha", &err);
+    if (!g || !bt || !al) return fail(NUTLS_ERR_WEIGHTS, err);
+    if (static_cast<int>(g->size()) != 32 * sh.g) return fail(NUTLS_ERR_WEIGHTS, "unexpected LayerNorm width for " + layer);
+    if ((rc = upload(e, g->data, &cw.gamma))) return rc;
+    if ((rc = upload(e, bt->data, &cw.beta))) return rc;
+    cw.alpha = al->data[0];
+  }
+  e->convw[key] = cw;
+  return NUTLS_OK;
+}
+
+static std::vector<int> iota_perm(int n) {
+  std::vector<int> p(n);
+  for (int i = 0; i < n; ++i) p[i] = i;
+  return p;
+}
+// Sub-pixel shuffle folded into the output-channel order (proposed.py:240-251):
+// packed channel r*32+c of position f IS out[2f+r, c].
+static std::vector<int> perm_shuffle64() {
+  std::vector<int> p(64);
+  for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 32; ++c) p[r * 32 + c] = 2 * c + r;
+  return p;
+}
+// 128-channel variant: the reference reshapes with the *input* channel count (32,2), so
+// out[2f+r, C2] = y[f, r*64 + (C2%32)*2 + C2/32].
+static std::vector<int> perm_shuffle128() {
+  std::vector<int> p(128);
+  for (int r = 0; r < 2; ++r)
+    for (int c2 = 0; c2 < 64; ++c2) p[r * 64 + c2] = r * 64 + (c2 % 32) * 2 + c2 / 32;
+  return p;
+}
+
+static int prep_weights(Engine* e, const WeightMap& wm) {
+  std::string err;
+  int rc;
+  const std::vector<std::pair<int, int>> taps3 = {{0, 0}, {0, 1}, {0, 2}};
+  const std::vector<std::pair<int, int>> tap1 = {{0, 0}};
+  for (int side = 0; side < 2; ++side)
+    for (int s = 0; s < 6; ++s) {
+      const StageDesc& st = side ? kDecoder[s] : kEncoder[s];
+      const std::string P = st.prefix;
+      if ((rc = prep_conv(e, wm, P + "_in", P + "_in", side ? CONV_IN_C128 : CONV_IN_C64, iota_perm(64), tap1))) return rc;
+      for (int i = 1; i <= st.depth; ++i) {
+        const int cin = (i == 1) ? (side ? 128 : 64) : (side ? 64 : 32);
+        const ConvKind k = cin == 32 ? CONV_EL_C32 : cin == 64 ? CONV_EL_C64 : CONV_EL_C128;
+        const std::string L = P + "_conv" + std::to_string(i);
+        if ((rc = prep_conv(e, wm, L, L, k, iota_perm(32), taps3))) return rc;
+      }
+      for (int j = 1; j <= st.depth; ++j) {
+        const std::string L = P + "_spconv" + std::to_string(j);
+        if (j < st.depth) rc = prep_conv(e, wm, L, L, CONV_DL_N64, perm_shuffle64(), taps3);
+        else rc = prep_conv(e, wm, L, L, CONV_DL_N128, perm_shuffle128(), taps3);
+        if (rc) return rc;
+      }
+      if (!side) {
+        if ((rc = prep_conv(e, wm, st.resample, st.resample, CONV_DOWN, iota_perm(64), taps3))) return rc;
+      } else {
+        // Conv2DTranspose (1,3) stride 2 (proposed.py:260-265):  out[2i] = W0 x[i] + W2 x[i-1],
+        // out[2i+1] = W1 x[i]  
+        if ((rc = prep_conv(e, wm, st.resample, std::string(st.resample) + "#even", CONV_UP_EVEN, iota_perm(128), {{0, 2}, {0, 0}}))) return rc;
+        if ((rc = prep_conv(e, wm, st.resample, std::string(st.resample) + "#odd", CONV_UP_ODD, iota_perm(128), {{0, 1}}))) return rc;
+      }
+      // CTFA MLPs
+      for (const char* br : {"_ta", "_fa"}) {
+        const HostTensor* w1 = find(wm, P + br + ".w1", &err);
+        const HostTensor* b1 = find(wm, P + br + ".b1", &err);
+        const HostTensor* w2 = find(wm, P + br + ".w2", &err);
+        const HostTensor* b2 = find(wm, P + br + ".b2", &err);
+        if (!w1 || !b1 || !w2 || !b2) return fail(NUTLS_ERR_WEIGHTS, err);
+        if (w1->size() != 16 * 64 || w2->size() != 64 * 16) return fail(NUTLS_ERR_WEIGHTS, "unexpected CTFA shape " + P + br);
+        CtfaW cw{};
+        if ((rc = upload(e, transpose2d(*w1, 16, 64), &cw.w1T))) return rc;
+        if ((rc = upload(e, b1->data, &cw.b1))) return rc;
+        if ((rc = upload(e, transpose2d(*w2, 64, 16), &cw.w2T))) return rc;
+        if ((rc = upload(e, b2->data, &cw.b2))) return rc;
+        e->ctfaw[P + br] = cw;
+      }
+    }
+  // LSTM + Dense pairs (13)
+  std::vector<std::pair<std::string, std::string>> lstms;
+  for (int s = 0; s < 6; ++s) lstms.push_back({std::string(kEncoder[s].prefix) + "_lstm", std::string(kEncoder[s].prefix) + "_dense"});
+  lstms.push_back({"lstm", "dense"});
+  for (int s = 0; s < 6; ++s) lstms.push_back({std::string(kDecoder[s].prefix) + "_lstm", std::string(kDecoder[s].prefix) + "_dense"});
+  for (auto& ld : lstms) {
+    const HostTensor* wx = find(wm, ld.first + ".wx", &err);
+    const HostTensor* wh = find(wm, ld.first + ".wh", &err);
+    const HostTensor* b = find(wm, ld.first + ".b", &err);
+    const HostTensor* wd = find(wm, ld.second + ".w", &err);
+    const HostTensor* bd = find(wm, ld.second + ".b", &err);
+    if (!wx || !wh || !b || !wd || !bd) return fail(NUTLS_ERR_WEIGHTS, err);
+    LstmW lw{};
+    lw.din = wx->dims[1];
+    lw.dout = wd->dims[0];
+    if (wx->dims[0] != 84 || wh->dims[0] != 84 || wh->dims[1] != 21 || wd->dims[1] != 21)
+      return fail(NUTLS_ERR_WEIGHTS, "unexpected LSTM shape " + ld.first);
+    if ((rc = upload(e, transpose2d(*wx, 84, lw.din), &lw.wxT))) return rc;
+    if ((rc = upload(e, transpose2d(*wh, 84, 21), &lw.whT))) return rc;
+    if ((rc = upload(e, b->data, &lw.bias))) return rc;
+    if ((rc = upload(e, transpose2d(*wd, lw.dout, 21), &lw.wdT))) return rc;
+    if ((rc = upload(e, bd->data, &lw.bd))) return rc;
+    e->lstmw[ld.first] = lw;
+  }
+  // input layer / output conv
+  const HostTensor* iw = find(wm, "input_layer.w", &err);
+  const HostTensor* ib = find(wm, "input_layer.b", &err);
+  const HostTensor* ig = find(wm, "input_layer.gamma", &err);
+  const HostTensor* ibt = find(wm, "input_layer.beta", &err);
+  const HostTensor* ia = find(wm, "input_layer.alpha", &err);
+  const HostTensor* ow = find(wm, "out_conv.w", &err);
+  const HostTensor* ob = find(wm, "out_conv.b", &err);
+  if (!iw || !ib || !ig || !ibt || !ia || !ow || !ob) return fail(NUTLS_ERR_WEIGHTS, err);
+  if ((rc = upload(e, iw->data, &e->in_w))) return rc;
+  if ((rc = upload(e, ib->data, &e->in_b))) return rc;
+  if ((rc = upload(e, ig->data, &e->in_g))) return rc;
+  if ((rc = upload(e, ibt->data, &e->in_bt))) return rc;
+  if ((rc = upload(e, ow->data, &e->out_w))) return rc;
+  e->in_alpha = ia->data[0];
+  e->out_bias = ob->data[0];
+  return NUTLS_OK;
+}
+
+// ------------------------------------------------------------------------------- state --------
+static int add_state(Engine* e, const std::string& prev, const std::string& cur, int d0, int d1) {
+  StateTensor st;
+  st.name_prev = prev;
+  st.name_cur = cur;
+  st.d0 = d0;
+  st.d1 = d1;
+  for (int i = 0; i < 2; ++i) {
+    int rc = dev_alloc(e, static_cast<size_t>(e->B) * d0 * d1, &st.buf[i], true);
+    if (rc) return rc;
+  }
+  const int idx = static_cast<int>(e->states.size());
+  e->states.push_back(st);
+  e->state_index[prev] = idx;
+  e->state_index[cur] = idx;
+  return idx;
+}
+
+// State inventory in the order of the reference's signature (converter_proposed.py:27-186).
+static int build_states(Engine* e) {
+  for (int side = 0; side < 2; ++side)
+    for (int s = 0; s < 6; ++s) {
+      const StageDesc& st = side ? kDecoder[s] : kEncoder[s];
+      StageStates& ss = side ? e->dec_st[s] : e->enc_st[s];
+      for (int i = 1; i <= st.depth; ++i) {
+        const int f = st.f0 >> (i - 1);
+        const int c = (i == 1) ? (side ? 128 : 64) : (side ? 64 : 32);
+        const std::string tag = st.conv_tag;
+        int idx = add_state(e, tag + "_prev" + std::to_string(i), tag + "_cur" + std::to_string(i), f, c);
+        if (idx < 0) return idx;
+        ss.conv.push_back(idx);
+      }
+      for (int j = 1; j <= st.depth; ++j) {
+        const int f = (st.f0 >> st.depth) << (j - 1);
+        const std::string tag = st.spconv_tag;
+        int idx = add_state(e, tag + "_prev" + std::to_string(j), tag + "_cur" + std::to_string(j), f, 64);
+        if (idx < 0) return idx;
+        ss.spconv.push_back(idx);
+      }
+    }
+  auto add_hc = [&](const std::string& base, int* h, int* c) -> int {
+    *h = add_state(e, base + "_h", base + "_h", NUTLS_LSTM_UNITS, 1);
+    if (*h < 0) return *h;
+    *c = add_state(e, base + "_c", base + "_c", NUTLS_LSTM_UNITS, 1);
+    return *c < 0 ? *c : 0;
+  };
+  int rc;
+  for (int s = 0; s < 6; ++s)
+    if ((rc = add_hc(kEncoder[s].prefix, &e->enc_st[s].h, &e->enc_st[s].c)) < 0) return rc;
+  if ((rc = add_hc("state", &e->central_h, &e->central_c)) < 0) return rc;
+  for (int s = 0; s < 6; ++s)
+    if ((rc = add_hc(kDecoder[s].prefix, &e->dec_st[s].h, &e->dec_st[s].c)) < 0) return rc;
+  return NUTLS_OK;
+}
+
+// ------------------------------------------------------------------------------- plan ---------
+static void push_conv(Engine* e, std::vector<Launch>* plan, const std::string& wkey, ConvKind k, const float* src0,
+                      const float* src1, int src_ld, int f_in, int f_out, float* dst0, int ld0, float* dst1, int ld1,
+                      int row_mul, int row_add, bool enc_strided = false) {
+  const ConvLayerW& w = e->convw.at(wkey);
+  Launch L{};
+  L.kind = Launch::CONV;
+  L.ck = k;
+  L.name = wkey;
+  L.encoder_strided = enc_strided;
+  ConvParams& p = L.conv;
+  p.src0 = src0; p.src1 = src1; p.wpk = w.wpk; p.bias = w.bias; p.gamma = w.gamma; p.beta = w.beta;
+  p.dst0 = dst0; p.dst1 = dst1; p.src_ld = src_ld; p.ld0 = ld0; p.ld1 = ld1;
+  p.B = e->B; p.F_in = f_in; p.F_out = f_out; p.log2_fout = ilog2(f_out);
+  p.row_mul = row_mul; p.row_add = row_add; p.alpha = w.alpha;
+  plan->push_back(L);
+}
+
+static void push_lstm(Engine* e, std::vector<Launch>* plan, const std::string& lname, const float* x, int x_ld, int x_rows,
+                      int x_cols, float* dst, int dst_ld, int dst_rows, int dst_cols, int h_idx, int c_idx, int par) {
+  const LstmW& w = e->lstmw.at(lname);
+  Launch L{};
+  L.kind = Launch::LSTM;
+  L.name = lname;
+  LstmParams& p = L.lstm;
+  p.x = x; p.x_ld = x_ld; p.x_rows = x_rows; p.x_cols = x_cols;
+  p.wxT = w.wxT; p.whT = w.whT; p.bias = w.bias; p.wdT = w.wdT; p.bd = w.bd;
+  p.h_in = e->states[h_idx].buf[1 - par]; p.c_in = e->states[c_idx].buf[1 - par];
+  p.h_out = e->states[h_idx].buf[par]; p.c_out = e->states[c_idx].buf[par];
+  p.dst = dst; p.dst_ld = dst_ld; p.dst_rows = dst_rows; p.dst_cols = dst_cols;
+  p.Din = w.din; p.Dout = w.dout; p.B = e->B;
+  plan->push_back(L);
+}
+
+// One MSFE stage (converter_proposed.py:225-262 encoder, :467-498 decoder).
+static void build_stage(Engine* e, std::vector<Launch>* plan, int side, int s, int par, const float* x_src, int x_ld,
+                        float* y_dst, int y_ld) {
+  const StageDesc& st = side ? kDecoder[s] : kEncoder[s];
+  const StageStates& ss = side ? e->dec_st[s] : e->enc_st[s];
+  const StageStates* pair_dec = side ? nullptr : &e->dec_st[decoder_of_encoder(s)];
+  const std::string P = st.prefix;
+  const int D = st.depth, FD = st.f0 >> D;
+  auto cur = [&](int idx) { return e->states[idx].buf[par]; };
+  auto prev = [&](int idx) { return e->states[idx].buf[1 - par]; };
+  const int c1 = side ? 128 : 64;
+  // e0 = inconv(x)  -> channels [0,64) of the first strided conv's input
+  push_conv(e, plan, P + "_in", side ? CONV_IN_C128 : CONV_IN_C64, x_src, nullptr, x_ld, st.f0, st.f0, cur(ss.conv[0]), c1,
+            nullptr, 0, 1, 0);
+  // e_i = EL_i([prev_i ; cur_i]); e_i feeds conv i+1 and the stage's own sub-pixel conv D-i+1
+  for (int i = 1; i <= D; ++i) {
+    const int ci = e->states[ss.conv[i - 1]].d1, fi = st.f0 >> (i - 1);
+    const ConvKind k = ci == 32 ? CONV_EL_C32 : ci == 64 ? CONV_EL_C64 : CONV_EL_C128;
+    float *d0, *d1 = nullptr;
+    int l0, l1 = 0;
+    if (i < D) {
+      d0 = cur(ss.conv[i]); l0 = e->states[ss.conv[i]].d1;
+      d1 = cur(ss.spconv[D - i]) + 32; l1 = 64;          // sub-pixel conv j = D-i+1 -> index D-i
+    } else {
+      d0 = cur(ss.spconv[0]) + 32; l0 = 64;
+    }
+    push_conv(e, plan, P + "_conv" + std::to_string(i), k, prev(ss.conv[i - 1]), cur(ss.conv[i - 1]), ci, fi, fi / 2, d0, l0,
+              d1, l1, 1, 0, side == 0);
+  }
+  // d_0 = Dense(LSTM(flatten(e_D)))  -> channels [0,32) of the first sub-pixel conv's input
+  push_lstm(e, plan, P + "_lstm", cur(ss.spconv[0]) + 32, 64, FD, 32, cur(ss.spconv[0]), 64, FD, 32, ss.h, ss.c, par);
+  // d_j = DL_j([prev_j ; cur_j])
+  const float* dD = nullptr;
+  int dD_ld = 0;
+  for (int j = 1; j <= D; ++j) {
+    const int fj = FD << (j - 1);
+    float *d0, *d1 = nullptr;
+    int l0, l1 = 0;
+    if (j < D) {
+      d0 = cur(ss.spconv[j]); l0 = 64;
+      if (pair_dec) { d1 = cur(pair_dec->conv[D - j]) + 32; l1 = 64; }   // decoder conv i = D-j+1 (second-level skip)
+      push_conv(e, plan, P + "_spconv" + std::to_string(j), CONV_DL_N64, prev(ss.spconv[j - 1]), cur(ss.spconv[j - 1]), 64, fj,
+                fj, d0, l0, d1, l1, 2, 0);
+    } else {
+      if (pair_dec) { d0 = cur(pair_dec->conv[0]) + 64; l0 = 128; }      // skip into decoder conv 1
+      else { d0 = e->t_d; l0 = 64; }
+      dD = d0; dD_ld = l0;
+      push_conv(e, plan, P + "_spconv" + std::to_string(j), CONV_DL_N128, prev(ss.spconv[j - 1]), cur(ss.spconv[j - 1]), 64, fj,
+                fj, d0, l0, nullptr, 0, 2, 0);
+    }
+  }
+  // y = d_D * (TA*FA) + e0
+  Launch L{};
+  L.kind = Launch::CTFA;
+  L.name = P + "_ctfa";
+  CtfaParams& c = L.ctfa;
+  const CtfaW& ta = e->ctfaw.at(P + "_ta");
+  const CtfaW& fa = e->ctfaw.at(P + "_fa");
+  c.x = dD; c.x_ld = dD_ld; c.e0 = cur(ss.conv[0]); c.e0_ld = c1; c.y = y_dst; c.y_ld = y_ld;
+  c.ta_w1T = ta.w1T; c.ta_b1 = ta.b1; c.ta_w2T = ta.w2T; c.ta_b2 = ta.b2;
+  c.fa_w1T = fa.w1T; c.fa_b1 = fa.b1; c.fa_w2T = fa.w2T; c.fa_b2 = fa.b2;
+  c.B = e->B; c.F = st.f0;
+  plan->push_back(L);
+}
+
+static void build_plan(Engine* e, int par) {
+  std::vector<Launch>* plan = &e->plan[par];
+  plan->clear();
+  {
+    Launch L{};
+    L.kind = Launch::INLAYER;
+    L.name = "input_layer";
+    L.inl = InLayerParams{e->io_in, e->t_inlayer, e->in_w, e->in_b, e->in_g, e->in_bt, e->in_alpha, e->B * NUTLS_BINS};
+    plan->push_back(L);
+  }
+  const float* x = e->t_inlayer;
+  int x_ld = 64;
+  for (int s = 0; s < 6; ++s) {
+    const StageDesc& st = kEncoder[s];
+    build_stage(e, plan, 0, s, par, x, x_ld, e->t_y, 64);
+    // down-sampling output lives in channels [64,128) of the paired decoder's up-sampling input
+    float* cat = e->upcat[decoder_of_encoder(s)];
+    push_conv(e, plan, st.resample, CONV_DOWN, e->t_y, nullptr, 64, st.f0, st.f0 / 2, cat + 64, 128, nullptr, 0, 1, 0);
+    x = cat + 64;
+    x_ld = 128;
+  }
+  // central LSTM over flatten([4,64]) (converter_proposed.py:456-459)
+  push_lstm(e, plan, "lstm", e->upcat[0] + 64, 128, 4, 64, e->upcat[0], 128, 4, 64, e->central_h, e->central_c, par);
+  for (int s = 0; s < 6; ++s) {
+    const StageDesc& st = kDecoder[s];
+    const int fin = st.f0 / 2;
+    push_conv(e, plan, std::string(st.resample) + "#even", CONV_UP_EVEN, e->upcat[s], nullptr, 128, fin, fin, e->t_up, 128, nullptr,
+              0, 2, 0);
+    push_conv(e, plan, std::string(st.resample) + "#odd", CONV_UP_ODD, e->upcat[s], nullptr, 128, fin, fin, e->t_up, 128, nullptr, 0,
+              2, 1);
+    float* y = (s < 5) ? e->upcat[s + 1] : e->t_y;
+    build_stage(e, plan, 1, s, par, e->t_up, 128, y, (s < 5) ? 128 : 64);
+  }
+  Launch L{};
+  L.kind = Launch::OUTCONV;
+  L.name = "out_conv";
+  L.outc = OutConvParams{e->t_y, 64, e->io_out, e->out_w, e->out_bias, e->B * NUTLS_BINS};
+  plan->push_back(L);
+}
+
+static hipError_t run_launch(const Launch& L, hipStream_t s) {
+  switch (L.kind) {
+    case Launch::CONV: return launch_conv(L.ck, L.conv, s);
+    case Launch::LSTM: return launch_lstm(L.lstm, s);
+    case Launch::CTFA: return launch_ctfa(L.ctfa, s);
+    case Launch::INLAYER: return launch_input_layer(L.inl, s);
+    case Launch::OUTCONV: return launch_out_conv(L.outc, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+static int run_plan(Engine* e, int par, hipStream_t s) {
+  for (const Launch& L : e->plan[par]) {
+    hipError_t err = run_launch(L, s);
+    if (err != hipSuccess) return fail(NUTLS_ERR_HIP, "launch " + L.name + ": " + hipGetErrorString(err));
+  }
+  return NUTLS_OK;
+}
+
+static int capture_graphs(Engine* e) {
+  for (int par = 0; par < 2; ++par) {
+    if (e->gexec[par]) continue;
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_plan(e, par, e->stream);
+    hipError_t ee = hipStreamEndCapture(e->stream, &g);
+    if (rc) return rc;
+    if (ee != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+    hipError_t ie = hipGraphInstantiate(&e->gexec[par], g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+  }
+  return NUTLS_OK;
+}
+
+}  // namespace nutls
+
+// =================================================================================================
+//  C ABI
+// =================================================================================================
+using namespace nutls;
+
+struct nutls_handle {
+  Engine eng;
+};
+
+extern "C" {
+
+const char* nutls_last_error(void) { return g_last_error.c_str(); }
+const char* nutls_version(void) { return "nutls-hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, int device, nutls_handle** out) {
+  if (!weights || !out || batch < 1) return fail(NUTLS_ERR_ARG, "nutls_create: null pointer or batch < 1");
+  if (variant != NUTLS_VARIANT_LSTM) return fail(NUTLS_ERR_ARG, "nutls_create: unknown variant");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(NUTLS_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(NUTLS_ERR_ARG, "nutls_create: device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NUTLS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  WeightMap wm;
+  std::string err;
+  if (!parse_weight_blob(weights, n_bytes, &wm, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
+  std::unique_ptr<nutls_handle> h(new nutls_handle());
+  Engine* e = &h->eng;
+  e->B = batch;
+  e->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  int rc;
+  if ((rc = prep_weights(e, wm))) return rc;
+  if ((rc = build_states(e))) return rc;
+  const size_t B = static_cast<size_t>(batch);
+  if ((rc = dev_alloc(e, B * NUTLS_BINS, &e->io_in, true))) return rc;
+  if ((rc = dev_alloc(e, B * NUTLS_BINS, &e->io_out, true))) return rc;
+  if ((rc = dev_alloc(e, B * 256 * 64, &e->t_inlayer, true))) return rc;
+  if ((rc = dev_alloc(e, B * 256 * 64, &e->t_y, true))) return rc;
+  if ((rc = dev_alloc(e, B * 256 * 64, &e->t_d, true))) return rc;
+  if ((rc = dev_alloc(e, B * 256 * 128, &e->t_up, true))) return rc;
+  for (int s = 0; s < 6; ++s)
+    if ((rc = dev_alloc(e, B * (kDecoder[s].f0 / 2) * 128, &e->upcat[s], true))) return rc;
+  build_plan(e, 0);
+  build_plan(e, 1);
+  e->debug["input_layer"] = {e->t_inlayer, 256 * 64};
+  e->debug["msfe6_de.y"] = {e->t_y, 256 * 64};
+  e->debug["msfe6_de.up"] = {e->t_up, 256 * 128};
+  e->debug["msfe6_de.d"] = {e->t_d, 256 * 64};
+  for (int s = 0; s < 6; ++s) e->debug[std::string(kDecoder[s].prefix) + ".upcat"] = {e->upcat[s], static_cast<size_t>(kDecoder[s].f0 / 2) * 128};
+  HIP_TRY(hipDeviceSynchronize());
+  *out = h.release();
+  return NUTLS_OK;
+}
+
+int nutls_destroy(nutls_handle* h) {
+  if (!h) return NUTLS_OK;
+  (void)hipSetDevice(h->eng.device);
+  (void)hipDeviceSynchronize();
+  delete h;
+  return NUTLS_OK;
+}
+
+int nutls_batch(nutls_handle* h) { return h ? h->eng.B : fail(NUTLS_ERR_ARG, "null handle"); }
+int nutls_launches_per_step(nutls_handle* h) { return h ? static_cast<int>(h->eng.plan[0].size()) : fail(NUTLS_ERR_ARG, "null handle"); }
+
+int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out) {
+  if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_io_buffers: null pointer");
+  *mag_in = h->eng.io_in;
+  *mag_out = h->eng.io_out;
+  return NUTLS_OK;
+}
+
+int nutls_use_graph(nutls_handle* h, int enable) {
+  if (!h) return fail(NUTLS_ERR_ARG, "null handle");
+  Engine* e = &h->eng;
+  HIP_TRY(hipSetDevice(e->device));
+  if (enable) {
+    int rc = capture_graphs(e);
+    if (rc) return rc;
+  }
+  e->use_graph = enable != 0;
+  return NUTLS_OK;
+}
+
+int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* stream) {
+  if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_step: null pointer");
+  Engine* e = &h->eng;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t bytes = static_cast<size_t>(e->B) * NUTLS_BINS * sizeof(float);
+  if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
+  const int par = e->next_parity;
+  if (e->use_graph) {
+    HIP_TRY(hipGraphLaunch(e->gexec[par], s));
+  } else {
+    int rc = run_plan(e, par, s);
+    if (rc) return rc;
+  }
+  if (mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
+  e->next_parity = 1 - par;
+  return NUTLS_OK;
+}
+
+int nutls_step_host(nutls_handle* h, const float* mag_in, float* mag_out) {
+  if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_step_host: null pointer");
+  Engine* e = &h->eng;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t bytes = static_cast<size_t>(e->B) * NUTLS_BINS * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyHostToDevice, e->stream));
+  int rc = nutls_step(h, e->io_in, e->io_out, e->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return NUTLS_OK;
+}
+
+int nutls_state_count(nutls_handle* h) { return h ? static_cast<int>(h->eng.states.size()) : fail(NUTLS_ERR_ARG, "null handle"); }
+
+int nutls_state_info(nutls_handle* h, int index, const char** name, int* dim0, int* dim1) {
+  if (!h || index < 0 || index >= static_cast<int>(h->eng.states.size())) return fail(NUTLS_ERR_ARG, "nutls_state_info: bad index");
+  const StateTensor& st = h->eng.states[index];
+  if (name) *name = st.name_prev.c_str();
+  if (dim0) *dim0 = st.d0;
+  if (dim1) *dim1 = st.d1;
+  return NUTLS_OK;
+}
+
+static int state_lookup(Engine* e, const char* name, size_t n_floats, StateTensor** out) {
+  if (!name) return fail(NUTLS_ERR_ARG, "state name is null");
+  auto it = e->state_index.find(name);
+  if (it == e->state_index.end()) return fail(NUTLS_ERR_ARG, std::string("unknown state tensor: ") + name);
+  StateTensor* st = &e->states[it->second];
+  if (n_floats != st->per_stream() * e->B)
+    return fail(NUTLS_ERR_ARG, std::string("size mismatch for ") + name + ": expected " + std::to_string(st->per_stream() * e->B) +
+                                   " floats, got " + std::to_string(n_floats));
+  *out = st;
+  return NUTLS_OK;
+}
+
+int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats) {
+  if (!h || !host_buf) return fail(NUTLS_ERR_ARG, "nutls_state_get: null pointer");
+  Engine* e = &h->eng;
+  StateTensor* st;
+  int rc = state_lookup(e, name, n_floats, &st);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_buf, st->buf[1 - e->next_parity], n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return NUTLS_OK;
+}
+
+int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, size_t n_floats) {
+  if (!h || !host_buf) return fail(NUTLS_ERR_ARG, "nutls_state_set: null pointer");
+  Engine* e = &h->eng;
+  StateTensor* st;
+  int rc = state_lookup(e, name, n_floats, &st);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(st->buf[1 - e->next_parity], host_buf, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  return NUTLS_OK;
+}
+
+int nutls_reset(nutls_handle* h, int stream_idx) {
+  if (!h) return fail(NUTLS_ERR_ARG, "null handle");
+  Engine* e = &h->eng;
+  if (stream_idx >= e->B) return fail(NUTLS_ERR_ARG, "nutls_reset: stream index out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  for (StateTensor& st : e->states)
+    for (int i = 0; i < 2; ++i) {
+      if (stream_idx < 0) HIP_TRY(hipMemset(st.buf[i], 0, st.per_stream() * e->B * sizeof(float)));
+      else HIP_TRY(hipMemset(st.buf[i] + st.per_stream() * stream_idx, 0, st.per_stream() * sizeof(float)));
+    }
+  HIP_TRY(hipDeviceSynchronize());
+  return NUTLS_OK;
+}
+
+int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats) {
+  if (!h || !name || !host_buf) return fail(NUTLS_ERR_ARG, "nutls_debug_get: null pointer");
+  Engine* e = &h->eng;
+  auto it = e->debug.find(name);
+  if (it == e->debug.end()) return fail(NUTLS_ERR_ARG, std::string("unknown debug tensor: ") + name);
+  if (n_floats != it->second.second * e->B) return fail(NUTLS_ERR_ARG, std::string("size mismatch for debug tensor ") + name);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_buf, it->second.first, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return NUTLS_OK;
+}
+
+int nutls_time_kernel(nutls_handle* h, int which, int iters, float* avg_ms) {
+  if (!h || !avg_ms || iters < 1) return fail(NUTLS_ERR_ARG, "nutls_time_kernel: bad argument");
+  Engine* e = &h->eng;
+  HIP_TRY(hipSetDevice(e->device));
+  std::vector<const Launch*> sel;
+  for (const Launch& L : e->plan[0]) {
+    if (which == 0 && L.name == "msfe6_en_spconv6") sel.push_back(&L);
+    if (which == 1 && L.name == "msfe6_en_conv1") sel.push_back(&L);
+    if (which == 2 && L.encoder_strided) sel.push_back(&L);
+  }
+  if (sel.empty()) return fail(NUTLS_ERR_ARG, "nutls_time_kernel: unknown selector");
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  for (const Launch* L : sel) HIP_TRY(run_launch(*L, e->stream));   // warm-up
+  HIP_TRY(hipEventRecord(e0, e->stream));
+  for (int i = 0; i < iters; ++i)
+    for (const Launch* L : sel) HIP_TRY(run_launch(*L, e->stream));
+  HIP_TRY(hipEventRecord(e1, e->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / iters;
+  return NUTLS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,452 @@
+// gfx950 (MI355X / CDNA4) kernels of the NUNet-TLS-LSTM frame step.  wave = 64 lanes.
+//
+// Data layout in HBM: every activation is channels-last fp32 rows, [stream][frequency][channel];
+// a "row" is the C channels of one (stream, frequency bin).  All conv-like layers
+// (reference: models/proposed.py:198-265) are evaluated as output-stationary GEMMs on the
+// fp32 matrix cores, v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain):
+//
+//     D[ch, pos] += W[ch, k] * X[k, pos]        ch -> MFMA rows (A operand = weights)
+//                                               pos -> MFMA columns = lanes (B operand = activations)
+//     k = (time tap, frequency tap, input channel)
+//
+// With positions on lanes, the 32 (or 64) channels of one position sit in the 16 accumulator
+// registers of lanes l and l+32, so the per-position LayerNorm (over channels) is a register
+// reduction plus ONE cross-lane exchange, and the result leaves as 16-byte channels-last stores.
+#include <hip/hip_runtime.h>
+
+#include "nutls_internal.hpp"
+
+namespace nutls {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LN_EPS 1e-8f   // models/proposed.py:202  LayerNormalization(epsilon=1e-8)
+
+// ================================================================================================
+//  Generic tap-GEMM convolution
+//
+//  One wave owns 32 consecutive output positions (flattened (stream, f_out)) x 32*NT output
+//  channels.  A workgroup of NW waves stages, per (time tap, 64-channel chunk), the input rows its
+//  32*NW positions touch into LDS (16-byte coalesced global reads, rows zero-filled outside the
+//  stream = the ZeroPadding2D of proposed.py:210/:242), then every lane reads its B fragment with one
+//  ds_read_b128 per 8 input channels:  lane (pos p, half h) gets channels 8g+4h..8g+4h+3 of row
+//  (s*p + kf), which feed 4 MFMA k-steps.  The LDS row pitch CC+4 (stride 1) or 2*CC+4 per row
+//  *pair* (stride 2: rows 2r and 2r+1 share a pitch unit) makes the 16-lane ds_read_b128 groups
+//  hit 16 distinct 4-bank slots.  Weights stream from L2 in fragment order (1 KiB per wave load).
+// ================================================================================================
+template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int G, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(const ConvParams p) {
+  constexpr int CC = CIN < 64 ? CIN : 64;
+  constexpr int NCH = CIN / CC;
+  constexpr int TP = 32 * NW;
+  constexpr int PITCH = (STRIDE == 1) ? (CC + 4) : (2 * CC + 4);
+  constexpr int R = NT / G;
+  static_assert(NT % G == 0, "groups must tile the channel tiles");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int pl = lane & 31, h = lane >> 5;
+  const int F_out = p.F_out, log2f = p.log2_fout;
+  const int seg_len = F_out < TP ? F_out : TP;          // power of two
+  const int nseg = TP / seg_len;
+  const int RS = (STRIDE == 1) ? (seg_len + KF - 1) : (seg_len + (KF - 1) / 2);  // LDS rows(-pairs)/segment
+  const int LR = (STRIDE == 1) ? RS : 2 * RS;                                    // input rows staged/segment
+  const int P0 = blockIdx.x * TP;
+  const int total_pos = p.B << log2f;
+
+  const int ploc = wave * 32 + pl;
+  const int myseg = ploc / seg_len, myfl = ploc - myseg * seg_len;
+  const int lbase = (myseg * RS + myfl) * PITCH + 4 * h;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  const f32x4* wp = reinterpret_cast<const f32x4*>(p.wpk) + lane;
+  const int rows_total = nseg * LR;
+
+#pragma unroll 1
+  for (int t = 0; t < TT; ++t) {
+    const float* src = (TT == 2 && t == 1) ? p.src1 : p.src0;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (t + ch > 0) __syncthreads();   // all waves finished reading the previous phase
+      // ---------------- stage input rows -> LDS -----------------------------------------------
+      for (int q = tid; q < rows_total * (CC / 4); q += 64 * NW) {
+        const int c4 = q % (CC / 4);
+        const int rr = q / (CC / 4);
+        const int sg = rr / LR, lr = rr - sg * LR;
+        const int pseg = P0 + sg * seg_len;
+        const int b = pseg >> log2f, f0 = pseg & (F_out - 1);
+        const int gr = STRIDE * f0 - PADL + lr;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < p.B && gr >= 0 && gr < p.F_in)
+          v = *reinterpret_cast<const f32x4*>(src + (static_cast<size_t>(b) * p.F_in + gr) * p.src_ld + ch * CC + 4 * c4);
+        const int la = (STRIDE == 1) ? ((sg * RS + lr) * PITCH + 4 * c4)
+                                     : ((sg * RS + (lr >> 1)) * PITCH + (lr & 1) * CC + 4 * c4);
+        *reinterpret_cast<f32x4*>(lds + la) = v;
+      }
+      __syncthreads();
+      // ---------------- MFMA over (frequency tap, channel group) --------------------------------
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf) {
+        const int koff = (STRIDE == 1) ? (kf * PITCH) : ((kf >> 1) * PITCH + (kf & 1) * CC);
+#pragma unroll
+        for (int g = 0; g < CC / 8; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds + lbase + koff + 8 * g);
+          f32x4 a4[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) a4[n] = wp[n * 64];
+          wp += NT * 64;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[n][j], b4[j], acc[n], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---------------- epilogue: bias (+ LayerNorm over the group's channels + PReLU), store ------
+  // accumulator register r of lane (pos, h) holds channel  tile*32 + 8*(r>>2) + 4*h + (r&3)
+  const int P = P0 + ploc;
+  const bool valid = P < total_pos;
+  const int b = P >> log2f, f = P & (F_out - 1);
+  const size_t row0 = static_cast<size_t>(b) * (F_out * p.row_mul) + f * p.row_mul + p.row_add;
+#pragma unroll
+  for (int gi = 0; gi < R; ++gi) {
+    float v[G][16];
+#pragma unroll
+    for (int tg = 0; tg < G; ++tg) {
+      const int n = gi * G + tg;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[tg][4 * q + i] = acc[n][4 * q + i] + bb[i];
+      }
+    }
+    if (EPI_LN) {
+      constexpr float inv_n = 1.0f / (32 * G);
+      float s = 0.f;
+#pragma unroll
+      for (int tg = 0; tg < G; ++tg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[tg][r];
+      s += __shfl_xor(s, 32);
+      const float mean = s * inv_n;
+      float qv = 0.f;
+#pragma unroll
+      for (int tg = 0; tg < G; ++tg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[tg][r] -= mean;
+          qv += v[tg][r] * v[tg][r];
+        }
+      qv += __shfl_xor(qv, 32);
+      const float rstd = 1.0f / sqrtf(qv * inv_n + LN_EPS);
+#pragma unroll
+      for (int tg = 0; tg < G; ++tg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + tg * 32 + 8 * q + 4 * h);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + tg * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float y = v[tg][4 * q + i] * rstd * gm[i] + bt[i];
+            v[tg][4 * q + i] = y >= 0.f ? y : p.alpha * y;
+          }
+        }
+    }
+    if (valid) {
+      const size_t row = row0 + gi;
+#pragma unroll
+      for (int tg = 0; tg < G; ++tg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = {v[tg][4 * q], v[tg][4 * q + 1], v[tg][4 * q + 2], v[tg][4 * q + 3]};
+          const int c = tg * 32 + 8 * q + 4 * h;
+          *reinterpret_cast<f32x4*>(p.dst0 + row * p.ld0 + c) = o;
+          if (p.dst1) *reinterpret_cast<f32x4*>(p.dst1 + row * p.ld1 + c) = o;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+ConvShape conv_shape(ConvKind k) {
+  switch (k) {
+    //                         cin  nt  s  tt kf padl ln g
+    case CONV_EL_C32:   return {32,  1, 2, 2, 3, 1, 1, 1};
+    case CONV_EL_C64:   return {64,  1, 2, 2, 3, 1, 1, 1};
+    case CONV_EL_C128:  return {128, 1, 2, 2, 3, 1, 1, 1};
+    case CONV_DL_N64:   return {64,  2, 1, 2, 3, 1, 1, 1};
+    case CONV_DL_N128:  return {64,  4, 1, 2, 3, 1, 1, 2};
+    case CONV_IN_C64:   return {64,  2, 1, 1, 1, 0, 1, 2};
+    case CONV_IN_C128:  return {128, 2, 1, 1, 1, 0, 1, 2};
+    case CONV_DOWN:     return {64,  2, 2, 1, 3, 0, 0, 2};
+    case CONV_UP_EVEN:  return {128, 4, 1, 1, 2, 1, 0, 4};
+    case CONV_UP_ODD:   return {128, 4, 1, 1, 1, 0, 0, 4};
+    default:            return {0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+
+size_t conv_lds_bytes(ConvKind k, int f_out, int nw) {
+  const ConvShape s = conv_shape(k);
+  const int cc = s.cin < 64 ? s.cin : 64;
+  const int tp = 32 * nw;
+  const int seg_len = f_out < tp ? f_out : tp;
+  const int nseg = tp / seg_len;
+  const int pitch = s.stride == 1 ? cc + 4 : 2 * cc + 4;
+  const int rs = s.stride == 1 ? seg_len + s.kf - 1 : seg_len + (s.kf - 1) / 2;
+  return static_cast<size_t>(nseg) * rs * pitch * sizeof(float);
+}
+
+int conv_pick_nw(ConvKind, int B, int f_out) {
+  // 4-wave workgroups (128 positions) once there are enough positions to give every CU several
+  // workgroups; single-wave workgroups otherwise so small layers spread over more CUs.
+  return (static_cast<long long>(B) * f_out >= 128LL * 512) ? 4 : 1;
+}
+
+template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int G>
+static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) {
+  const int nw = conv_pick_nw(k, p.B, p.F_out);
+  const size_t lds = conv_lds_bytes(k, p.F_out, nw);
+  const long long total = static_cast<long long>(p.B) * p.F_out;
+  if (nw == 4) {
+    auto kern = conv_mfma_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4>;
+    static size_t lds_cap = 64 * 1024;   // raise the dynamic-LDS cap once per instantiation
+    if (lds > lds_cap) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return e;
+      lds_cap = lds;
+    }
+    const unsigned grid = static_cast<unsigned>((total + 127) / 128);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
+  } else {
+    auto kern = conv_mfma_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1>;
+    static size_t lds_cap = 64 * 1024;   // raise the dynamic-LDS cap once per instantiation
+    if (lds > lds_cap) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return e;
+      lds_cap = lds;
+    }
+    const unsigned grid = static_cast<unsigned>((total + 31) / 32);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_conv(ConvKind k, const ConvParams& p, hipStream_t s) {
+  switch (k) {
+    case CONV_EL_C32:   return launch_conv_t<32,  1, 2, 2, 3, 1, 1, 1>(k, p, s);
+    case CONV_EL_C64:   return launch_conv_t<64,  1, 2, 2, 3, 1, 1, 1>(k, p, s);
+    case CONV_EL_C128:  return launch_conv_t<128, 1, 2, 2, 3, 1, 1, 1>(k, p, s);
+    case CONV_DL_N64:   return launch_conv_t<64,  2, 1, 2, 3, 1, 1, 1>(k, p, s);
+    case CONV_DL_N128:  return launch_conv_t<64,  4, 1, 2, 3, 1, 1, 2>(k, p, s);
+    case CONV_IN_C64:   return launch_conv_t<64,  2, 1, 1, 1, 0, 1, 2>(k, p, s);
+    case CONV_IN_C128:  return launch_conv_t<128, 2, 1, 1, 1, 0, 1, 2>(k, p, s);
+    case CONV_DOWN:     return launch_conv_t<64,  2, 2, 1, 3, 0, 0, 2>(k, p, s);
+    case CONV_UP_EVEN:  return launch_conv_t<128, 4, 1, 1, 2, 1, 0, 4>(k, p, s);
+    case CONV_UP_ODD:   return launch_conv_t<128, 4, 1, 1, 1, 0, 0, 4>(k, p, s);
+    default:            return hipErrorInvalidValue;
+  }
+}
+
+// ================================================================================================
+//  LSTM cell (21 units, gates i,f,g,o) + Dense  -- models/proposed.py:70-119, used at
+//  converter_proposed.py:234-237.  One workgroup per stream; the flattened [F_D, 32] bottleneck
+//  (F major, C minor) is gathered into LDS, thread n < 84 owns gate pre-activation n, weights are
+//  stored transposed ([k][n]) so the 84 threads read consecutive floats.
+// ================================================================================================
+#define LSTM_UNITS 21
+#define LSTM_GATES 84
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(128) void lstm_dense_kernel(const LstmParams p) {
+  __shared__ float v[256];
+  __shared__ float hs[32];
+  __shared__ float z[96];
+  __shared__ float hn[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < p.Din; k += 128) {
+    const int f = k / p.x_cols, c = k - f * p.x_cols;
+    v[k] = p.x[(static_cast<size_t>(b) * p.x_rows + f) * p.x_ld + c];
+  }
+  if (tid < LSTM_UNITS) hs[tid] = p.h_in[static_cast<size_t>(b) * LSTM_UNITS + tid];
+  __syncthreads();
+  if (tid < LSTM_GATES) {
+    float a = p.bias[tid];
+    for (int k = 0; k < p.Din; ++k) a = fmaf(p.wxT[k * LSTM_GATES + tid], v[k], a);
+    float r = 0.f;
+    for (int u = 0; u < LSTM_UNITS; ++u) r = fmaf(p.whT[u * LSTM_GATES + tid], hs[u], r);
+    z[tid] = a + r;
+  }
+  __syncthreads();
+  if (tid < LSTM_UNITS) {
+    const float gi = sigmoid_f(z[tid]);
+    const float gf = sigmoid_f(z[LSTM_UNITS + tid]);
+    const float gg = tanhf(z[2 * LSTM_UNITS + tid]);
+    const float go = sigmoid_f(z[3 * LSTM_UNITS + tid]);
+    const float c_old = p.c_in[static_cast<size_t>(b) * LSTM_UNITS + tid];
+    const float c_new = gf * c_old + gi * gg;
+    const float h_new = go * tanhf(c_new);
+    p.c_out[static_cast<size_t>(b) * LSTM_UNITS + tid] = c_new;
+    p.h_out[static_cast<size_t>(b) * LSTM_UNITS + tid] = h_new;
+    hn[tid] = h_new;
+  }
+  __syncthreads();
+  for (int m = tid; m < p.Dout; m += 128) {
+    float a = p.bd[m];
+#pragma unroll
+    for (int u = 0; u < LSTM_UNITS; ++u) a = fmaf(p.wdT[u * p.Dout + m], hn[u], a);
+    const int f = m / p.dst_cols, c = m - f * p.dst_cols;
+    p.dst[(static_cast<size_t>(b) * p.dst_rows + f) * p.dst_ld + c] = a;
+  }
+}
+
+hipError_t launch_lstm(const LstmParams& p, hipStream_t s) {
+  if (p.Din > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lstm_dense_kernel, dim3(p.B), dim3(128), 0, s, p);
+  return hipGetLastError();
+}
+
+// ================================================================================================
+//  CTFA gate + residual -- ctfa_rt (models/proposed.py:162-196) as wired at
+//  converter_proposed.py:258-262:   y = x * (TA * FA) + e0
+//      TA = sigmoid(W2 relu(W1 mean_f(x) + b1) + b2)
+//      FA = sigmoid(V2 relu(V1 (TA/32) + c1) + c2)      (T = 1: the 32-frame average pool sees
+//                                                          31 zero frames + TA)
+//  One workgroup per stream: 16 row-groups x 16 float4 channel groups reduce the mean over F in
+//  LDS, 64 threads run the two 64->16->64 MLPs, then all threads apply the gate (x re-read from L2).
+// ================================================================================================
+__global__ __launch_bounds__(256) void ctfa_kernel(const CtfaParams p) {
+  __shared__ __attribute__((aligned(16))) float part[16][64];
+  __shared__ float m[64];
+  __shared__ float hid[16];
+  __shared__ float ta[64];
+  __shared__ __attribute__((aligned(16))) float gate[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c4 = tid & 15, rg = tid >> 4;
+  const float* xb = p.x + static_cast<size_t>(b) * p.F * p.x_ld;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int f = rg; f < p.F; f += 16) s += *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
+  *reinterpret_cast<f32x4*>(&part[rg][4 * c4]) = s;
+  __syncthreads();
+  if (tid < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += part[r][tid];
+    m[tid] = a / static_cast<float>(p.F);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float a = p.ta_b1[tid];
+    for (int c = 0; c < 64; ++c) a = fmaf(p.ta_w1T[c * 16 + tid], m[c], a);
+    hid[tid] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float a = p.ta_b2[tid];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a = fmaf(p.ta_w2T[u * 64 + tid], hid[u], a);
+    ta[tid] = sigmoid_f(a);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float a = p.fa_b1[tid];
+    for (int c = 0; c < 64; ++c) a = fmaf(p.fa_w1T[c * 16 + tid], ta[c] * (1.0f / 32.0f), a);
+    hid[tid] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float a = p.fa_b2[tid];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a = fmaf(p.fa_w2T[u * 64 + tid], hid[u], a);
+    gate[tid] = sigmoid_f(a) * ta[tid];
+  }
+  __syncthreads();
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(&gate[4 * c4]);
+  const float* eb = p.e0 + static_cast<size_t>(b) * p.F * p.e0_ld;
+  float* yb = p.y + static_cast<size_t>(b) * p.F * p.y_ld;
+  for (int f = rg; f < p.F; f += 16) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
+    const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
+    *reinterpret_cast<f32x4*>(yb + static_cast<size_t>(f) * p.y_ld + 4 * c4) = xv * g4 + ev;
+  }
+}
+
+hipError_t launch_ctfa(const CtfaParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(ctfa_kernel, dim3(p.B), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// ================================================================================================
+//  input_layer: 1x1 conv 1 -> 64 + LN + PReLU (models/proposed.py:218-225 with Cin = 1).
+//  16 lanes per position, 4 channels per lane; LayerNorm reduces across the 16 lanes.
+// ================================================================================================
+__global__ __launch_bounds__(256) void input_layer_kernel(const InLayerParams p) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int pos = gid >> 4, c4 = gid & 15;
+  const bool valid = pos < p.n_pos;
+  const float x = valid ? p.x[pos] : 0.f;
+  const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + 4 * c4);
+  const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b + 4 * c4);
+  f32x4 y = w * x + bb;
+  float s = y[0] + y[1] + y[2] + y[3];
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.0f / 64.0f);
+  y -= mean;
+  float q = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + 4 * c4);
+  const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + 4 * c4);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t = y[i] * rstd * gm[i] + bt[i];
+    o[i] = t >= 0.f ? t : p.alpha * t;
+  }
+  if (valid) *reinterpret_cast<f32x4*>(p.y + static_cast<size_t>(pos) * 64 + 4 * c4) = o;
+}
+
+hipError_t launch_input_layer(const InLayerParams& p, hipStream_t s) {
+  const unsigned grid = static_cast<unsigned>((static_cast<long long>(p.n_pos) * 16 + 255) / 256);
+  hipLaunchKernelGGL(input_layer_kernel, dim3(grid), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// ================================================================================================
+//  output conv: 1x1, 64 -> 1, linear (models/proposed.py:65, :1146)
+// ================================================================================================
+__global__ __launch_bounds__(256) void out_conv_kernel(const OutConvParams p) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int pos = gid >> 4, c4 = gid & 15;
+  const bool valid = pos < p.n_pos;
+  float s = 0.f;
+  if (valid) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + static_cast<size_t>(pos) * p.x_ld + 4 * c4);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + 4 * c4);
+    s = xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+  if (valid && c4 == 0) p.y[pos] = s + p.bias;
+}
+
+hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s) {
+  const unsigned grid = static_cast<unsigned>((static_cast<long long>(p.n_pos) * 16 + 255) / 256);
+  hipLaunchKernelGGL(out_conv_kernel, dim3(grid), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace nutls

@@ -1,0 +1,116 @@
+// Internal declarations shared by the host engine (engine.cpp), the weight container
+// parser (weights.cpp) and the gfx950 kernels (kernels.hip).  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace nutls {
+
+// ------------------------------------------------------------------ weight container ----------
+struct HostTensor {
+  std::vector<int> dims;
+  std::vector<float> data;  // de-quantised (int8 * scale), exactly the graph's DEQUANTIZE
+  size_t size() const { return data.size(); }
+};
+using WeightMap = std::map<std::string, HostTensor>;
+
+// Parses a NUTLSW01 container (layout: tools/convert_tflite_weights.py).  Returns false and
+// fills `err` on malformed input.
+bool parse_weight_blob(const void* blob, size_t n, WeightMap* out, std::string* err);
+
+// ------------------------------------------------------------------ kernel parameters ---------
+// Generic "tap-GEMM" convolution over channels-last rows (see kernels.hip for the tiling).
+struct ConvParams {
+  const float* src0;   // time tap 0 (previous frame) -- or the only input when TT == 1
+  const float* src1;   // time tap 1 (current frame)
+  const float* wpk;    // weights in MFMA fragment order (pack_conv_weights)
+  const float* bias;   // [32*NT]  packed channel order
+  const float* gamma;  // [32*G]   LayerNorm scale (EPI_LN only)
+  const float* beta;   // [32*G]
+  float* dst0;         // first destination (never null)
+  float* dst1;         // optional second destination (skip-connection copy) or null
+  int src_ld;          // floats between consecutive input rows
+  int ld0, ld1;        // floats between consecutive output rows of dst0 / dst1
+  int B, F_in, F_out;  // streams, input rows per stream, output positions per stream
+  int log2_fout;
+  int row_mul, row_add;  // output row of position f, group g:  f*row_mul + row_add + g
+  float alpha;           // PReLU slope
+};
+
+enum ConvKind : int {
+  CONV_EL_C32 = 0,   // (2,3) stride-2, Cin 32  -> 32, LN+PReLU      (encoder levels >= 2)
+  CONV_EL_C64,       // (2,3) stride-2, Cin 64  -> 32                 (encoder level 1, decoder levels >= 2)
+  CONV_EL_C128,      // (2,3) stride-2, Cin 128 -> 32                 (decoder level 1)
+  CONV_DL_N64,       // (2,3) stride-1, Cin 64 -> 64 conv ch = 2 rows x 32, LN(32)+PReLU  (sub-pixel)
+  CONV_DL_N128,      // (2,3) stride-1, Cin 64 -> 128 conv ch = 2 rows x 64, LN(64)+PReLU (last sub-pixel)
+  CONV_IN_C64,       // 1x1, Cin 64  -> 64, LN(64)+PReLU
+  CONV_IN_C128,      // 1x1, Cin 128 -> 64, LN(64)+PReLU
+  CONV_DOWN,         // (1,3) stride-2, pad right, 64 -> 64, bias only
+  CONV_UP_EVEN,      // transposed (1,3) stride-2: even output rows  (taps x[i-1], x[i]), 128 -> 128
+  CONV_UP_ODD,       // transposed (1,3) stride-2: odd output rows   (tap x[i]),          128 -> 128
+  CONV_KIND_COUNT
+};
+
+struct ConvShape {  // static description of a ConvKind
+  int cin, nt, stride, tt, kf, padl, epi_ln, g;
+};
+ConvShape conv_shape(ConvKind k);
+// bytes of dynamic LDS one workgroup of `nw` waves needs for this kind at F_out
+size_t conv_lds_bytes(ConvKind k, int f_out, int nw);
+int conv_pick_nw(ConvKind k, int B, int f_out);
+hipError_t launch_conv(ConvKind k, const ConvParams& p, hipStream_t s);
+
+struct LstmParams {
+  const float* x; int x_ld, x_rows, x_cols;   // v[f*x_cols+c] = x[(b*x_rows+f)*x_ld + c]
+  const float* wxT;   // [Din][84]
+  const float* whT;   // [21][84]
+  const float* bias;  // [84]
+  const float* wdT;   // [21][Dout]
+  const float* bd;    // [Dout]
+  const float* h_in; const float* c_in; float* h_out; float* c_out;   // [B,21]
+  float* dst; int dst_ld, dst_rows, dst_cols;  // y[f*dst_cols+c] -> dst[(b*dst_rows+f)*dst_ld + c]
+  int Din, Dout, B;
+};
+hipError_t launch_lstm(const LstmParams& p, hipStream_t s);
+
+struct CtfaParams {
+  const float* x; int x_ld;      // d_D  [B,F,64]
+  const float* e0; int e0_ld;    // residual [B,F,64]
+  float* y; int y_ld;            // out  [B,F,64]
+  const float* ta_w1T; const float* ta_b1; const float* ta_w2T; const float* ta_b2;  // [64][16],[16],[16][64],[64]
+  const float* fa_w1T; const float* fa_b1; const float* fa_w2T; const float* fa_b2;
+  int B, F;
+};
+hipError_t launch_ctfa(const CtfaParams& p, hipStream_t s);
+
+struct InLayerParams {   // input_layer: 1x1 conv 1->64 + LN + PReLU
+  const float* x;        // [B,256]
+  float* y;              // [B,256,64]
+  const float* w; const float* b; const float* gamma; const float* beta; float alpha;
+  int n_pos;             // B*256
+};
+hipError_t launch_input_layer(const InLayerParams& p, hipStream_t s);
+
+struct OutConvParams {   // 1x1 conv 64->1
+  const float* x; int x_ld;   // [B,256,64]
+  float* y;                   // [B,256]
+  const float* w; float bias;
+  int n_pos;
+};
+hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
+
+
+// Packs OHWI conv weights [Cout][th][kw][Cin] into the order the MFMA loop streams them.
+//   perm[n'] = original output channel feeding packed channel n'
+//   taps     = list of (t, kw) source taps in kernel order (time-major)
+std::vector<float> pack_conv_weights(const HostTensor& w, const std::vector<int>& perm,
+                                     const std::vector<std::pair<int, int>>& taps_per_t,
+                                     int tt, int cin, int nt);
+
+}  // namespace nutls

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's model call surface, bound to the HIP library through
+the C ABI of ``include/nutls.h`` with ``ctypes``.
+
+* :class:`NutlsRunner` -- drop-in for the TF-Lite signature runner the reference obtains with
+  ``interpreter.get_signature_runner('nutls_lstm_sm')`` and calls once per frame with 131 named
+  tensors (``/root/reference/dnn_model/interpreter_proposed.py:380, 215-350``): same names,
+  shapes, dtypes, same ``ValueError`` on unknown / missing names or wrong shapes; batch 1.
+* :class:`NutlsEngine` -- the batched form of the same step: ``B`` independent streams, all 130
+  recurrent-state tensors resident in HBM, ``step(mag[B,256]) -> out[B,256]``.
+
+There is no CPU fallback: constructing either class without the built ``libnutls_hip.so`` or
+without a gfx950 GPU raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import topology as T
+from .weights import DEFAULT_WEIGHTS, read_blob
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnutls_hip.so")
+_lib = None
+
+NUTLS_ERR_ARG = -1
+
+# every symbol include/nutls.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "nutls_create", "nutls_destroy", "nutls_step", "nutls_step_host", "nutls_io_buffers",
+    "nutls_use_graph", "nutls_state_get", "nutls_state_set", "nutls_state_count",
+    "nutls_state_info", "nutls_reset", "nutls_debug_get", "nutls_batch",
+    "nutls_launches_per_step", "nutls_time_kernel", "nutls_last_error", "nutls_version",
+)
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the HIP library and declare the C ABI.  Fails loudly when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "HIP library %s not found -- build it with `python -m nunet_amd.build` "
+            "(there is no CPU fallback for the model step)" % p)
+    lib = ctypes.CDLL(p)
+    c = ctypes
+    fp = c.POINTER(c.c_float)
+    lib.nutls_create.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
+    lib.nutls_destroy.argtypes = [c.c_void_p]
+    lib.nutls_step.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nutls_step_host.argtypes = [c.c_void_p, fp, fp]
+    lib.nutls_io_buffers.argtypes = [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p)]
+    lib.nutls_use_graph.argtypes = [c.c_void_p, c.c_int]
+    lib.nutls_state_get.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
+    lib.nutls_state_set.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
+    lib.nutls_state_count.argtypes = [c.c_void_p]
+    lib.nutls_state_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    lib.nutls_reset.argtypes = [c.c_void_p, c.c_int]
+    lib.nutls_debug_get.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
+    lib.nutls_batch.argtypes = [c.c_void_p]
+    lib.nutls_launches_per_step.argtypes = [c.c_void_p]
+    lib.nutls_time_kernel.argtypes = [c.c_void_p, c.c_int, c.c_int, c.POINTER(c.c_float)]
+    lib.nutls_last_error.restype = c.c_char_p
+    lib.nutls_version.restype = c.c_char_p
+    for name in ABI_SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is None or fn.restype is c.c_int:
+            fn.restype = c.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int):
+    if rc == 0:
+        return
+    msg = lib.nutls_last_error().decode("utf-8", "replace")
+    if rc == NUTLS_ERR_ARG:
+        raise ValueError(msg)      # what TF-Lite raises for bad names / shapes
+    raise RuntimeError("nutls error %d: %s" % (rc, msg))
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+class NutlsEngine:
+    """B streams, device-resident state.  ``step`` takes/returns ``[B,256]`` magnitudes."""
+
+    def __init__(self, weights=None, batch: int = 1, device: int = 0, use_graph: bool = True):
+        self._lib = load_library()
+        blob = read_blob(weights if weights is not None else DEFAULT_WEIGHTS)
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        _check(self._lib, self._lib.nutls_create(buf, len(blob), 0, int(batch), int(device), ctypes.byref(self._h)))
+        self.batch = int(batch)
+        self.device = int(device)
+        pin, pout = ctypes.c_void_p(), ctypes.c_void_p()
+        _check(self._lib, self._lib.nutls_io_buffers(self._h, ctypes.byref(pin), ctypes.byref(pout)))
+        self.io_in_ptr, self.io_out_ptr = pin.value, pout.value
+        if use_graph:
+            self.use_graph(True)
+
+    # -- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nutls_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_graph(self, enable: bool = True):
+        _check(self._lib, self._lib.nutls_use_graph(self._h, 1 if enable else 0))
+
+    @property
+    def launches_per_step(self) -> int:
+        return self._lib.nutls_launches_per_step(self._h)
+
+    # -- the hot path ----------------------------------------------------------------------
+    def step(self, mag, out=None):
+        """One frame for all B streams.  ``mag``: ``[B,256]`` float32, either a torch tensor on
+        this engine's GPU (zero-copy, asynchronous on the current torch stream; ``out`` may be
+        a preallocated tensor) or a numpy array (H2D + step + D2H, synchronous)."""
+        if isinstance(mag, np.ndarray):
+            m = np.ascontiguousarray(mag, dtype=np.float32)
+            if m.shape != (self.batch, T.N_BINS):
+                raise ValueError("mag must be [%d,%d], got %s" % (self.batch, T.N_BINS, m.shape))
+            o = np.empty_like(m)
+            _check(self._lib, self._lib.nutls_step_host(self._h, _fptr(m), _fptr(o)))
+            return o
+        import torch
+        if not (torch.is_tensor(mag) and mag.is_cuda and mag.dtype == torch.float32 and mag.is_contiguous()):
+            raise ValueError("mag must be a contiguous float32 CUDA tensor or a numpy array")
+        if tuple(mag.shape) != (self.batch, T.N_BINS):
+            raise ValueError("mag must be [%d,%d], got %s" % (self.batch, T.N_BINS, tuple(mag.shape)))
+        if out is None:
+            out = torch.empty_like(mag)
+        stream = torch.cuda.current_stream(mag.device).cuda_stream
+        _check(self._lib, self._lib.nutls_step(self._h, mag.data_ptr(), out.data_ptr(), stream))
+        return out
+
+    def step_resident(self, stream: int = 0):
+        """Step on the library-owned I/O buffers (``io_in_ptr`` / ``io_out_ptr``): no copies."""
+        _check(self._lib, self._lib.nutls_step(self._h, self.io_in_ptr, self.io_out_ptr, stream))
+
+    # -- state -----------------------------------------------------------------------------
+    def state_specs(self) -> List[Tuple[str, Tuple[int, int]]]:
+        n = self._lib.nutls_state_count(self._h)
+        res = []
+        for i in range(n):
+            name, d0, d1 = ctypes.c_char_p(), ctypes.c_int(), ctypes.c_int()
+            _check(self._lib, self._lib.nutls_state_info(self._h, i, ctypes.byref(name), ctypes.byref(d0), ctypes.byref(d1)))
+            res.append((name.value.decode(), (d0.value, d1.value)))
+        return res
+
+    def _state_shape(self, name: str):
+        if not hasattr(self, "_shapes"):
+            self._shapes = {}
+            for n, (d0, d1) in self.state_specs():
+                self._shapes[n] = (d0, d1)
+                self._shapes[n.replace("_prev", "_cur")] = (d0, d1)
+        if name not in self._shapes:
+            raise ValueError("unknown state tensor: %s" % name)
+        return self._shapes[name]
+
+    def state_get(self, name: str) -> np.ndarray:
+        d0, d1 = self._state_shape(name)
+        a = np.empty((self.batch, d0, d1), np.float32)
+        _check(self._lib, self._lib.nutls_state_get(self._h, name.encode(), _fptr(a), a.size))
+        return a.reshape(self.batch, d0) if d1 == 1 and d0 == T.LSTM_UNITS else a
+
+    def state_set(self, name: str, value) -> None:
+        d0, d1 = self._state_shape(name)
+        a = np.ascontiguousarray(value, dtype=np.float32)
+        if a.size != self.batch * d0 * d1:
+            raise ValueError("size mismatch for %s: expected %d floats, got %d" % (name, self.batch * d0 * d1, a.size))
+        _check(self._lib, self._lib.nutls_state_set(self._h, name.encode(), _fptr(a), a.size))
+
+    def reset(self, stream_idx: int = -1) -> None:
+        _check(self._lib, self._lib.nutls_reset(self._h, int(stream_idx)))
+
+    def debug_get(self, name: str, per_stream_shape) -> np.ndarray:
+        a = np.empty((self.batch,) + tuple(per_stream_shape), np.float32)
+        _check(self._lib, self._lib.nutls_debug_get(self._h, name.encode(), _fptr(a), a.size))
+        return a
+
+    def time_kernel(self, which: int, iters: int = 20) -> float:
+        ms = ctypes.c_float()
+        _check(self._lib, self._lib.nutls_time_kernel(self._h, which, iters, ctypes.byref(ms)))
+        return float(ms.value)
+
+
+class NutlsRunner:
+    """``runner(input=..., msfe6_ee_prev1=..., ..., msfe6_de_c=...) -> dict`` exactly like the
+    reference's ``nutls_lstm_sm`` signature runner (interpreter_proposed.py:215-350), batch 1.
+
+    The caller owns the state arrays, as in the reference.  When it echoes back the very
+    arrays this runner returned last frame (what the reference loop does) the upload is
+    skipped, because the device already holds them."""
+
+    signature_key = "nutls_lstm_sm"
+
+    def __init__(self, weights=None, device: int = 0, use_graph: bool = True):
+        self.engine = NutlsEngine(weights, batch=1, device=device, use_graph=use_graph)
+        self._in_names = T.input_names()
+        self._specs = T.state_specs()
+        self._last: Dict[str, np.ndarray] = {}
+
+    def get_input_details(self) -> Dict[str, Tuple[int, ...]]:
+        d = {"input": (1, 1, T.N_BINS, 1)}
+        for base, shp in self._specs:
+            d[base.format("prev")] = (1, shp[0]) if len(shp) == 1 else (1,) + shp
+        return d
+
+    def __call__(self, **feeds) -> Dict[str, np.ndarray]:
+        names = set(self._in_names)
+        given = set(feeds)
+        if given != names:
+            raise ValueError("Invalid input names: unknown=%s missing=%s" % (sorted(given - names), sorted(names - given)))
+        x = np.asarray(feeds["input"])
+        if x.shape != (1, 1, T.N_BINS, 1) or x.dtype != np.float32:
+            raise ValueError("input must be float32 [1,1,256,1], got %s %s" % (x.dtype, x.shape))
+        eng = self.engine
+        for base, shp in self._specs:
+            k_in, k_out = base.format("prev"), base.format("cur")
+            a = feeds[k_in]
+            want = (1, shp[0]) if len(shp) == 1 else (1,) + shp
+            if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.shape != want:
+                raise ValueError("%s must be float32 %s" % (k_in, want))
+            if self._last.get(k_out) is not a:      # not the echo of our own output: upload
+                eng.state_set(k_in, a)
+        out = eng.step(x.reshape(1, T.N_BINS))
+        res = {"model_out": out.reshape(1, 1, T.N_BINS, 1)}
+        for base, shp in self._specs:
+            k_in, k_out = base.format("prev"), base.format("cur")
+            a = eng.state_get(k_in)
+            res[k_out] = a.reshape((1, shp[0]) if len(shp) == 1 else (1,) + shp)
+        self._last = res
+        return res
