@@ -97,10 +97,18 @@ int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n
 int nutls_batch(nutls_handle* h);
 int nutls_launches_per_step(nutls_handle* h);
 
-/* Time `iters` launches of the dominant kernel family member `which` (0 = largest sub-pixel conv,
- * 1 = largest encoder strided conv, 2 = whole encoder strided-conv stack) with HIP events on the
- * library's own stream; writes the average milliseconds per launch (or per stack). */
-int nutls_time_kernel(nutls_handle* h, int which, int iters, float* avg_ms);
+/* Introspection of the per-frame launch plan (nutls_launches_per_step entries, in issue order):
+ * layer name (reference Keras layer, e.g. "msfe6_en_spconv6"), kernel family (one family = one
+ * kernel symbol), and the ALGORITHMIC work of that launch for the handle's batch:
+ * flops = 2 * MACs, bytes = 4 * (input elements read incl. the previous-frame tap + output
+ * elements written)  -- the "layer-fused" traffic model of SURVEY.md section 8(d). */
+int nutls_launch_info(nutls_handle* h, int index, const char** layer, const char** family,
+                      double* flops, double* bytes);
+
+/* Run ONE step with plain launches on the library's own stream, bracketing every launch with
+ * HIP events recorded on that stream; writes the milliseconds of each launch to ms[0..n).
+ * Advances the state like nutls_step (input = the library's mag_in buffer).  Synchronous. */
+int nutls_profile_step(nutls_handle* h, float* ms, int n);
 
 const char* nutls_last_error(void);
 const char* nutls_version(void);

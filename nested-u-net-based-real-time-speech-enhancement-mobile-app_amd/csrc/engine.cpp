@@ -74,7 +74,7 @@ struct Launch {
   InLayerParams inl;
   OutConvParams outc;
   std::string name;
-  bool encoder_strided = false;
+  bool encoder_strided = false;   // one of the 26 encoder (2,3) stride-2 convs (the "encoder conv stack")
 };
 
 struct StageStates {
@@ -721,31 +721,81 @@ int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n
   return NUTLS_OK;
 }
 
-int nutls_time_kernel(nutls_handle* h, int which, int iters, float* avg_ms) {
-  if (!h || !avg_ms || iters < 1) return fail(NUTLS_ERR_ARG, "nutls_time_kernel: bad argument");
-  Engine* e = &h->eng;
-  HIP_TRY(hipSetDevice(e->device));
-  std::vector<const Launch*> sel;
-  for (const Launch& L : e->plan[0]) {
-    if (which == 0 && L.name == "msfe6_en_spconv6") sel.push_back(&L);
-    if (which == 1 && L.name == "msfe6_en_conv1") sel.push_back(&L);
-    if (which == 2 && L.encoder_strided) sel.push_back(&L);
+static const char* family_name(const Launch& L, int B) {
+  static const char* conv_names[CONV_KIND_COUNT] = {"conv_el_c32", "conv_el_c64", "conv_el_c128", "conv_dl_n64", "conv_dl_n128",
+                                                    "conv_in_c64", "conv_in_c128", "conv_down", "conv_up_even", "conv_up_odd"};
+  static std::string tmp[2 * CONV_KIND_COUNT];
+  switch (L.kind) {
+    case Launch::CONV: {
+      const int nw = conv_pick_nw(L.ck, B, L.conv.F_out);
+      std::string& t = tmp[2 * L.ck + (nw == 4)];
+      t = std::string(conv_names[L.ck]) + (nw == 4 ? "/w4" : "/w1");
+      return t.c_str();
+    }
+    case Launch::LSTM: return "lstm_dense";
+    case Launch::CTFA: return "ctfa";
+    case Launch::INLAYER: return "input_layer";
+    case Launch::OUTCONV: return "out_conv";
   }
-  if (sel.empty()) return fail(NUTLS_ERR_ARG, "nutls_time_kernel: unknown selector");
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  for (const Launch* L : sel) HIP_TRY(run_launch(*L, e->stream));   // warm-up
-  HIP_TRY(hipEventRecord(e0, e->stream));
-  for (int i = 0; i < iters; ++i)
-    for (const Launch* L : sel) HIP_TRY(run_launch(*L, e->stream));
-  HIP_TRY(hipEventRecord(e1, e->stream));
-  HIP_TRY(hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *avg_ms = ms / iters;
+  return "?";
+}
+
+int nutls_launch_info(nutls_handle* h, int index, const char** layer, const char** family, double* flops, double* bytes) {
+  if (!h || index < 0 || index >= static_cast<int>(h->eng.plan[0].size())) return fail(NUTLS_ERR_ARG, "nutls_launch_info: bad index");
+  const Engine* e = &h->eng;
+  const Launch& L = e->plan[0][index];
+  const double B = e->B;
+  double fl = 0, by = 0;
+  switch (L.kind) {
+    case Launch::CONV: {
+      const ConvShape sh = conv_shape(L.ck);
+      const double k = static_cast<double>(sh.tt) * sh.kf * sh.cin, n = 32.0 * sh.nt;
+      fl = 2.0 * B * L.conv.F_out * k * n;
+      by = 4.0 * B * (static_cast<double>(sh.tt) * L.conv.F_in * sh.cin + L.conv.F_out * n);
+      break;
+    }
+    case Launch::LSTM:
+      fl = 2.0 * B * (84.0 * (L.lstm.Din + 21) + 21.0 * L.lstm.Dout);
+      by = 4.0 * B * (L.lstm.Din + L.lstm.Dout + 4 * 21);
+      break;
+    case Launch::CTFA:
+      fl = B * (3.0 * L.ctfa.F * 64 + 2.0 * 4 * 64 * 16);
+      by = 4.0 * B * 3 * L.ctfa.F * 64;
+      break;
+    case Launch::INLAYER:
+      fl = 2.0 * L.inl.n_pos * 64;
+      by = 4.0 * L.inl.n_pos * 65;
+      break;
+    case Launch::OUTCONV:
+      fl = 2.0 * L.outc.n_pos * 64;
+      by = 4.0 * L.outc.n_pos * 65;
+      break;
+  }
+  if (layer) *layer = L.name.c_str();
+  if (family) *family = family_name(L, e->B);
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  return NUTLS_OK;
+}
+
+int nutls_profile_step(nutls_handle* h, float* ms, int n) {
+  if (!h || !ms) return fail(NUTLS_ERR_ARG, "nutls_profile_step: null pointer");
+  Engine* e = &h->eng;
+  const int par = e->next_parity;
+  const std::vector<Launch>& plan = e->plan[par];
+  if (n != static_cast<int>(plan.size())) return fail(NUTLS_ERR_ARG, "nutls_profile_step: n must equal nutls_launches_per_step");
+  HIP_TRY(hipSetDevice(e->device));
+  std::vector<hipEvent_t> ev(plan.size() + 1);
+  for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+  HIP_TRY(hipEventRecord(ev[0], e->stream));
+  for (size_t i = 0; i < plan.size(); ++i) {
+    HIP_TRY(run_launch(plan[i], e->stream));
+    HIP_TRY(hipEventRecord(ev[i + 1], e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (size_t i = 0; i < plan.size(); ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+  for (auto& x : ev) (void)hipEventDestroy(x);
+  e->next_parity = 1 - par;
   return NUTLS_OK;
 }
 

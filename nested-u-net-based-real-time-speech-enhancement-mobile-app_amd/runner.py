@@ -32,7 +32,8 @@ ABI_SYMBOLS = (
     "nutls_create", "nutls_destroy", "nutls_step", "nutls_step_host", "nutls_io_buffers",
     "nutls_use_graph", "nutls_state_get", "nutls_state_set", "nutls_state_count",
     "nutls_state_info", "nutls_reset", "nutls_debug_get", "nutls_batch",
-    "nutls_launches_per_step", "nutls_time_kernel", "nutls_last_error", "nutls_version",
+    "nutls_launches_per_step", "nutls_launch_info", "nutls_profile_step", "nutls_last_error",
+    "nutls_version",
 )
 
 
@@ -63,7 +64,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_debug_get.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
     lib.nutls_batch.argtypes = [c.c_void_p]
     lib.nutls_launches_per_step.argtypes = [c.c_void_p]
-    lib.nutls_time_kernel.argtypes = [c.c_void_p, c.c_int, c.c_int, c.POINTER(c.c_float)]
+    lib.nutls_launch_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
+                                      c.POINTER(c.c_double), c.POINTER(c.c_double)]
+    lib.nutls_profile_step.argtypes = [c.c_void_p, fp, c.c_int]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:
@@ -192,10 +195,23 @@ class NutlsEngine:
         _check(self._lib, self._lib.nutls_debug_get(self._h, name.encode(), _fptr(a), a.size))
         return a
 
-    def time_kernel(self, which: int, iters: int = 20) -> float:
-        ms = ctypes.c_float()
-        _check(self._lib, self._lib.nutls_time_kernel(self._h, which, iters, ctypes.byref(ms)))
-        return float(ms.value)
+    def launch_plan(self) -> List[Dict[str, object]]:
+        """The per-frame launch list: layer name, kernel family, algorithmic flops / bytes."""
+        res = []
+        for i in range(self.launches_per_step):
+            layer, fam = ctypes.c_char_p(), ctypes.c_char_p()
+            fl, by = ctypes.c_double(), ctypes.c_double()
+            _check(self._lib, self._lib.nutls_launch_info(self._h, i, ctypes.byref(layer), ctypes.byref(fam),
+                                                          ctypes.byref(fl), ctypes.byref(by)))
+            res.append({"layer": layer.value.decode(), "family": fam.value.decode(), "flops": fl.value, "bytes": by.value})
+        return res
+
+    def profile_step(self) -> np.ndarray:
+        """One step with every launch bracketed by HIP events on the library's stream; returns
+        milliseconds per launch (input: whatever the library's mag_in buffer holds)."""
+        ms = np.zeros(self.launches_per_step, np.float32)
+        _check(self._lib, self._lib.nutls_profile_step(self._h, _fptr(ms), ms.size))
+        return ms
 
 
 class NutlsRunner:

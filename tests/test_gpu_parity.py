@@ -1,0 +1,194 @@
+"""Parity tests proper (``-m gpu``): the HIP path, called through the C ABI, against oracle B
+on identical inputs and against the committed golden vectors (oracle A = the reference's shipped
+graph executed op by op).  Tolerance from BASELINE.json's north_star: 1e-3 RMS on the enhanced
+magnitudes; fp32 MFMA gets ~1e-7, so the tests assert a much tighter 2e-5."""
+import os
+
+import numpy as np
+import pytest
+
+import nunet_amd
+from nunet_amd import NutlsEngine, NutlsRunner, stream_enhance as SE, topology as T
+from oracle.nutls_ref import NutlsRef
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR_RMS = 1e-3
+TIGHT_RMS = 2e-5
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def clip():
+    return np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+
+
+def synthetic_mags(batch, steps, seed=1234):
+    """BASELINE config 2 input distribution: 0.25*|N(0,1)|, default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    return (0.25 * np.abs(rng.standard_normal((steps, batch, 256)))).astype(np.float32)
+
+
+def test_kat_b1_closed_form():
+    kat = np.load(os.path.join(GOLDEN, "kat_b1.npz"))
+    eng = NutlsEngine(batch=1)
+    for fr in (1, 2, 3):
+        out = eng.step(kat["x"].reshape(1, 256)).reshape(-1)
+        assert rms(out, kat["out%d" % fr]) < TIGHT_RMS
+        np.testing.assert_allclose(eng.state_get("state_h").reshape(-1), kat["state_h%d" % fr], atol=1e-5)
+    eng.close()
+
+
+def test_golden_clip_64_frames_and_every_state_tensor(clip):
+    """Outputs and ALL 130 state tensors (= every conv input of the net) vs oracle-A goldens."""
+    eng = NutlsEngine(batch=1)
+    outs = []
+    for i in range(64):
+        outs.append(eng.step(clip["mags_in"][i:i + 1]).reshape(-1))
+        if i + 1 in (3, 64):
+            st = np.load(os.path.join(GOLDEN, "state_f%d.npz" % (i + 1)))
+            for base, shp in T.state_specs():
+                k_in = base if len(shp) == 1 else base.format("prev")
+                k_gold = base if len(shp) == 1 else base.format("cur")
+                np.testing.assert_allclose(eng.state_get(k_in).reshape(-1), st[k_gold].reshape(-1),
+                                           rtol=1e-4, atol=1e-4, err_msg=k_gold)
+    err = rms(np.stack(outs), clip["mags_out"][:64])
+    assert err < TIGHT_RMS < NORTH_STAR_RMS, err
+    eng.close()
+
+
+def test_full_clip_249_frames(clip):
+    eng = NutlsEngine(batch=1)
+    outs = np.stack([eng.step(clip["mags_in"][i:i + 1]).reshape(-1) for i in range(249)])
+    assert rms(outs, clip["mags_out"]) < TIGHT_RMS
+    eng.close()
+
+
+def test_batch_invariance_and_stream_position(clip):
+    """Stream i's result must not depend on B or on its slot in the batch (edge cases: B = 1,
+    B = 3 (ragged vs. the 32-position tiles), B = 40)."""
+    frames = clip["mags_in"]
+    single = NutlsEngine(batch=1)
+    want = [single.step(frames[20 + i:21 + i]).reshape(-1) for i in range(4)]
+    single.close()
+    for B, slot in ((3, 1), (40, 37)):
+        eng = NutlsEngine(batch=B)
+        for i in range(4):
+            x = np.stack([frames[(7 * s + 3 * i) % 249] for s in range(B)])
+            x[slot] = frames[20 + i]
+            out = eng.step(x)
+            assert rms(out[slot], want[i]) < 1e-6
+        eng.close()
+
+
+def test_batch_256_synthetic_vs_oracle():
+    """BASELINE config 2 shape: B = 256 synthetic streams; all outputs vs oracle B."""
+    B, steps = 256, 6
+    mags = synthetic_mags(B, steps)
+    eng, ref = NutlsEngine(batch=B), NutlsRef(batch=B)
+    for s in range(steps):
+        out = eng.step(mags[s])
+        want = ref.step(mags[s]).numpy()
+        assert rms(out, want) < TIGHT_RMS
+    for name in ("msfe6_ee_prev1", "msfe4_dd3_prev2", "msfe3_de_prev1", "state_c", "msfe6_de_h"):
+        # white-noise inputs make some LayerNorm variances tiny (eps = 1e-8), which amplifies the
+        # fp32 summation-order difference between MFMA and the CPU GEMM: compare by RMS
+        a, b = eng.state_get(name).reshape(B, -1), ref.state[name].numpy().reshape(B, -1)
+        assert rms(a, b) < 1e-4 * max(1.0, float(np.abs(b).max())), name
+    eng.close()
+
+
+def test_graph_replay_equals_plain_launches(clip):
+    a, b = NutlsEngine(batch=2, use_graph=True), NutlsEngine(batch=2, use_graph=False)
+    for i in range(5):
+        x = clip["mags_in"][2 * i:2 * i + 2]
+        assert np.array_equal(a.step(x), b.step(x))
+    a.close(); b.close()
+
+
+def test_torch_device_tensors_zero_copy(clip):
+    import torch
+    eng, host = NutlsEngine(batch=4), NutlsEngine(batch=4)
+    for i in range(3):
+        x = clip["mags_in"][4 * i:4 * i + 4]
+        xt = torch.from_numpy(x).cuda()
+        out = eng.step(xt)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), host.step(x))
+    eng.close(); host.close()
+
+
+def test_state_get_set_reset_round_trip(clip):
+    eng = NutlsEngine(batch=2)
+    for i in range(3):
+        eng.step(clip["mags_in"][i:i + 2])
+    snap = {n: eng.state_get(n) for n, _ in eng.state_specs()}
+    assert len(snap) == 130
+    o1 = eng.step(clip["mags_in"][10:12])
+    # restore the snapshot -> same result again (pause / migrate a stream)
+    for n, v in snap.items():
+        eng.state_set(n, v)
+    o2 = eng.step(clip["mags_in"][10:12])
+    assert np.array_equal(o1, o2)
+    # reset stream 1 only: stream 0 continues, stream 1 restarts from the zero seed
+    eng.reset(1)
+    fresh = NutlsEngine(batch=1)
+    o3 = eng.step(clip["mags_in"][12:14])
+    assert rms(o3[1], fresh.step(clip["mags_in"][13:14])[0]) < 1e-6
+    assert float(np.abs(eng.state_get("msfe6_ee_prev1")[0]).max()) > 0
+    with pytest.raises(ValueError):
+        eng.state_get("no_such_state")
+    with pytest.raises(ValueError):
+        eng.state_set("state_h", np.zeros(5, np.float32))
+    eng.close(); fresh.close()
+
+
+def test_signature_runner_drop_in(clip):
+    """The reference's call surface: 131 named tensors in, 131 out, cur->prev echo by the caller
+    (interpreter_proposed.py:215-350), including the caller-owned-state path (fresh arrays)."""
+    run = NutlsRunner()
+    out = SE.zero_state()
+    for i in range(3):
+        m = clip["mags_in"][i].reshape(1, 1, 256, 1)
+        feeds = SE.feeds_from_outputs(out, m)
+        if i == 2:   # hand back copies instead of the runner's own arrays -> forces the upload path
+            feeds = {k: v.copy() for k, v in feeds.items()}
+        out = run(**feeds)
+        assert set(out) == set(T.output_names())
+        assert out["model_out"].shape == (1, 1, 256, 1) and out["msfe6_de_c"].shape == (1, 21)
+        assert out["msfe4_ee2_cur3"].shape == (1, 1, 8, 32) and out["msfe6_de_cur1"].dtype == np.float32
+        assert rms(out["model_out"].reshape(-1), clip["mags_out"][i]) < TIGHT_RMS
+    with pytest.raises(ValueError):
+        run(input=np.zeros((1, 1, 256, 1), np.float32))
+    bad = SE.feeds_from_outputs(out, clip["mags_in"][3].reshape(1, 1, 256, 1))
+    bad["msfe6_ee_prev1"] = np.zeros((1, 1, 128, 64), np.float32)
+    with pytest.raises(ValueError):
+        run(**bad)
+
+
+def test_config1_clip_end_to_end_snr(clip):
+    """BASELINE config 1 through the GPU: 4 s clip -> enhanced waveform, SNR 0.76 -> 11.63 dB."""
+    audio = clip["noisy_i16"].astype(np.float64) / 32768.0
+    clean = clip["clean_i16"].astype(np.float64) / 32768.0
+    enh, times = SE.real_time_speech_enhancer(audio, NutlsRunner())
+    n = 248 * 256
+    assert abs(SE.snr_db(clean[:n], enh[:n]) - 11.63) < 0.05
+    assert abs(SE.si_snr_db(clean[:n], enh[:n]) - 13.28) < 0.05
+    assert float(np.max(np.abs(enh[:n] - clip["enhanced"][:n]))) < 1e-4
+
+
+def test_linearity_free_property_scale_silence():
+    """Size-independent sanity at the bench size: all-zero input from zero state gives the same
+    output in every one of the 256 streams, frame after frame (no cross-stream leakage)."""
+    eng = NutlsEngine(batch=256)
+    z = np.zeros((256, 256), np.float32)
+    for _ in range(3):
+        out = eng.step(z)
+        assert np.all(out == out[0:1])
+        assert np.all(np.isfinite(out))
+    eng.close()

@@ -1,0 +1,64 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes exercise the stream sharding and the
+counter reduction that bench.py runs over RCCL."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import nunet_amd  # noqa: F401
+    from nunet_amd.sharding import reduce_throughput, stream_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = stream_range(2048 + 3, rank, world)
+    frames, elapsed = (hi - lo) * 10, 1.0 + rank          # rank 1 is the slow one
+    tot, mx = reduce_throughput(frames, elapsed, dist, torch.device("cpu"))
+    q.put((rank, lo, hi, tot, mx))
+    dist.destroy_process_group()
+
+
+def test_stream_range_partitions_exactly():
+    from nunet_amd.sharding import stream_range
+    for total, world in ((2048, 8), (10, 3), (1, 2), (0, 4)):
+        spans = [stream_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        stream_range(8, 2, 2)
+
+
+@pytest.mark.timeout(120)
+def test_counter_reduction_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, tot0, mx0), (r1, lo1, hi1, tot1, mx1) = res
+    assert (lo0, hi1) == (0, 2051) and hi0 == lo1
+    assert tot0 == tot1 == 2051 * 10          # whole-job frames
+    assert mx0 == mx1 == 2.0                  # max over ranks
