@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", default="persistent", choices=["persistent", "graph", "launches"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default="", help="write the per-launch HIP-event timeline here")
     args = ap.parse_args()
@@ -103,7 +103,7 @@ def main():
     from nunet_amd.sharding import reduce_throughput
 
     B = args.batch
-    eng = nunet_amd.NutlsEngine(batch=B, device=local_rank, use_graph=not args.no_graph)
+    eng = nunet_amd.NutlsEngine(batch=B, device=local_rank, mode=args.mode)
     pool_host = synthetic_pool(B, 8, 1234 + rank)
     pool = torch.from_numpy(pool_host).cuda()            # inputs resident in HBM
     out = torch.empty(B, 256, device="cuda")
@@ -130,30 +130,60 @@ def main():
     assert bool(torch.isfinite(out).all())
 
     if rank == 0:
-        # ---- live per-launch timing of the same workload with HIP events on the library stream
-        eng.use_graph(False)
+        import re
         plan = eng.launch_plan()
-        reps = 10
-        ms = np.zeros(len(plan))
-        for _ in range(2):
-            eng.profile_step()
-        for _ in range(reps):
-            ms += eng.profile_step()
-        ms /= reps
+        step_flops = sum(p["flops"] for p in plan)
+
+        def is_enc_conv(p):   # the 26 encoder (2,3) stride-2 convs = the north-star's "encoder conv stack"
+            return re.search(r"_en\d?_conv\d$", p["layer"]) is not None
+
+        if args.mode == "persistent":
+            # The whole step is ONE kernel (nutls_stream_step_kernel).  Its average duration over the
+            # timed region comes from HIP events recorded on the stream it is launched on.
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record(stream)
+            for s in range(args.steps):
+                eng.step(pool[s % 8], out)
+            ev[1].record(stream)
+            torch.cuda.synchronize()
+            avg_ms = ev[0].elapsed_time(ev[1]) / args.steps
+            achieved = step_flops / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": "nutls_stream_step_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                        "traffic": None, "launches_per_step": 1, "avg_launch_ms": round(avg_ms, 5),
+                        "flops_per_launch": step_flops}
+            # in-kernel timeline of workgroup 0 (wall clock stamps at every layer boundary)
+            reps = 10
+            for _ in range(2):
+                eng.profile_persistent()
+            us = np.zeros(len(plan))
+            for _ in range(reps):
+                us += eng.profile_persistent()
+            ms = us / reps / 1e3
+        else:
+            # one kernel per layer: per-launch HIP events on the library stream
+            eng.set_mode("launches")
+            reps = 10
+            ms = np.zeros(len(plan))
+            for _ in range(2):
+                eng.profile_step()
+            for _ in range(reps):
+                ms += eng.profile_step()
+            ms /= reps
         fam = {}
         for p, t in zip(plan, ms):
             f = fam.setdefault(p["family"], {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
             f["ms"] += t; f["n"] += 1; f["flops"] += p["flops"]; f["bytes"] += p["bytes"]
-        dom = max(fam, key=lambda k: fam[k]["ms"])
-        d = fam[dom]
-        avg_ms = d["ms"] / d["n"]
-        achieved = d["flops"] / d["n"] / (avg_ms * 1e-3) / 1e12
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": d["n"], "avg_launch_ms": round(avg_ms, 5),
-                    "share_of_step": round(d["ms"] / ms.sum(), 3)}
-        import re
-        enc = [(p, t) for p, t in zip(plan, ms) if re.search(r"_en\d?_conv\d$", p["layer"])]   # the 26 encoder (2,3) s2 convs
+        if args.mode != "persistent":
+            dom = max(fam, key=lambda k: fam[k]["ms"])
+            d = fam[dom]
+            avg_ms = d["ms"] / d["n"]
+            achieved = d["flops"] / d["n"] / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": d["n"], "avg_launch_ms": round(avg_ms, 5),
+                        "share_of_step": round(d["ms"] / ms.sum(), 3)}
+        enc = [(p, t) for p, t in zip(plan, ms) if is_enc_conv(p)]
         enc_ms = sum(t for _, t in enc)
         enc_bytes = sum(p["bytes"] for p, _ in enc)
         enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
@@ -162,8 +192,8 @@ def main():
                          "tflops": round(sum(p["flops"] for p, _ in enc) / (enc_ms * 1e-3) / 1e12, 2)}
         if args.profile_json:
             with open(args.profile_json, "w") as f:
-                json.dump({"batch": B, "launches": [dict(p, ms=float(t)) for p, t in zip(plan, ms)],
-                           "families": fam, "event_step_ms": float(ms.sum())}, f, indent=1)
+                json.dump({"batch": B, "mode": args.mode, "launches": [dict(p, ms=float(t)) for p, t in zip(plan, ms)],
+                           "families": fam, "timeline_step_ms": float(ms.sum())}, f, indent=1)
         value = total_frames / max_elapsed
         line = {
             "metric": "STFT frames/sec (512-pt, 50% hop) through the NUNet-TLS-LSTM frame step",
@@ -173,7 +203,7 @@ def main():
             "data": "synthetic magnitudes 0.25*|N(0,1)|, trained weights de-quantised from the reference's nutls_lstm.tflite",
             "config": {"workload": "NUNet-TLS-LSTM (proposed) frame step, batch=%d streams per GPU, 256-bin frames (BASELINE configs[1])" % B,
                        "streams_per_gpu": B, "total_streams": B * world, "parallelism": "stream-sharded x%d" % world,
-                       "graph": not args.no_graph, "launches_per_step": len(plan)},
+                       "mode": args.mode, "layers_per_step": len(plan)},
             "rtf_per_stream": round(1e3 * max_elapsed / args.steps / 16.0, 5),
             "tflops": round(value * FLOPS_PER_FRAME / 1e12, 2),
             "frac_f32_peak": round(value * FLOPS_PER_FRAME / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4),

@@ -70,8 +70,14 @@ int nutls_step_host(nutls_handle* h, const float* mag_in, float* mag_out);
  * the captured hipGraph run with no per-call parameter update. */
 int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out);
 
-/* Capture the launch sequence of a step into hipGraphs (one per state parity) and replay them
- * from then on.  enable = 0 goes back to plain launches. */
+/* Execution mode of nutls_step:
+ *   2 (default)  persistent kernel: ONE launch per frame, one 1024-thread workgroup per stream runs
+ *                every layer of the step (layer boundary = workgroup barrier, not a kernel boundary);
+ *   1            one kernel per layer, the ~160 launches captured in a hipGraph (one per state parity);
+ *   0            one kernel per layer, plain launches.
+ * All three compute the same function. */
+int nutls_set_mode(nutls_handle* h, int mode);
+/* enable != 0: mode 1 (capture + replay); enable == 0: mode 0. */
 int nutls_use_graph(nutls_handle* h, int enable);
 
 /* State access by the reference's signature names.  `name` is any of the 130 state inputs
@@ -109,6 +115,10 @@ int nutls_launch_info(nutls_handle* h, int index, const char** layer, const char
  * HIP events recorded on that stream; writes the milliseconds of each launch to ms[0..n).
  * Advances the state like nutls_step (input = the library's mag_in buffer).  Synchronous. */
 int nutls_profile_step(nutls_handle* h, float* ms, int n);
+
+/* Persistent-mode twin of nutls_profile_step: runs one step in mode 2 with workgroup 0 stamping
+ * wall_clock64() at every layer boundary; writes microseconds per layer to us[0..n). */
+int nutls_profile_persistent(nutls_handle* h, double* us, int n);
 
 const char* nutls_last_error(void);
 const char* nutls_version(void);

@@ -100,7 +100,10 @@ struct Engine {
   float *t_inlayer = nullptr, *t_y = nullptr, *t_d = nullptr, *t_up = nullptr;
   float* upcat[6] = {nullptr};
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
-  bool use_graph = false;
+  int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel
+  DevLaunch* dplan[2] = {nullptr, nullptr};
+  unsigned long long* dprof = nullptr;
+  int n_cu = 256;
   hipGraphExec_t gexec[2] = {nullptr, nullptr};
   std::unordered_map<std::string, std::pair<float*, size_t>> debug;   // name -> (ptr, floats per stream)
   std::unordered_map<std::string, ConvLayerW> convw;
@@ -510,6 +513,42 @@ static int run_plan(Engine* e, int par, hipStream_t s) {
   return NUTLS_OK;
 }
 
+static int upload_device_plans(Engine* e) {
+  for (int par = 0; par < 2; ++par) {
+    std::vector<DevLaunch> dv(e->plan[par].size());
+    for (size_t i = 0; i < dv.size(); ++i) {
+      const Launch& L = e->plan[par][i];
+      DevLaunch& d = dv[i];
+      std::memset(&d, 0, sizeof(d));
+      d.ck = L.ck;
+      switch (L.kind) {
+        case Launch::CONV: d.op = DEV_OP_CONV; d.conv = L.conv; break;
+        case Launch::LSTM: d.op = DEV_OP_LSTM; d.lstm = L.lstm; break;
+        case Launch::CTFA: d.op = DEV_OP_CTFA; d.ctfa = L.ctfa; break;
+        case Launch::INLAYER: d.op = DEV_OP_INLAYER; d.inl = L.inl; break;
+        case Launch::OUTCONV: d.op = DEV_OP_OUTCONV; d.outc = L.outc; break;
+      }
+    }
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, dv.size() * sizeof(DevLaunch)));
+    e->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, dv.data(), dv.size() * sizeof(DevLaunch), hipMemcpyHostToDevice));
+    e->dplan[par] = static_cast<DevLaunch*>(p);
+  }
+  void* q = nullptr;
+  HIP_TRY(hipMalloc(&q, (e->plan[0].size() + 1) * sizeof(unsigned long long)));
+  e->allocs.push_back(q);
+  e->dprof = static_cast<unsigned long long*>(q);
+  return NUTLS_OK;
+}
+
+static int run_persistent(Engine* e, int par, hipStream_t s, bool prof) {
+  const int grid = e->B;   // one workgroup per stream; the hardware runs as many as fit (1 per CU)
+  hipError_t err = launch_stream_step(e->dplan[par], static_cast<int>(e->plan[par].size()), e->B, grid, prof ? e->dprof : nullptr, s);
+  if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("persistent step launch: ") + hipGetErrorString(err));
+  return NUTLS_OK;
+}
+
 static int capture_graphs(Engine* e) {
   for (int par = 0; par < 2; ++par) {
     if (e->gexec[par]) continue;
@@ -576,6 +615,8 @@ int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, in
     if ((rc = dev_alloc(e, B * (kDecoder[s].f0 / 2) * 128, &e->upcat[s], true))) return rc;
   build_plan(e, 0);
   build_plan(e, 1);
+  if ((rc = upload_device_plans(e))) return rc;
+  e->n_cu = prop.multiProcessorCount;
   e->debug["input_layer"] = {e->t_inlayer, 256 * 64};
   e->debug["msfe6_de.y"] = {e->t_y, 256 * 64};
   e->debug["msfe6_de.up"] = {e->t_up, 256 * 128};
@@ -612,7 +653,14 @@ int nutls_use_graph(nutls_handle* h, int enable) {
     int rc = capture_graphs(e);
     if (rc) return rc;
   }
-  e->use_graph = enable != 0;
+  e->mode = enable ? 1 : 0;
+  return NUTLS_OK;
+}
+
+int nutls_set_mode(nutls_handle* h, int mode) {
+  if (!h || mode < 0 || mode > 2) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode must be 0, 1 or 2");
+  if (mode == 1) return nutls_use_graph(h, 1);
+  h->eng.mode = mode;
   return NUTLS_OK;
 }
 
@@ -623,7 +671,10 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   const size_t bytes = static_cast<size_t>(e->B) * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
   const int par = e->next_parity;
-  if (e->use_graph) {
+  if (e->mode == 2) {
+    int rc = run_persistent(e, par, s, false);
+    if (rc) return rc;
+  } else if (e->mode == 1) {
     HIP_TRY(hipGraphLaunch(e->gexec[par], s));
   } else {
     int rc = run_plan(e, par, s);
@@ -795,6 +846,26 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (size_t i = 0; i < plan.size(); ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
   for (auto& x : ev) (void)hipEventDestroy(x);
+  e->next_parity = 1 - par;
+  return NUTLS_OK;
+}
+
+int nutls_profile_persistent(nutls_handle* h, double* us, int n) {
+  if (!h || !us) return fail(NUTLS_ERR_ARG, "nutls_profile_persistent: null pointer");
+  Engine* e = &h->eng;
+  const int par = e->next_parity;
+  const int n_ops = static_cast<int>(e->plan[par].size());
+  if (n != n_ops) return fail(NUTLS_ERR_ARG, "nutls_profile_persistent: n must equal nutls_launches_per_step");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = run_persistent(e, par, e->stream, true);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<unsigned long long> t(n_ops + 1);
+  HIP_TRY(hipMemcpy(t.data(), e->dprof, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device);
+  if (khz <= 0) khz = 100000;
+  for (int i = 0; i < n_ops; ++i) us[i] = static_cast<double>(t[i + 1] - t[i]) * 1000.0 / khz;
   e->next_parity = 1 - par;
   return NUTLS_OK;
 }

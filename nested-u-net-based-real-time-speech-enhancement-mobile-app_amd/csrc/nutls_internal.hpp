@@ -106,6 +106,27 @@ struct OutConvParams {   // 1x1 conv 64->1
 hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
 
 
+// ------------------------------------------------------------------ persistent kernel ---------
+// Device-resident launch plan: one entry per layer, consumed by nutls_stream_step_kernel
+// (megakernel.hip), which runs the whole frame step of one stream inside one workgroup.
+enum DevOp : int { DEV_OP_CONV = 0, DEV_OP_LSTM, DEV_OP_CTFA, DEV_OP_INLAYER, DEV_OP_OUTCONV };
+constexpr int NUTLS_DEV_BINS = 256;
+struct DevLaunch {
+  int op;   // DevOp
+  int ck;   // ConvKind when op == DEV_OP_CONV
+  int pad0, pad1;
+  union {
+    ConvParams conv;
+    LstmParams lstm;
+    CtfaParams ctfa;
+    InLayerParams inl;
+    OutConvParams outc;
+  };
+};
+// grid = number of workgroups (each loops over streams blockIdx.x, +grid, ...); prof (nullable)
+// receives wall_clock64() at every layer boundary of workgroup 0 (n_ops + 1 entries).
+hipError_t launch_stream_step(const DevLaunch* plan, int n_ops, int B, int grid, unsigned long long* prof, hipStream_t s);
+
 // Packs OHWI conv weights [Cout][th][kw][Cin] into the order the MFMA loop streams them.
 //   perm[n'] = original output channel feeding packed channel n'
 //   taps     = list of (t, kw) source taps in kernel order (time-major)

@@ -30,9 +30,10 @@ NUTLS_ERR_ARG = -1
 # every symbol include/nutls.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "nutls_create", "nutls_destroy", "nutls_step", "nutls_step_host", "nutls_io_buffers",
-    "nutls_use_graph", "nutls_state_get", "nutls_state_set", "nutls_state_count",
+    "nutls_use_graph", "nutls_set_mode", "nutls_state_get", "nutls_state_set", "nutls_state_count",
     "nutls_state_info", "nutls_reset", "nutls_debug_get", "nutls_batch",
-    "nutls_launches_per_step", "nutls_launch_info", "nutls_profile_step", "nutls_last_error",
+    "nutls_launches_per_step", "nutls_launch_info", "nutls_profile_step",
+    "nutls_profile_persistent", "nutls_last_error",
     "nutls_version",
 )
 
@@ -56,6 +57,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_step_host.argtypes = [c.c_void_p, fp, fp]
     lib.nutls_io_buffers.argtypes = [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p)]
     lib.nutls_use_graph.argtypes = [c.c_void_p, c.c_int]
+    lib.nutls_set_mode.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_state_get.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
     lib.nutls_state_set.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
     lib.nutls_state_count.argtypes = [c.c_void_p]
@@ -67,6 +69,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_launch_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
                                       c.POINTER(c.c_double), c.POINTER(c.c_double)]
     lib.nutls_profile_step.argtypes = [c.c_void_p, fp, c.c_int]
+    lib.nutls_profile_persistent.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:
@@ -94,7 +97,11 @@ def _fptr(a: np.ndarray):
 class NutlsEngine:
     """B streams, device-resident state.  ``step`` takes/returns ``[B,256]`` magnitudes."""
 
-    def __init__(self, weights=None, batch: int = 1, device: int = 0, use_graph: bool = True):
+    MODES = {"launches": 0, "graph": 1, "persistent": 2}
+
+    def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: str = "persistent"):
+        """``mode``: "persistent" (default; one launch per frame, one workgroup per stream),
+        "graph" (one kernel per layer, hipGraph replay) or "launches" (one kernel per layer)."""
         self._lib = load_library()
         blob = read_blob(weights if weights is not None else DEFAULT_WEIGHTS)
         self._h = ctypes.c_void_p()
@@ -105,8 +112,7 @@ class NutlsEngine:
         pin, pout = ctypes.c_void_p(), ctypes.c_void_p()
         _check(self._lib, self._lib.nutls_io_buffers(self._h, ctypes.byref(pin), ctypes.byref(pout)))
         self.io_in_ptr, self.io_out_ptr = pin.value, pout.value
-        if use_graph:
-            self.use_graph(True)
+        self.set_mode(mode)
 
     # -- lifetime --------------------------------------------------------------------------
     def close(self):
@@ -120,8 +126,11 @@ class NutlsEngine:
         except Exception:
             pass
 
-    def use_graph(self, enable: bool = True):
-        _check(self._lib, self._lib.nutls_use_graph(self._h, 1 if enable else 0))
+    def set_mode(self, mode: str):
+        if mode not in self.MODES:
+            raise ValueError("mode must be one of %s" % sorted(self.MODES))
+        _check(self._lib, self._lib.nutls_set_mode(self._h, self.MODES[mode]))
+        self.mode = mode
 
     @property
     def launches_per_step(self) -> int:
@@ -206,6 +215,14 @@ class NutlsEngine:
             res.append({"layer": layer.value.decode(), "family": fam.value.decode(), "flops": fl.value, "bytes": by.value})
         return res
 
+    def profile_persistent(self) -> np.ndarray:
+        """One persistent-mode step with workgroup 0 time-stamping every layer boundary
+        (wall clock); returns microseconds per layer."""
+        us = np.zeros(self.launches_per_step, np.float64)
+        _check(self._lib, self._lib.nutls_profile_persistent(
+            self._h, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), us.size))
+        return us
+
     def profile_step(self) -> np.ndarray:
         """One step with every launch bracketed by HIP events on the library's stream; returns
         milliseconds per launch (input: whatever the library's mag_in buffer holds)."""
@@ -224,8 +241,8 @@ class NutlsRunner:
 
     signature_key = "nutls_lstm_sm"
 
-    def __init__(self, weights=None, device: int = 0, use_graph: bool = True):
-        self.engine = NutlsEngine(weights, batch=1, device=device, use_graph=use_graph)
+    def __init__(self, weights=None, device: int = 0, mode: str = "persistent"):
+        self.engine = NutlsEngine(weights, batch=1, device=device, mode=mode)
         self._in_names = T.input_names()
         self._specs = T.state_specs()
         self._last: Dict[str, np.ndarray] = {}

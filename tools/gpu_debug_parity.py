@@ -16,7 +16,8 @@ from oracle.nutls_ref import NutlsRef  # noqa: E402
 def main():
     nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     clip = np.load(os.path.join(ROOT, "tests/golden/clip_4s.npz"))
-    eng = NutlsEngine(batch=1, use_graph=False)
+    mode = sys.argv[2] if len(sys.argv) > 2 else "persistent"
+    eng = NutlsEngine(batch=1, mode=mode)
     ref = NutlsRef(batch=1)
     print("launches per step:", eng.launches_per_step)
     for i in range(nframes):
@@ -31,9 +32,13 @@ def main():
         b = ref.state[k].numpy().reshape(-1)
         err = np.abs(a - b).max()
         worst.append((k, err, np.abs(b).max()))
+    nbad = 0
     for k, err, mag in worst:
-        flag = "  <<<<" if err > 1e-3 * max(1.0, mag) else ""
-        print("%-20s maxerr %.3e  max|ref| %.3e%s" % (k, err, mag, flag))
+        bad = err > 1e-3 * max(1.0, mag)
+        nbad += bad
+        if bad or "-v" in sys.argv:
+            print("%-20s maxerr %.3e  max|ref| %.3e%s" % (k, err, mag, "  <<<<" if bad else ""))
+    print("states checked: %d, bad: %d, worst maxerr %.3e" % (len(worst), nbad, max(w[1] for w in worst)))
 
 
 if __name__ == "__main__":
