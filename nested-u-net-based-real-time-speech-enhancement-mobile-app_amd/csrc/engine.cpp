@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -513,6 +514,77 @@ static int run_plan(Engine* e, int par, hipStream_t s) {
   return NUTLS_OK;
 }
 
+// Regions of HBM a launch writes, for the hand-off analysis: (row-0 pointer incl. channel offset, ld, channels)
+struct WriteRegion { const float* ptr; int ld, nchan, launch; };
+
+static void collect_writes(const Launch& L, int idx, std::vector<WriteRegion>* out) {
+  switch (L.kind) {
+    case Launch::CONV: {
+      const ConvShape sh = conv_shape(L.ck);
+      const int gc = 32 * sh.g;
+      out->push_back({L.conv.dst0, L.conv.ld0, gc, idx});
+      if (L.conv.dst1) out->push_back({L.conv.dst1, L.conv.ld1, gc, idx});
+      break;
+    }
+    case Launch::LSTM: out->push_back({L.lstm.dst, L.lstm.dst_ld, L.lstm.dst_cols, idx}); break;
+    case Launch::CTFA: out->push_back({L.ctfa.y, L.ctfa.y_ld, 64, idx}); break;
+    case Launch::INLAYER: out->push_back({L.inl.y, 64, 64, idx}); break;
+    case Launch::OUTCONV: break;
+  }
+}
+
+// Decides, for every pair of consecutive conv layers (L, N), whether L completes N's LDS image
+// (hand-off) -- possible when N keeps all its phases resident and every channel of N's current-frame
+// input was written either by L itself (then L forwards those rows from its epilogue) or by a launch
+// before L (then L prefetches them from HBM while its own MFMAs run).
+static void plan_handoffs(const std::vector<Launch>& plan, std::vector<DevLaunch>* dv) {
+  std::vector<WriteRegion> writes;
+  for (size_t i = 0; i < plan.size(); ++i) collect_writes(plan[i], static_cast<int>(i), &writes);
+  const bool disabled = getenv("NUTLS_NO_HANDOFF") != nullptr;
+  for (size_t i = 0; i + 1 < plan.size(); ++i) {
+    if (plan[i].kind != Launch::CONV || plan[i + 1].kind != Launch::CONV) continue;
+    DevLaunch& L = (*dv)[i];
+    DevLaunch& N = (*dv)[i + 1];
+    const ConvParams& np = N.conv;
+    const float* ncur = (N.cp.tt == 2) ? np.src1 : np.src0;
+    bool ok = N.cp.merged && !disabled;
+    int fwd_sel = 0, fwd_coff = 0, covered = 0;
+    if (ok) {
+      for (const WriteRegion& w : writes) {
+        if (w.ld != np.src_ld) continue;
+        const ptrdiff_t off = w.ptr - ncur;
+        if (off < 0 || off >= N.cp.cin) continue;          // not a channel slice of N's input rows
+        covered += w.nchan;
+        if (w.launch > static_cast<int>(i)) ok = false;    // produced later than L (cannot happen, guard)
+        if (w.launch == static_cast<int>(i)) {
+          const int sel = (w.ptr == L.conv.dst0) ? 1 : 2;
+          if (fwd_sel && fwd_sel != sel) ok = false;
+          fwd_sel = sel;
+          fwd_coff = static_cast<int>(off);
+        }
+      }
+      // up-sampling writes alternate rows with two launches: each covers all channels once
+      if (covered < N.cp.cin) ok = false;
+      if (fwd_sel) {
+        const int rows_l = L.conv.F_out * L.conv.row_mul;
+        if (rows_l != np.F_in || (fwd_coff % 4)) ok = false;
+      }
+    }
+    if (ok) {
+      L.cp.hand_next = 1;
+      L.cp.fwd_sel = fwd_sel;
+      L.cp.fwd_coff4 = fwd_coff / 4;
+      const bool all_rows = (L.cp.R == L.conv.row_mul);
+      L.cp.fwd_rmul = all_rows ? 1 : L.conv.row_mul;
+      L.cp.fwd_radd = all_rows ? 0 : L.conv.row_add;
+      N.cp.staged_by_prev = 1;
+    } else if (N.cp.tt == 2 && !N.cp.merged) {
+      L.cp.pre_next_phase0 = 1;
+      N.cp.pf_phase0_ready = 1;
+    }
+  }
+}
+
 static int upload_device_plans(Engine* e) {
   for (int par = 0; par < 2; ++par) {
     std::vector<DevLaunch> dv(e->plan[par].size());
@@ -522,12 +594,22 @@ static int upload_device_plans(Engine* e) {
       std::memset(&d, 0, sizeof(d));
       d.ck = L.ck;
       switch (L.kind) {
-        case Launch::CONV: d.op = DEV_OP_CONV; d.conv = L.conv; break;
+        case Launch::CONV: d.op = DEV_OP_CONV; d.conv = L.conv; d.cp = make_conv_plan(L.ck, L.conv); d.cp.fwd_rmul = 1; break;
         case Launch::LSTM: d.op = DEV_OP_LSTM; d.lstm = L.lstm; break;
         case Launch::CTFA: d.op = DEV_OP_CTFA; d.ctfa = L.ctfa; break;
         case Launch::INLAYER: d.op = DEV_OP_INLAYER; d.inl = L.inl; break;
         case Launch::OUTCONV: d.op = DEV_OP_OUTCONV; d.outc = L.outc; break;
       }
+    }
+    plan_handoffs(e->plan[par], &dv);
+    if (par == 0 && getenv("NUTLS_DUMP_PLAN")) {
+      for (size_t i = 0; i < dv.size(); ++i)
+        if (dv[i].op == DEV_OP_CONV) {
+          const ConvPlan& c = dv[i].cp;
+          fprintf(stderr, "%-24s F %3d->%3d merged %d rounds %d RG %2d KS %2d gpk %2d tiles %2d | staged_by_prev %d pf0 %d hand %d fwd %d@%d r%%%d==%d pre0 %d\n",
+                  e->plan[par][i].name.c_str(), dv[i].conv.F_in, dv[i].conv.F_out, c.merged, c.rounds, c.RG, c.KS, c.gpk, c.tiles,
+                  c.staged_by_prev, c.pf_phase0_ready, c.hand_next, c.fwd_sel, c.fwd_coff4, c.fwd_rmul, c.fwd_radd, c.pre_next_phase0);
+        }
     }
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, dv.size() * sizeof(DevLaunch)));
@@ -536,7 +618,8 @@ static int upload_device_plans(Engine* e) {
     e->dplan[par] = static_cast<DevLaunch*>(p);
   }
   void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, (e->plan[0].size() + 1) * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&q, (e->plan[0].size() * 9 + 1) * sizeof(unsigned long long)));   // layer stamps + 8 sub-stamps per layer
+  HIP_TRY(hipMemset(q, 0, (e->plan[0].size() * 9 + 1) * sizeof(unsigned long long)));
   e->allocs.push_back(q);
   e->dprof = static_cast<unsigned long long*>(q);
   return NUTLS_OK;
@@ -867,6 +950,21 @@ int nutls_profile_persistent(nutls_handle* h, double* us, int n) {
   if (khz <= 0) khz = 100000;
   for (int i = 0; i < n_ops; ++i) us[i] = static_cast<double>(t[i + 1] - t[i]) * 1000.0 / khz;
   e->next_parity = 1 - par;
+  if (const char* dump = getenv("NUTLS_SUBSTAMPS")) {   // debugging aid: phase breakdown of every conv layer
+    std::vector<unsigned long long> sub(static_cast<size_t>(n_ops) * 8);
+    HIP_TRY(hipMemcpy(sub.data(), e->dprof + n_ops + 1, sub.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(dump, "w")) {
+      for (int i = 0; i < n_ops; ++i) {
+        if (e->plan[par][i].kind != Launch::CONV) continue;
+        fprintf(f, "%-24s", e->plan[par][i].name.c_str());
+        fprintf(f, " init %6.2f", static_cast<double>(sub[8 * i] - t[i]) * 1000.0 / khz);
+        const char* nm[5] = {"stage", "mfma", "pwrite", "epi", "bar"};
+        for (int k = 0; k < 5; ++k) fprintf(f, " %s %6.2f", nm[k], static_cast<double>(sub[8 * i + k + 1] - sub[8 * i + k]) * 1000.0 / khz);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
   return NUTLS_OK;
 }
 

@@ -1,21 +1,24 @@
 // Persistent "one workgroup per stream" kernel: the whole NUNet-TLS-LSTM frame step of one stream
 // runs inside ONE 1024-thread workgroup (16 waves = 4 per SIMD, one workgroup per CU), layer after
-// layer, driven by the device-resident launch plan.  Streams are independent,
-// so no inter-workgroup synchronisation exists: a layer boundary is a __syncthreads(), not a
-// kernel boundary.  At B = 256 streams this is exactly one stream per CU of the MI355X.
+// layer, driven by the device-resident plan (DevLaunch[]).  Streams are independent (SURVEY.md
+// section 8e), so no inter-workgroup synchronisation exists: a layer boundary is a
+// __syncthreads(), not a kernel boundary.  At B = 256 this is exactly one stream per CU.
 //
-// Per conv-like layer (reference blocks: models/proposed.py:198-265) the workgroup
-//   1. stages the input rows of the current (time tap, 64-channel chunk) in LDS; the global loads
-//      of the NEXT phase -- and, across layers, of the next layer's previous-frame tap, which
-//      never depends on the current frame -- are issued before the MFMA loop and land in registers
-//      while the matrix cores work (register-staged prefetch);
-//   2. splits the GEMM  D[ch,pos] = W[ch,k] X[k,pos]  into (position tile, channel tile, K slice)
-//      tasks of 32x32 outputs, one task per wave, so even a layer with 4 output positions keeps
-//      8..16 waves busy (split-K); v_mfma_f32_32x32x2_f32, exact fp32;
-//   3. drops the partial tiles into an LDS exchange buffer [k-slice][position][channel];
-//   4. re-reads it row-wise (8/16/32 lanes per output row, float4 per lane): sum of K slices + bias,
-//      LayerNorm over the row's channels with DPP shuffles, PReLU, and writes full 128-byte
-//      channels-last rows to the (up to two) destination state tensors.
+// Per conv-like layer (reference blocks: models/proposed.py:198-265):
+//   * the input rows ([prev ; cur] time taps x 64-channel chunks, zero halo) live in an LDS image;
+//     for small layers the WHOLE image (all phases) is resident and is completed by the PREVIOUS
+//     layer: its epilogue forwards the rows it just produced straight into the next layer's image
+//     and stores the rest (previous-frame tap, skip-connection channels) from registers whose
+//     global loads were issued before that layer's MFMA work ("hand-off": no global round trip and
+//     no staging step on the critical path);
+//   * the GEMM  D[ch,pos] = W[ch,k] X[k,pos]  is cut into (position tile, channel tile, K slice)
+//     tasks of 32x32 outputs, one per wave, so even a 4-position layer keeps 12..16 waves busy
+//     (split-K); v_mfma_f32_32x32x2_f32 (exact fp32); weight fragments stream from L2 through a
+//     double-buffered 4-fragment register ring, the first chunk already fetched by the previous layer;
+//   * partial tiles meet in an LDS exchange buffer [k-slice][position][channel];
+//   * the epilogue re-reads it row-wise (8/16/32 lanes per output row, float4 per lane): K-slice sum +
+//     bias, LayerNorm over the row's channels with DPP shuffles, PReLU, full-line channels-last stores
+//     to the (up to two) destination state tensors in HBM.
 #include <hip/hip_runtime.h>
 
 #include "nutls_internal.hpp"
@@ -34,7 +37,6 @@ typedef f32x4 __attribute__((address_space(1))) * g4_t;
 typedef const float __attribute__((address_space(1))) * gcf_t;
 typedef float __attribute__((address_space(1))) * gf_t;
 __device__ __forceinline__ gc4_t G4(const float* p) { return (gc4_t)(unsigned long long)p; }
-__device__ __forceinline__ gc4_t G4(const f32x4* p) { return (gc4_t)(unsigned long long)p; }
 __device__ __forceinline__ g4_t G4W(float* p) { return (g4_t)(unsigned long long)p; }
 __device__ __forceinline__ gcf_t GF(const float* p) { return (gcf_t)(unsigned long long)p; }
 __device__ __forceinline__ gf_t GFW(float* p) { return (gf_t)(unsigned long long)p; }
@@ -42,107 +44,163 @@ __device__ __forceinline__ gf_t GFW(float* p) { return (gf_t)(unsigned long long
 #define MK_LN_EPS 1e-8f
 constexpr int MK_THREADS = 1024;
 constexpr int MK_WAVES = 16;
-constexpr int MK_MAXPF = 4;                   // float4 prefetch registers per thread (256 rows x 16 chunks / 1024)
-constexpr int MK_LDS_IN = 17920;              // floats: >= 256 rows x 68, 129 row pairs x 132, 2 x 130 rows x 68
+constexpr int MK_MAXPF = 4;                   // float4 prefetch registers per thread
+constexpr int MK_LDS_IN = MK_LDS_IN_FLOATS;
 constexpr int MK_LDS_OUT = 16 * 32 * 36;      // floats: 16 tasks x 32 positions x (32+4)
 constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT) * sizeof(float);
 
-struct StageGeom {   // how one (time tap, channel chunk) of a conv input is laid out in LDS
-  int rows;          // input rows to stage (incl. halo)
-  int cc;            // channels per chunk (32 or 64)
-  int stride, padl, F_in, pitch;
-};
+#define MK_STAMP(k) do { if (sub && tid == 0) sub[k] = wall_clock64(); } while (0)
 
-__device__ __forceinline__ StageGeom make_geom(const ConvShape& sh, const ConvParams& p) {
-  StageGeom g;
-  g.cc = sh.cin < 64 ? sh.cin : 64;
-  g.stride = sh.stride;
-  g.padl = sh.padl;
-  g.F_in = p.F_in;
-  g.pitch = sh.stride == 1 ? g.cc + 4 : 2 * g.cc + 4;
-  g.rows = sh.stride == 1 ? p.F_out + sh.kf - 1 : 2 * (p.F_out + (sh.kf - 1) / 2);
-  return g;
+// LDS float offset of (image row lr, float4 column c4) inside one phase
+__device__ __forceinline__ int img_addr(const ConvPlan& c, int lr, int c4) {
+  return c.stride == 1 ? lr * c.pitch + 4 * c4 : (lr >> 1) * c.pitch + (lr & 1) * c.cc + 4 * c4;
 }
 
-// global -> registers (issue only; the wait happens at the first use in stage_store).  Only rows
-// that exist in the stream travel through registers; halo rows are zero-filled by stage_store.
-__device__ __forceinline__ void stage_load(const float* src, int src_ld, const StageGeom& g, int tid, f32x4 (&pf)[MK_MAXPF]) {
-  const int cc4 = g.cc >> 2;
-  const int nvalid = (g.rows - g.padl < g.F_in ? g.rows - g.padl : g.F_in) * cc4;
+// ---------------------------------------------------------------------------------------------
+//  Staging of a layer's LDS image through registers.  Item q (float4) -> (phase, row, column):
+//  phase = (time tap t, channel chunk ch); only rows that exist in the stream travel through
+//  registers, halo rows are zero-filled (ZeroPadding2D of proposed.py:210/:242, SAME pad of :255).
+//  float4 columns [fwd_lo4, fwd_hi4) of the CURRENT-frame tap are excluded: the producing
+//  layer's epilogue forwards them.
+// ---------------------------------------------------------------------------------------------
+struct ItemAddr { int ph, row, c4, chan4; bool cur; };
+__device__ __forceinline__ ItemAddr item_of(const ConvPlan& c, int q) {
+  ItemAddr a;
+  a.ph = q >> c.n4p_shift;
+  const int r = q & ((1 << c.n4p_shift) - 1);
+  a.row = r >> c.cc4_shift;
+  a.c4 = r & ((1 << c.cc4_shift) - 1);
+  const int t = a.ph >> c.nch_shift, ch = a.ph & ((1 << c.nch_shift) - 1);
+  a.chan4 = (ch << c.cc4_shift) + a.c4;
+  a.cur = (t == c.tt - 1);
+  return a;
+}
+
+// phases [ph0, ph0+nphases) of layer (p, c) -> registers
+struct FwdWin { int lo4, hi4, rmul, radd; };   // float4 columns [lo4,hi4) of rows (row % rmul == radd) are forwarded
+__device__ __forceinline__ bool is_fwd(const FwdWin& f, const ItemAddr& a) {
+  return a.cur && a.chan4 >= f.lo4 && a.chan4 < f.hi4 && (a.row & (f.rmul - 1)) == f.radd;
+}
+
+__device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& c, int stream, int ph0, int nphases, const FwdWin& fw,
+                                           int tid, f32x4 (&pf)[MK_MAXPF]) {
+  const float* s0 = p.src0 + static_cast<size_t>(stream) * p.F_in * p.src_ld;
+  const float* s1 = p.src1 ? p.src1 + static_cast<size_t>(stream) * p.F_in * p.src_ld : s0;
+  const int n = nphases << c.n4p_shift;
 #pragma unroll
   for (int i = 0; i < MK_MAXPF; ++i) {
     const int q = tid + i * MK_THREADS;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q < nvalid) {
-      const int c4 = q & (cc4 - 1);
-      const int gr = q / cc4;
-      v = *G4(src + static_cast<size_t>(gr) * src_ld + 4 * c4);
+    if (q < n) {
+      const ItemAddr a = item_of(c, q + (ph0 << c.n4p_shift));
+      if (!is_fwd(fw, a)) {
+        const float* src = ((a.ph >> c.nch_shift) == 1) ? s1 : s0;
+        v = *G4(src + static_cast<size_t>(a.row) * p.src_ld + 4 * a.chan4);
+      }
     }
     pf[i] = v;
   }
 }
 
-__device__ __forceinline__ int stage_lds_addr(const StageGeom& g, int lr, int c4) {
-  return g.stride == 1 ? lr * g.pitch + 4 * c4 : (lr >> 1) * g.pitch + (lr & 1) * g.cc + 4 * c4;
-}
-
-// registers -> LDS (+ zero halo rows: the ZeroPadding2D of proposed.py:210/:242 and the SAME pad of :255)
-__device__ __forceinline__ void stage_store(float* lds_in, const StageGeom& g, int tid, const f32x4 (&pf)[MK_MAXPF]) {
-  const int cc4 = g.cc >> 2;
-  const int vrows = g.rows - g.padl < g.F_in ? g.rows - g.padl : g.F_in;
-  const int nvalid = vrows * cc4;
+// registers -> LDS image (phase ph lands at lds_in + (ph - ph_base) * phase_floats) + zero halo rows
+__device__ __forceinline__ void image_store(const ConvPlan& c, float* lds_in, int ph0, int nphases, int ph_base, const FwdWin& fw,
+                                            int tid, const f32x4 (&pf)[MK_MAXPF]) {
+  const int n = nphases << c.n4p_shift;
 #pragma unroll
   for (int i = 0; i < MK_MAXPF; ++i) {
     const int q = tid + i * MK_THREADS;
-    if (q < nvalid) *reinterpret_cast<f32x4*>(lds_in + stage_lds_addr(g, g.padl + q / cc4, q & (cc4 - 1))) = pf[i];
+    if (q < n) {
+      const ItemAddr a = item_of(c, q + (ph0 << c.n4p_shift));
+      if (!is_fwd(fw, a)) *reinterpret_cast<f32x4*>(lds_in + (a.ph - ph_base) * c.phase_floats + img_addr(c, c.padl + a.row, a.c4)) = pf[i];
+    }
   }
-  const int nhalo = (g.rows - vrows) * cc4;          // <= 3 rows
-  if (tid < nhalo) {
-    const int hr = tid / cc4;
-    const int lr = hr < g.padl ? hr : vrows + hr;    // top halo rows first, then the bottom ones
+  const int hrows = c.rows - c.vrows;                       // <= 3 halo rows per phase
+  const int nh = (hrows * nphases) << c.cc4_shift;          // <= 3 * 4 * 16 = 192 float4
+  if (tid < nh) {
+    const int c4 = tid & ((1 << c.cc4_shift) - 1);
+    const int hr_all = tid >> c.cc4_shift;
+    const int phl = hr_all / hrows, hr = hr_all - phl * hrows;
+    const int lr = hr < c.padl ? hr : c.vrows + hr;         // top halo rows first, then the bottom ones
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(lds_in + stage_lds_addr(g, lr, tid & (cc4 - 1))) = z;
+    *reinterpret_cast<f32x4*>(lds_in + (ph0 - ph_base + phl) * c.phase_floats + img_addr(c, lr, c4)) = z;
   }
 }
 
-__device__ __forceinline__ ConvShape dev_conv_shape(int k) {
-  //                     cin  nt  s  tt kf padl ln g      (mirror of conv_shape() in kernels.hip)
-  switch (k) {
-    case CONV_EL_C32:   return {32,  1, 2, 2, 3, 1, 1, 1};
-    case CONV_EL_C64:   return {64,  1, 2, 2, 3, 1, 1, 1};
-    case CONV_EL_C128:  return {128, 1, 2, 2, 3, 1, 1, 1};
-    case CONV_DL_N64:   return {64,  2, 1, 2, 3, 1, 1, 1};
-    case CONV_DL_N128:  return {64,  4, 1, 2, 3, 1, 1, 2};
-    case CONV_IN_C64:   return {64,  2, 1, 1, 1, 0, 1, 2};
-    case CONV_IN_C128:  return {128, 2, 1, 1, 1, 0, 1, 2};
-    case CONV_DOWN:     return {64,  2, 2, 1, 3, 0, 0, 2};
-    case CONV_UP_EVEN:  return {128, 4, 1, 1, 2, 1, 0, 4};
-    default:            return {128, 4, 1, 1, 1, 0, 0, 4};   // CONV_UP_ODD
+// ---------------------------------------------------------------------------------------------
+//  MFMA part of one round of one task.  4-group chunks: the next chunk's 4 weight fragments
+//  (1 KiB per wave load, L2) are in flight while the current chunk's 16 MFMAs issue.
+// ---------------------------------------------------------------------------------------------
+struct WeightCursor {   // wave-uniform
+  gc4_t base;           // packed weights + (k-slice, channel tile) offset of this task, round 0
+  int wstep;            // float4 between consecutive groups (NT * 64)
+  int round_step;       // float4 between consecutive rounds of this task (RG * wstep)
+};
+
+__device__ __forceinline__ void load_chunk(f32x4 (&w)[4], gc4_t ptr, int wstep, int lane) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) w[u] = ptr[u * wstep + lane];
+}
+
+__device__ __forceinline__ void mfma_round(f32x16& acc, f32x4 (&wa)[4], const WeightCursor& wc, int rd, bool last_round,
+                                           const ConvPlan& c, const float* lds_lane, int ks, int lane) {
+  const int nchunks = c.gpk >> 2;
+  gc4_t wp = wc.base + static_cast<size_t>(rd) * wc.round_step;
+  // wave-uniform cursor over the resident image: (local phase, frequency tap, first group of the chunk)
+  const int g_first = ks * c.gpk;
+  const int seg = g_first / c.gpc;
+  int gg = g_first - seg * c.gpc;
+  int phl = seg / c.kf, kf = seg - phl * c.kf;
+#pragma unroll 1
+  for (int ch = 0; ch < nchunks; ++ch) {
+    // prefetch the next chunk: next in this slice, else the first chunk of the next round's slice,
+    // else re-read the current one (harmless, keeps the loop free of divergent control flow)
+    f32x4 wb[4];
+    {
+      gc4_t np = (ch + 1 < nchunks) ? wp + 4 * wc.wstep : (last_round ? wp : wc.base + static_cast<size_t>(rd + 1) * wc.round_step);
+      load_chunk(wb, np, wc.wstep, lane);
+    }
+    const int koff = (c.stride == 1) ? kf * c.pitch : ((kf >> 1) * c.pitch + (kf & 1) * c.cc);
+    const float* bp = lds_lane + phl * c.phase_floats + koff + 8 * gg;
+    f32x4 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const f32x4*>(bp + 8 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], b[u][j], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wa[u] = wb[u];
+    wp += 4 * wc.wstep;
+    gg += 4;
+    if (gg == c.gpc) { gg = 0; if (++kf == c.kf) { kf = 0; ++phl; } }
   }
 }
 
-// Row-wise epilogue: LPG lanes per output row (row = LPG*4 channels), optional LN + PReLU.
+// ---------------------------------------------------------------------------------------------
+//  Row-wise epilogue: LPG lanes per output row (row = LPG*4 channels), optional LN + PReLU; writes
+//  HBM destinations and, when `nx` is given, forwards the rows into the next layer's LDS image.
+// ---------------------------------------------------------------------------------------------
 template <int LPG, bool LN>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, int stream, const float* lds_out, int KS, int slot_floats,
-                                              int opitch, int R, int tid) {
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPlan& c, int stream, const float* lds_out, int tid,
+                                              f32x4 bias, f32x4 gm, f32x4 bt, const ConvPlan* nx, float* lds_next, int fwd_sel,
+                                              int fwd_coff4) {
   constexpr int GC = LPG * 4;
   const int li = tid & (LPG - 1);
-  const int units = p.F_out * R;
-  const f32x4 bias_dummy = {0.f, 0.f, 0.f, 0.f};
-  (void)bias_dummy;
-  f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
-  if (LN) {
-    gm = *G4(p.gamma + 4 * li);
-    bt = *G4(p.beta + 4 * li);
-  }
+  const int units = p.F_out * c.R;
   float* d0 = p.dst0 + static_cast<size_t>(stream) * (p.F_out * p.row_mul) * p.ld0;
   float* d1 = p.dst1 ? p.dst1 + static_cast<size_t>(stream) * (p.F_out * p.row_mul) * p.ld1 : nullptr;
+  // forwarded block inside the next image: float4 column (coff4 + li) of the current-frame phase
+  int f_ph = 0, f_c4 = 0;
+  if (nx && fwd_sel) {
+    const int chan4 = fwd_coff4 + li;
+    f_ph = ((nx->tt - 1) << nx->nch_shift) + (chan4 >> nx->cc4_shift);
+    f_c4 = chan4 & ((1 << nx->cc4_shift) - 1);
+  }
   for (int u = tid / LPG; u < units; u += MK_THREADS / LPG) {
-    const int pos = u / R, gi = u - pos * R;      // R is 1 or 2
-    const int ch = gi * GC + 4 * li;
-    f32x4 v = *G4(p.bias + ch);
-    const float* o = lds_out + pos * opitch + ch;
-    for (int ks = 0; ks < KS; ++ks) v += *reinterpret_cast<const f32x4*>(o + ks * slot_floats);
+    const int pos = (c.R == 2) ? (u >> 1) : u, gi = (c.R == 2) ? (u & 1) : 0;
+    const float* o = lds_out + pos * c.opitch + gi * GC + 4 * li;
+    f32x4 v = bias;
+    for (int ks = 0; ks < c.KS; ++ks) v += *reinterpret_cast<const f32x4*>(o + ks * c.slot_floats);
     if (LN) {
       float s = v[0] + v[1] + v[2] + v[3];
 #pragma unroll
@@ -159,208 +217,134 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int stream, c
         v[i] = y >= 0.f ? y : p.alpha * y;
       }
     }
-    const size_t row = static_cast<size_t>(pos) * p.row_mul + p.row_add + gi;
-    *G4W(d0 + row * p.ld0 + 4 * li) = v;
-    if (d1) *G4W(d1 + row * p.ld1 + 4 * li) = v;
+    const int row = pos * p.row_mul + p.row_add + gi;
+    *G4W(d0 + static_cast<size_t>(row) * p.ld0 + 4 * li) = v;
+    if (d1) *G4W(d1 + static_cast<size_t>(row) * p.ld1 + 4 * li) = v;
+    if (nx && fwd_sel) *reinterpret_cast<f32x4*>(lds_next + f_ph * nx->phase_floats + img_addr(*nx, nx->padl + row, f_c4)) = v;
   }
 }
 
-// This wave's weight stream: fragments are consumed in order (round, group); a RING-deep register
-// ring holds the next RING fragments, whose loads were issued RING groups earlier.  All cursor
-// state is wave-uniform (SGPRs); the only per-lane part of an address is lane*16 bytes.
-template <int RING>
-struct WeightStream {
-  gc4_t base;          // wave-uniform: packed weights + this task's (k-slice, channel tile) offset
-  int wstep;           // float4 between consecutive groups  (NT * 64)
-  int gpk, rounds;     // groups per slice, slices (one per round) in this wave's stream
-  int round_step;      // float4 between the starts of consecutive slices (RG * wstep)
-  int pre_gi, pre_r;   // prefetch cursor
-  int pre_off;         // float4 offset of the prefetch cursor from base
-  f32x4 ring[RING];
-
-  __device__ __forceinline__ void init(gc4_t b, int wstep_, int gpk_, int rounds_, int round_step_, int lane) {
-    base = b; wstep = wstep_; gpk = gpk_; rounds = rounds_; round_step = round_step_;
-    pre_gi = 0; pre_r = 0; pre_off = 0;
-#pragma unroll
-    for (int u = 0; u < RING; ++u) { ring[u] = base[pre_off + lane]; advance(); }
-  }
-  // move the prefetch cursor one group ahead; past the end of the stream it parks on the last
-  // fragment (re-loading it is harmless and keeps the loop free of divergent control flow)
-  __device__ __forceinline__ void advance() {
-    int gi = pre_gi + 1, r = pre_r, off = pre_off + wstep;
-    if (gi == gpk) { gi = 0; r += 1; off += round_step - gpk * wstep; }
-    const bool end = r >= rounds;
-    pre_gi = end ? pre_gi : gi;
-    pre_r = end ? pre_r : r;
-    pre_off = end ? pre_off : off;
-  }
-};
-
-// The MFMA part of one round of one task: `gpk` consecutive 8-channel groups starting at group
-// `g_first` of the resident LDS phases.
-template <int RING>
-__device__ __forceinline__ void mfma_slice(f32x16& acc, WeightStream<RING>& ws, const float* lds_lane, int g_first, int gpp,
-                                           int gpc, const StageGeom& g, int phase_floats, int lane) {
-  // wave-uniform cursor over (local phase, frequency tap, channel group)
-  int phl = g_first / gpp;
-  int rem = g_first - phl * gpp;
-  int kf = rem / gpc, gg = rem - kf * gpc;
-  auto b_off = [&]() {
-    const int koff = (g.stride == 1) ? kf * g.pitch : ((kf >> 1) * g.pitch + (kf & 1) * g.cc);
-    return phl * phase_floats + koff + 8 * gg;
-  };
-  auto step = [&]() {
-    int ngg = gg + 1, nkf = kf, nph = phl;
-    if (ngg == gpc) { ngg = 0; nkf += 1; }
-    if (nkf * gpc == gpp) { nkf = 0; nph += 1; }
-    gg = ngg; kf = nkf; phl = nph;
-  };
-  f32x4 b_cur = *reinterpret_cast<const f32x4*>(lds_lane + b_off());
-#pragma unroll 1
-  for (int gi = 0; gi < ws.gpk; gi += RING) {
-#pragma unroll
-    for (int u = 0; u < RING; ++u) {
-      const f32x4 a = ws.ring[u];
-      ws.ring[u] = ws.base[ws.pre_off + lane];     // fragment RING groups ahead (parked at the end)
-      ws.advance();
-      const f32x4 b = b_cur;
-      step();
-      // next B fragment (the read after the slice's last group is unused; its address stays inside LDS)
-      b_cur = *reinterpret_cast<const f32x4*>(lds_lane + ((gi + u + 1 < ws.gpk) ? b_off() : 0));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-    }
-  }
-}
-
-struct ConvTask {        // how one layer is spread over the 16 waves
-  int nstage;            // phases resident in LDS at once (1, or all of them for small layers)
-  int rounds;            // nph / nstage
-  int RG;                // 8-channel groups per round = nstage * gpp
-  int KS, gpk;           // K slices per round, groups per slice
-  int PT, NT, tiles;
-  int phase_floats;      // LDS floats of one staged phase
-  int per_thread;        // float4 staged per thread per phase
-};
-
-__device__ __forceinline__ ConvTask plan_task(const ConvShape& sh, const StageGeom& g, int F_out, int ring) {
-  ConvTask t;
-  const int nch = sh.cin / g.cc, nph = sh.tt * nch;
-  const int gpp = sh.kf * (g.cc >> 3);
-  t.phase_floats = (sh.stride == 1 ? g.rows : (g.rows >> 1)) * g.pitch;
-  const int n4 = (g.rows - g.padl < g.F_in ? g.rows - g.padl : g.F_in) * (g.cc >> 2);
-  t.per_thread = (n4 + MK_THREADS - 1) / MK_THREADS;
-  // small layers: keep every (time tap, channel chunk) resident -> one barrier, deeper split-K
-  const bool merge = (nph * t.phase_floats <= MK_LDS_IN) && (nch * t.per_thread <= MK_MAXPF);
-  t.nstage = merge ? nph : 1;
-  t.rounds = nph / t.nstage;
-  t.RG = t.nstage * gpp;
-  t.PT = (F_out + 31) >> 5;
-  t.NT = sh.nt;
-  t.tiles = t.PT * t.NT;
-  int ks = MK_WAVES / t.tiles;
-  if (ks < 1) ks = 1;
-  int kmax = t.RG / ring;              // slices must hold whole rings
-  kmax = kmax & (-kmax);               // largest power-of-two divisor
-  t.KS = ks < kmax ? ks : kmax;
-  t.gpk = t.RG / t.KS;
-  return t;
-}
-
-// One conv-like layer for one stream.  On entry `pf` may already hold the issued loads of this
-// layer's previous-frame tap (`have_pf`); on exit it holds the next layer's when that layer is a
-// two-tap conv (its previous-frame rows never depend on the current frame).
-template <int RING>
-__device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvShape& sh, int stream, float* lds_in, float* lds_out,
-                                           int tid, f32x4 (&pf)[MK_MAXPF], bool have_pf, const DevLaunch* next) {
-  const StageGeom g = make_geom(sh, p);
-  const ConvTask T = plan_task(sh, g, p.F_out, RING);
+// One conv-like layer for one stream.
+//   pf      in : this layer's phase-0 loads when cp.pf_phase0_ready;  out: the next layer's prefetch
+//   wnext   in : this task's first weight chunk when `have_w`;        out: next layer's first chunk
+__device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* N, int stream, float* lds_in, float* lds_out, int tid,
+                                           f32x4 (&pf)[MK_MAXPF], f32x4 (&wnext)[4], bool& have_w, unsigned long long* sub) {
+  const ConvParams& p = L.conv;
+  const ConvPlan& c = L.cp;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SGPR
   const int pl = lane & 31, h = lane >> 5;
-  const int nch = sh.cin / g.cc;
-  const int gpc = g.cc >> 3;                       // 8-channel groups per frequency tap
-  const int gpp = sh.kf * gpc;
-  const bool active = wave < T.tiles * T.KS;
-  const int ks = wave / T.tiles, tl = wave - ks * T.tiles;
-  const int pt = tl / T.NT, nt = tl - pt * T.NT;
+  const bool active = wave < c.tiles * c.KS;
+  const int ks = wave >> c.tiles_shift, tl = wave & (c.tiles - 1);
+  const int pt = tl >> c.nt_shift, nt = tl & (c.nt - 1);
   int pc = pt * 32 + pl;
   if (pc > p.F_out - 1) pc = p.F_out - 1;          // padding lanes recompute the last position
-  const float* lds_lane = lds_in + pc * g.pitch + 4 * h;
-  const int wstep = T.NT * 64;
+  const float* lds_lane = lds_in + pc * c.pitch + 4 * h;
 
-  const float* s0 = p.src0 + static_cast<size_t>(stream) * p.F_in * p.src_ld;
-  const float* s1 = p.src1 ? p.src1 + static_cast<size_t>(stream) * p.F_in * p.src_ld : s0;
+  WeightCursor wc;
+  wc.wstep = c.nt * 64;
+  wc.round_step = c.RG * wc.wstep;
+  wc.base = (gc4_t)(unsigned long long)p.wpk + (static_cast<size_t>(ks * c.gpk) * c.nt + nt) * 64;
 
-  // ---- weight ring: first RING fragments of this wave's stream, issued before anything else
-  WeightStream<RING> ws;
-  if (active)
-    ws.init(G4(p.wpk) + (static_cast<size_t>(ks * T.gpk) * T.NT + nt) * 64, wstep, T.gpk, T.rounds,
-            T.RG * wstep, lane);
-
-  // ---- stage round 0
-  if (T.nstage == 1) {
-    if (!have_pf) stage_load(s0, p.src_ld, g, tid, pf);
-    stage_store(lds_in, g, tid, pf);
-  } else {
-    // all phases resident: phase ph = t*nch + ch at lds_in + ph*phase_floats
-    for (int ph = 0; ph < T.nstage; ++ph) {
-      const int t = ph / nch, ch = ph - t * nch;
-      if (!(have_pf && ph == 0)) stage_load((t ? s1 : s0) + ch * g.cc, p.src_ld, g, tid, pf);
-      stage_store(lds_in + ph * T.phase_floats, g, tid, pf);
+  // ---- first weight chunk (unless the previous layer already fetched it)
+  f32x4 wa[4];
+  if (active) {
+    if (have_w) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wa[u] = wnext[u];
+    } else {
+      load_chunk(wa, wc.base, wc.wstep, lane);
     }
   }
-  __syncthreads();
+  MK_STAMP(0);
+
+  const FwdWin nofw = {0, 0, 1, 0};
+  // ---- LDS image of round 0 (skipped when the previous layer handed it over complete)
+  const int nstage = c.merged ? c.nph : 1;
+  if (!c.staged_by_prev) {
+    if (!c.pf_phase0_ready) image_load(p, c, stream, 0, nstage, nofw, tid, pf);
+    image_store(c, lds_in, 0, nstage, 0, nofw, tid, pf);
+    __syncthreads();
+  }
+  MK_STAMP(1);
+
+  // what this layer owes the next one
+  const bool nconv = N && N->op == DEV_OP_CONV;
+  const bool hand = nconv && c.hand_next;
+  const bool pre0 = nconv && c.pre_next_phase0;
+  FwdWin fw = nofw;
+  if (hand && c.fwd_sel) { fw.lo4 = c.fwd_coff4; fw.hi4 = c.fwd_coff4 + c.lpg; fw.rmul = c.fwd_rmul; fw.radd = c.fwd_radd; }
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
 #pragma unroll 1
-  for (int rd = 0; rd < T.rounds; ++rd) {
-    const bool more = rd + 1 < T.rounds;
-    if (more) {   // nstage == 1 here: prefetch the next phase's rows into registers
-      const int t = (rd + 1) / nch, ch = (rd + 1) - t * nch;
-      stage_load((t ? s1 : s0) + ch * g.cc, p.src_ld, g, tid, pf);
+  for (int rd = 0; rd < c.rounds; ++rd) {
+    const bool last = rd + 1 == c.rounds;
+    if (!last) {
+      image_load(p, c, stream, rd + 1, 1, nofw, tid, pf);          // next phase of THIS layer
+    } else {
+      // prefetch for the NEXT layer: everything its image needs that this layer does not produce
+      if (hand) image_load(N->conv, N->cp, stream, 0, N->cp.nph, fw, tid, pf);
+      else if (pre0) image_load(N->conv, N->cp, stream, 0, 1, nofw, tid, pf);
     }
-    if (active) mfma_slice<RING>(acc, ws, lds_lane, ks * T.gpk, gpp, gpc, g, T.phase_floats, lane);
-    if (more) {
+    if (active) mfma_round(acc, wa, wc, rd, last, c, lds_lane, ks, lane);
+    if (!last) {
       __syncthreads();           // every wave is done reading this phase's LDS rows
-      stage_store(lds_in, g, tid, pf);
+      image_store(c, lds_in, rd + 1, 1, rd + 1, nofw, tid, pf);
       __syncthreads();
     }
   }
+  MK_STAMP(2);
 
-  // ---- cross-layer prefetch of the next layer's previous-frame tap (independent of this frame)
-  if (next && next->op == DEV_OP_CONV) {
-    const ConvShape nsh = dev_conv_shape(next->ck);
-    if (nsh.tt == 2) {
-      const StageGeom ng = make_geom(nsh, next->conv);
-      stage_load(next->conv.src0 + static_cast<size_t>(stream) * next->conv.F_in * next->conv.src_ld, next->conv.src_ld, ng, tid, pf);
+  // ---- epilogue parameters + the next layer's first weight chunk: issued before the exchange barrier
+  const int lpg = c.lpg;
+  const int li = tid & (lpg - 1);
+  const int gi_mine = (c.R == 2) ? ((tid / lpg) & 1) : 0;
+  const f32x4 bias = *G4(p.bias + gi_mine * (4 * lpg) + 4 * li);
+  f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+  if (c.epi_ln) {
+    gm = *G4(p.gamma + 4 * li);
+    bt = *G4(p.beta + 4 * li);
+  }
+  have_w = false;
+  if (nconv) {
+    const ConvPlan& n = N->cp;
+    if (wave < n.tiles * n.KS) {
+      const int nks = wave >> n.tiles_shift, ntl = wave & (n.tiles - 1);
+      const int nnt = ntl & (n.nt - 1);
+      load_chunk(wnext, (gc4_t)(unsigned long long)N->conv.wpk + (static_cast<size_t>(nks * n.gpk) * n.nt + nnt) * 64, n.nt * 64, lane);
     }
+    have_w = true;
   }
 
   // ---- partial tiles -> LDS exchange buffer [ks][pos][32*NT (+4)]
-  const int opitch = 32 * T.NT + 4;
-  const int slot_floats = T.PT * 32 * opitch;
   if (active) {
-    float* o = lds_out + ks * slot_floats + (pt * 32 + pl) * opitch + nt * 32 + 4 * h;
+    float* o = lds_out + ks * c.slot_floats + (pt * 32 + pl) * c.opitch + nt * 32 + 4 * h;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
       *reinterpret_cast<f32x4*>(o + 8 * q) = v;
     }
   }
-  __syncthreads();
-  const int R = T.NT / sh.g;
-  if (sh.epi_ln) {
-    if (sh.g == 1) conv_epilogue<8, true>(p, stream, lds_out, T.KS, slot_floats, opitch, R, tid);
-    else conv_epilogue<16, true>(p, stream, lds_out, T.KS, slot_floats, opitch, R, tid);
+  __syncthreads();               // also: every wave has finished reading lds_in
+  MK_STAMP(3);
+
+  // ---- hand-off: the prefetched part of the next layer's image (the forwarded part follows in the epilogue)
+  if (hand) image_store(N->cp, lds_in, 0, N->cp.nph, 0, fw, tid, pf);
+
+  const ConvPlan* nx = hand ? &N->cp : nullptr;
+  if (c.epi_ln) {
+    if (c.g == 1) conv_epilogue<8, true>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
+    else conv_epilogue<16, true>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
   } else {
-    if (sh.g == 2) conv_epilogue<16, false>(p, stream, lds_out, T.KS, slot_floats, opitch, R, tid);
-    else conv_epilogue<32, false>(p, stream, lds_out, T.KS, slot_floats, opitch, R, tid);
+    if (c.g == 2) conv_epilogue<16, false>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
+    else conv_epilogue<32, false>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
   }
-  __syncthreads();               // stores visible to the whole workgroup, LDS free for the next layer
+  MK_STAMP(4);
+  __syncthreads();               // HBM stores visible to the workgroup; next image complete; exchange buffer free
+  MK_STAMP(5);
 }
 
 __device__ __forceinline__ float mk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -372,8 +356,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // LSTM cell + Dense for one stream (models/proposed.py:70-119; converter_proposed.py:234-237):
-// 8 K-slices x 128 gate slots, reduced through LDS.  All weight loads are issued up front
-// (independent of the gathered input) so only one memory latency is exposed.
+// 8 K-slices x 128 gate slots, reduced through LDS.  Weight loads are issued ahead of the barriers
+// that separate the stages so only one memory latency is exposed per stage.
 __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, float* lds, int tid) {
   float* v = lds;              // [256]
   float* hs = lds + 256;       // [32]
@@ -382,7 +366,6 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
   float* hn = z + 96;          // [32]
   const int n = tid & 127, sl = tid >> 7;
   const int kn = p.Din >> 3, k0 = sl * kn;       // kn in {4, 8, 16, 32}
-  // first batch of input weights + recurrent weights: issued before the input gather's barrier
   float w[8];
   if (n < 84) {
 #pragma unroll
@@ -426,7 +409,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
     for (int s = 0; s < 8; ++s) a += part[s * 84 + tid];
     z[tid] = a + r;
   }
-  // dense weights for the output rows this thread owns (Dout <= 256 -> one row per thread)
+  // dense weights for the output row this thread owns (Dout <= 256 -> one row per thread)
   float wd[21];
   float bd = 0.f;
   if (tid < p.Dout) {
@@ -581,18 +564,15 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Dev
 #pragma unroll 1
     while (i < n_ops) {
       if (plan[i].op == DEV_OP_CONV) {
-        // a run of consecutive conv layers: the activation prefetch registers live only here
+        // a run of consecutive conv layers: prefetch registers (activations, first weight chunk) live only here
         f32x4 pf[MK_MAXPF];
-        bool have_pf = false;
+        f32x4 wnext[4];
+        bool have_w = false;
 #pragma unroll 1
         while (i < n_ops && plan[i].op == DEV_OP_CONV) {
-          const DevLaunch& L = plan[i];
           if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
-          const DevLaunch* next = (i + 1 < n_ops) ? &plan[i + 1] : nullptr;
-          const ConvShape sh = dev_conv_shape(L.ck);
-          if (sh.kf == 3) conv_layer<3>(L.conv, sh, stream, lds_in, lds_out, tid, pf, have_pf, next);
-          else conv_layer<4>(L.conv, sh, stream, lds_in, lds_out, tid, pf, have_pf, next);
-          have_pf = next && next->op == DEV_OP_CONV && dev_conv_shape(next->ck).tt == 2;
+          unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
+          conv_layer(plan[i], (i + 1 < n_ops) ? &plan[i + 1] : nullptr, stream, lds_in, lds_out, tid, pf, wnext, have_w, sub);
           ++i;
         }
       } else {

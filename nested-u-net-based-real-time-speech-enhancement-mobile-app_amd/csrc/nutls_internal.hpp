@@ -111,6 +111,26 @@ hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
 // (megakernel.hip), which runs the whole frame step of one stream inside one workgroup.
 enum DevOp : int { DEV_OP_CONV = 0, DEV_OP_LSTM, DEV_OP_CTFA, DEV_OP_INLAYER, DEV_OP_OUTCONV };
 constexpr int NUTLS_DEV_BINS = 256;
+// Host-precomputed execution plan of one conv-like layer inside the persistent kernel (all the
+// integer bookkeeping the kernel would otherwise redo per layer: LDS geometry, task split, hand-off).
+struct ConvPlan {
+  int cin, nt, stride, tt, kf, padl, epi_ln, g;      // copy of ConvShape
+  // LDS image of one phase (= one (time tap, 64-channel chunk)): rows x channels, padded pitch
+  int cc, cc4_shift, pitch, rows, vrows, n4p_shift, nch_shift, nph, phase_floats;
+  // task decomposition over the 16 waves
+  int merged;            // every phase resident at once (rounds == 1)
+  int rounds, RG, KS, gpk, gpc, PT, tiles, tiles_shift, nt_shift;
+  int opitch, slot_floats, R, lpg;
+  // hand-off between consecutive layers
+  int staged_by_prev;    // the previous layer's epilogue already completed this layer's LDS image
+  int pf_phase0_ready;   // the previous layer already issued this layer's phase-0 loads into the prefetch registers
+  int hand_next;         // complete the next layer's LDS image in this layer's epilogue
+  int fwd_sel;           // 1 / 2: rows written to dst0 / dst1 are also forwarded into the next layer's image
+  int fwd_coff4;         // float4 offset of the forwarded block inside the next layer's input row
+  int fwd_rmul, fwd_radd; // rows this layer writes: row % fwd_rmul == fwd_radd (1, 0 = every row)
+  int pre_next_phase0;   // next is an un-merged two-tap conv: prefetch its phase 0 (previous-frame rows)
+};
+
 struct DevLaunch {
   int op;   // DevOp
   int ck;   // ConvKind when op == DEV_OP_CONV
@@ -122,7 +142,12 @@ struct DevLaunch {
     InLayerParams inl;
     OutConvParams outc;
   };
+  ConvPlan cp;   // valid when op == DEV_OP_CONV
 };
+constexpr int MK_LDS_IN_FLOATS = 17920;   // staged input: >= 256 rows x 68, 129 row pairs x 132, 2 x 130 rows x 68
+constexpr int MK_STAGE_ITEMS = 4096;      // float4 a merged layer may stage through registers (4 per thread)
+// Fills everything of ConvPlan except the hand-off fields.
+ConvPlan make_conv_plan(ConvKind k, const ConvParams& p);
 // grid = number of workgroups (each loops over streams blockIdx.x, +grid, ...); prof (nullable)
 // receives wall_clock64() at every layer boundary of workgroup 0 (n_ops + 1 entries).
 hipError_t launch_stream_step(const DevLaunch* plan, int n_ops, int B, int grid, unsigned long long* prof, hipStream_t s);

@@ -98,4 +98,52 @@ std::vector<float> pack_conv_weights(const HostTensor& w, const std::vector<int>
   return out;
 }
 
+static int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+ConvPlan make_conv_plan(ConvKind k, const ConvParams& p) {
+  const ConvShape sh = conv_shape(k);
+  ConvPlan c{};
+  c.cin = sh.cin; c.nt = sh.nt; c.stride = sh.stride; c.tt = sh.tt; c.kf = sh.kf; c.padl = sh.padl; c.epi_ln = sh.epi_ln; c.g = sh.g;
+  c.cc = sh.cin < 64 ? sh.cin : 64;
+  c.cc4_shift = ilog2_exact(c.cc / 4);
+  c.pitch = sh.stride == 1 ? c.cc + 4 : 2 * c.cc + 4;
+  c.rows = sh.stride == 1 ? p.F_out + sh.kf - 1 : 2 * (p.F_out + (sh.kf - 1) / 2);
+  c.vrows = (c.rows - sh.padl < p.F_in) ? c.rows - sh.padl : p.F_in;
+  c.n4p_shift = ilog2_exact(c.vrows * (c.cc / 4));
+  const int nch = sh.cin / c.cc;
+  c.nch_shift = ilog2_exact(nch);
+  c.nph = sh.tt * nch;
+  c.phase_floats = (sh.stride == 1 ? c.rows : c.rows / 2) * c.pitch;
+  c.merged = (c.nph * c.phase_floats <= MK_LDS_IN_FLOATS) && (c.nph * (c.vrows * (c.cc / 4)) <= MK_STAGE_ITEMS);
+  const int nstage = c.merged ? c.nph : 1;
+  c.rounds = c.nph / nstage;
+  c.gpc = c.cc / 8;
+  c.RG = nstage * sh.kf * c.gpc;
+  c.PT = (p.F_out + 31) / 32;
+  c.tiles = c.PT * sh.nt;
+  c.tiles_shift = ilog2_exact(c.tiles);
+  c.nt_shift = ilog2_exact(sh.nt);
+  // K split: the largest slice count that keeps <= 16 tasks, whole 4-group chunks per slice, and
+  // slices that are either one chunk or whole frequency-tap segments
+  int best = 1;
+  for (int ks = 1; ks <= 16 / c.tiles; ++ks) {
+    if (c.RG % ks) continue;
+    const int gpk = c.RG / ks;
+    if (gpk % 4) continue;
+    if (!(gpk % c.gpc == 0 || c.gpc % gpk == 0)) continue;
+    best = ks;
+  }
+  c.KS = best;
+  c.gpk = c.RG / best;
+  c.opitch = 32 * sh.nt + 4;
+  c.slot_floats = c.PT * 32 * c.opitch;
+  c.R = sh.nt / sh.g;
+  c.lpg = 8 * sh.g;
+  return c;
+}
+
 }  // namespace nutls
