@@ -578,9 +578,12 @@ static void plan_handoffs(const std::vector<Launch>& plan, std::vector<DevLaunch
       L.cp.fwd_rmul = all_rows ? 1 : L.conv.row_mul;
       L.cp.fwd_radd = all_rows ? 0 : L.conv.row_add;
       N.cp.staged_by_prev = 1;
-    } else if (N.cp.tt == 2 && !N.cp.merged) {
-      L.cp.pre_next_phase0 = 1;
-      N.cp.pf_phase0_ready = 1;
+    } else if (N.cp.tt == 2 && !N.cp.merged && !disabled) {
+      // un-merged two-tap layer: round 0 is the previous-frame tap of chunk 0, which never depends on
+      // this frame -> hand over that single phase
+      L.cp.hand_next = 1;
+      L.cp.fwd_sel = 0;
+      N.cp.staged_by_prev = 1;
     }
   }
 }

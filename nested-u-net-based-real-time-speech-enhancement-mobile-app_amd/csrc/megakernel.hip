@@ -82,23 +82,23 @@ __device__ __forceinline__ bool is_fwd(const FwdWin& f, const ItemAddr& a) {
   return a.cur && a.chan4 >= f.lo4 && a.chan4 < f.hi4 && (a.row & (f.rmul - 1)) == f.radd;
 }
 
-__device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& c, int stream, int ph0, int nphases, const FwdWin& fw,
-                                           int tid, f32x4 (&pf)[MK_MAXPF]) {
+__device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& c, int stream, int ph0, int nphases, int tid,
+                                           f32x4 (&pf)[MK_MAXPF]) {
   const float* s0 = p.src0 + static_cast<size_t>(stream) * p.F_in * p.src_ld;
   const float* s1 = p.src1 ? p.src1 + static_cast<size_t>(stream) * p.F_in * p.src_ld : s0;
   const int n = nphases << c.n4p_shift;
+  const int wave_q0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #pragma unroll
   for (int i = 0; i < MK_MAXPF; ++i) {
-    const int q = tid + i * MK_THREADS;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q < n) {
+    // wave-uniform guard (scalar branch); inside, every lane loads -- lanes past the end re-load the
+    // last item, forwarded items are loaded too: nothing selects on a pending load, so no early wait
+    if (wave_q0 + i * MK_THREADS < n) {
+      int q = tid + i * MK_THREADS;
+      q = q < n ? q : n - 1;
       const ItemAddr a = item_of(c, q + (ph0 << c.n4p_shift));
-      if (!is_fwd(fw, a)) {
-        const float* src = ((a.ph >> c.nch_shift) == 1) ? s1 : s0;
-        v = *G4(src + static_cast<size_t>(a.row) * p.src_ld + 4 * a.chan4);
-      }
+      const float* src = ((a.ph >> c.nch_shift) == 1) ? s1 : s0;
+      pf[i] = *G4(src + static_cast<size_t>(a.row) * p.src_ld + 4 * a.chan4);
     }
-    pf[i] = v;
   }
 }
 
@@ -106,10 +106,11 @@ __device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& 
 __device__ __forceinline__ void image_store(const ConvPlan& c, float* lds_in, int ph0, int nphases, int ph_base, const FwdWin& fw,
                                             int tid, const f32x4 (&pf)[MK_MAXPF]) {
   const int n = nphases << c.n4p_shift;
+  const int wave_q0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #pragma unroll
   for (int i = 0; i < MK_MAXPF; ++i) {
     const int q = tid + i * MK_THREADS;
-    if (q < n) {
+    if (wave_q0 + i * MK_THREADS < n && q < n) {
       const ItemAddr a = item_of(c, q + (ph0 << c.n4p_shift));
       if (!is_fwd(fw, a)) *reinterpret_cast<f32x4*>(lds_in + (a.ph - ph_base) * c.phase_floats + img_addr(c, c.padl + a.row, a.c4)) = pf[i];
     }
@@ -152,11 +153,12 @@ __device__ __forceinline__ void mfma_round(f32x16& acc, f32x4 (&wa)[4], const We
   int phl = seg / c.kf, kf = seg - phl * c.kf;
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
-    // prefetch the next chunk: next in this slice, else the first chunk of the next round's slice,
-    // else re-read the current one (harmless, keeps the loop free of divergent control flow)
+    // prefetch the next chunk: next in this slice, else the first chunk of the next round's slice
+    // (wave-uniform condition -> scalar branch; nothing is fetched after the layer's last chunk)
+    const bool more = (ch + 1 < nchunks) || !last_round;
     f32x4 wb[4];
-    {
-      gc4_t np = (ch + 1 < nchunks) ? wp + 4 * wc.wstep : (last_round ? wp : wc.base + static_cast<size_t>(rd + 1) * wc.round_step);
+    if (more) {
+      gc4_t np = (ch + 1 < nchunks) ? wp + 4 * wc.wstep : wc.base + static_cast<size_t>(rd + 1) * wc.round_step;
       load_chunk(wb, np, wc.wstep, lane);
     }
     const int koff = (c.stride == 1) ? kf * c.pitch : ((kf >> 1) * c.pitch + (kf & 1) * c.cc);
@@ -168,8 +170,10 @@ __device__ __forceinline__ void mfma_round(f32x16& acc, f32x4 (&wa)[4], const We
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], b[u][j], acc, 0, 0, 0);
+    if (more) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) wa[u] = wb[u];
+      for (int u = 0; u < 4; ++u) wa[u] = wb[u];
+    }
     wp += 4 * wc.wstep;
     gg += 4;
     if (gg == c.gpc) { gg = 0; if (++kf == c.kf) { kf = 0; ++phl; } }
@@ -225,10 +229,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPla
 }
 
 // One conv-like layer for one stream.
-//   pf      in : this layer's phase-0 loads when cp.pf_phase0_ready;  out: the next layer's prefetch
-//   wnext   in : this task's first weight chunk when `have_w`;        out: next layer's first chunk
+//   wnext  in : this task's first weight chunk (fetched while the previous layer ran) when `have_w`
+//          out: the next layer's first chunk (single static load site -> no copies of pending loads)
 __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* N, int stream, float* lds_in, float* lds_out, int tid,
-                                           f32x4 (&pf)[MK_MAXPF], f32x4 (&wnext)[4], bool& have_w, unsigned long long* sub) {
+                                           f32x4 (&wnext)[4], bool& have_w, unsigned long long* sub) {
   const ConvParams& p = L.conv;
   const ConvPlan& c = L.cp;
   const int lane = tid & 63;
@@ -240,40 +244,32 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
   int pc = pt * 32 + pl;
   if (pc > p.F_out - 1) pc = p.F_out - 1;          // padding lanes recompute the last position
   const float* lds_lane = lds_in + pc * c.pitch + 4 * h;
+  const FwdWin nofw = {0, 0, 1, 0};
 
   WeightCursor wc;
   wc.wstep = c.nt * 64;
   wc.round_step = c.RG * wc.wstep;
-  wc.base = (gc4_t)(unsigned long long)p.wpk + (static_cast<size_t>(ks * c.gpk) * c.nt + nt) * 64;
+  wc.base = (gc4_t)(unsigned long long)p.wpk + (static_cast<size_t>(active ? ks * c.gpk : 0) * c.nt + (active ? nt : 0)) * 64;
 
-  // ---- first weight chunk (unless the previous layer already fetched it)
+  // ---- first weight chunk: fetched by the previous layer, or (first layer of a run) right now
   f32x4 wa[4];
-  if (active) {
-    if (have_w) {
+  if (have_w) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) wa[u] = wnext[u];
-    } else {
-      load_chunk(wa, wc.base, wc.wstep, lane);
-    }
+    for (int u = 0; u < 4; ++u) wa[u] = wnext[u];
+  } else {
+    load_chunk(wa, wc.base, wc.wstep, lane);
   }
   MK_STAMP(0);
 
-  const FwdWin nofw = {0, 0, 1, 0};
   // ---- LDS image of round 0 (skipped when the previous layer handed it over complete)
   const int nstage = c.merged ? c.nph : 1;
   if (!c.staged_by_prev) {
-    if (!c.pf_phase0_ready) image_load(p, c, stream, 0, nstage, nofw, tid, pf);
+    f32x4 pf[MK_MAXPF];
+    image_load(p, c, stream, 0, nstage, tid, pf);
     image_store(c, lds_in, 0, nstage, 0, nofw, tid, pf);
     __syncthreads();
   }
   MK_STAMP(1);
-
-  // what this layer owes the next one
-  const bool nconv = N && N->op == DEV_OP_CONV;
-  const bool hand = nconv && c.hand_next;
-  const bool pre0 = nconv && c.pre_next_phase0;
-  FwdWin fw = nofw;
-  if (hand && c.fwd_sel) { fw.lo4 = c.fwd_coff4; fw.hi4 = c.fwd_coff4 + c.lpg; fw.rmul = c.fwd_rmul; fw.radd = c.fwd_radd; }
 
   f32x16 acc;
 #pragma unroll
@@ -282,41 +278,47 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
 #pragma unroll 1
   for (int rd = 0; rd < c.rounds; ++rd) {
     const bool last = rd + 1 == c.rounds;
-    if (!last) {
-      image_load(p, c, stream, rd + 1, 1, nofw, tid, pf);          // next phase of THIS layer
-    } else {
-      // prefetch for the NEXT layer: everything its image needs that this layer does not produce
-      if (hand) image_load(N->conv, N->cp, stream, 0, N->cp.nph, fw, tid, pf);
-      else if (pre0) image_load(N->conv, N->cp, stream, 0, 1, nofw, tid, pf);
-    }
+    f32x4 pfr[MK_MAXPF];
+    if (!last) image_load(p, c, stream, rd + 1, 1, tid, pfr);      // next phase of THIS layer
     if (active) mfma_round(acc, wa, wc, rd, last, c, lds_lane, ks, lane);
     if (!last) {
       __syncthreads();           // every wave is done reading this phase's LDS rows
-      image_store(c, lds_in, rd + 1, 1, rd + 1, nofw, tid, pf);
+      image_store(c, lds_in, rd + 1, 1, rd + 1, nofw, tid, pfr);
       __syncthreads();
     }
   }
   MK_STAMP(2);
 
-  // ---- epilogue parameters + the next layer's first weight chunk: issued before the exchange barrier
+  // ---- what this layer owes the next one; all loads below are issued before the exchange barrier
+  const bool nconv = N && N->op == DEV_OP_CONV;
+  const bool hand = nconv && c.hand_next;
+  FwdWin fw = nofw;
+  if (hand && c.fwd_sel) { fw.lo4 = c.fwd_coff4; fw.hi4 = c.fwd_coff4 + c.lpg; fw.rmul = c.fwd_rmul; fw.radd = c.fwd_radd; }
+  const int n_hand = hand ? (N->cp.merged ? N->cp.nph : 1) : 0;
+
+  // next layer's first weight chunk (single load site; a layer with no conv successor re-reads its own)
+  {
+    const DevLaunch& W = nconv ? *N : L;
+    const ConvPlan& n = W.cp;
+    const bool nact = wave < n.tiles * n.KS;
+    const int nks = nact ? (wave >> n.tiles_shift) : 0;
+    const int nnt = nact ? (wave & (n.nt - 1)) : 0;
+    load_chunk(wnext, (gc4_t)(unsigned long long)W.conv.wpk + (static_cast<size_t>(nks * n.gpk) * n.nt + nnt) * 64, n.nt * 64, lane);
+    have_w = nconv;
+  }
+  // the part of the next layer's LDS image this layer does not produce itself (previous-frame tap,
+  // skip-connection channels): HBM/L2 -> registers now, registers -> LDS after the epilogue
+  f32x4 pfn[MK_MAXPF];
+  if (hand) image_load(N->conv, N->cp, stream, 0, n_hand, tid, pfn);
+  // epilogue parameters
   const int lpg = c.lpg;
   const int li = tid & (lpg - 1);
   const int gi_mine = (c.R == 2) ? ((tid / lpg) & 1) : 0;
   const f32x4 bias = *G4(p.bias + gi_mine * (4 * lpg) + 4 * li);
-  f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+  f32x4 gm = bias, bt = bias;
   if (c.epi_ln) {
     gm = *G4(p.gamma + 4 * li);
     bt = *G4(p.beta + 4 * li);
-  }
-  have_w = false;
-  if (nconv) {
-    const ConvPlan& n = N->cp;
-    if (wave < n.tiles * n.KS) {
-      const int nks = wave >> n.tiles_shift, ntl = wave & (n.tiles - 1);
-      const int nnt = ntl & (n.nt - 1);
-      load_chunk(wnext, (gc4_t)(unsigned long long)N->conv.wpk + (static_cast<size_t>(nks * n.gpk) * n.nt + nnt) * 64, n.nt * 64, lane);
-    }
-    have_w = true;
   }
 
   // ---- partial tiles -> LDS exchange buffer [ks][pos][32*NT (+4)]
@@ -331,10 +333,7 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
   __syncthreads();               // also: every wave has finished reading lds_in
   MK_STAMP(3);
 
-  // ---- hand-off: the prefetched part of the next layer's image (the forwarded part follows in the epilogue)
-  if (hand) image_store(N->cp, lds_in, 0, N->cp.nph, 0, fw, tid, pf);
-
-  const ConvPlan* nx = hand ? &N->cp : nullptr;
+  const ConvPlan* nx = (hand && c.fwd_sel) ? &N->cp : nullptr;
   if (c.epi_ln) {
     if (c.g == 1) conv_epilogue<8, true>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
     else conv_epilogue<16, true>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
@@ -342,6 +341,8 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
     if (c.g == 2) conv_epilogue<16, false>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
     else conv_epilogue<32, false>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
   }
+  // ---- hand-off: the prefetched part of the next layer's image (the forwarded rows were written above)
+  if (hand) image_store(N->cp, lds_in, 0, n_hand, 0, fw, tid, pfn);
   MK_STAMP(4);
   __syncthreads();               // HBM stores visible to the workgroup; next image complete; exchange buffer free
   MK_STAMP(5);
@@ -565,14 +566,13 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Dev
     while (i < n_ops) {
       if (plan[i].op == DEV_OP_CONV) {
         // a run of consecutive conv layers: prefetch registers (activations, first weight chunk) live only here
-        f32x4 pf[MK_MAXPF];
         f32x4 wnext[4];
         bool have_w = false;
 #pragma unroll 1
         while (i < n_ops && plan[i].op == DEV_OP_CONV) {
           if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
           unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
-          conv_layer(plan[i], (i + 1 < n_ops) ? &plan[i + 1] : nullptr, stream, lds_in, lds_out, tid, pf, wnext, have_w, sub);
+          conv_layer(plan[i], (i + 1 < n_ops) ? &plan[i + 1] : nullptr, stream, lds_in, lds_out, tid, wnext, have_w, sub);
           ++i;
         }
       } else {

@@ -1,0 +1,11 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import nunet_amd
+eng = nunet_amd.NutlsEngine(batch=256)
+x = (0.25*np.abs(np.random.default_rng(0).standard_normal((256,256)))).astype(np.float32)
+for _ in range(5): eng.step(x)
+for _ in range(3): eng.profile_persistent()
+os.environ["NUTLS_SUBSTAMPS"] = "gpurun_out/substamps.txt"
+us = eng.profile_persistent()
+print("step us", us.sum())
