@@ -92,7 +92,11 @@ struct Engine {
   int B = 0, device = 0;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
-  std::vector<StateTensor> states;
+  float* arena = nullptr;        // stream-major arena: stream b's tensors at arena + b*sstride + slot offset
+  size_t sstride = 0;            // floats per stream
+  size_t arena_cursor = 0;       // next free slot offset (floats) while the layout is being built
+  std::vector<float**> arena_fixups;   // pointers that hold a slot offset until the arena is allocated
+  std::vector<StateTensor> states;   // reserve()d up front: slot_reserve keeps pointers into it
   std::unordered_map<std::string, int> state_index;
   StageStates enc_st[6], dec_st[6];
   int central_h = -1, central_c = -1;
@@ -134,6 +138,43 @@ static int dev_alloc(Engine* e, size_t floats, float** out, bool zero) {
   e->allocs.push_back(p);
   if (zero) HIP_TRY(hipMemset(p, 0, floats * sizeof(float)));
   *out = static_cast<float*>(p);
+  return NUTLS_OK;
+}
+
+// Reserves `floats` per stream inside the stream-major arena; *out temporarily holds the slot offset
+// (as a fake pointer) and is patched to the stream-0 address by arena_commit().
+static void slot_reserve(Engine* e, size_t floats, float** out) {
+  const size_t off = e->arena_cursor;
+  e->arena_cursor += (floats + 63) & ~static_cast<size_t>(63);     // 256-byte aligned slots
+  *out = reinterpret_cast<float*>(off * sizeof(float));
+  e->arena_fixups.push_back(out);
+}
+
+static int arena_commit(Engine* e) {
+  // Stream stride = an ODD number of 256-byte lines: at any moment all workgroups touch the same
+  // slot offset of their own stream, so a power-of-two-ish stride would line every CU up on the
+  // same HBM channel / L2 slice.
+  e->sstride = (e->arena_cursor + 63) & ~static_cast<size_t>(63);
+  if (const char* sk = getenv("NUTLS_STRIDE_ALIGN")) { const size_t a = static_cast<size_t>(atol(sk)); e->sstride = (e->arena_cursor + a - 1) / a * a; }
+  else if (((e->sstride / 64) & 1) == 0) e->sstride += 64;
+  void* p = nullptr;
+  const size_t bytes = e->sstride * sizeof(float) * e->B;
+  HIP_TRY(hipMalloc(&p, bytes));
+  e->allocs.push_back(p);
+  HIP_TRY(hipMemset(p, 0, bytes));
+  e->arena = static_cast<float*>(p);
+  for (float** f : e->arena_fixups) *f = e->arena + reinterpret_cast<size_t>(*f) / sizeof(float);
+  e->arena_fixups.clear();
+  return NUTLS_OK;
+}
+
+// per-stream tensor (stream-0 pointer `dev`, `per_stream` floats) <-> dense host array [B][per_stream]
+static int copy_stream_tensor(Engine* e, float* dev, size_t per_stream, float* host, bool to_host, int stream_idx = -1) {
+  const size_t dpitch = e->sstride * sizeof(float), hpitch = per_stream * sizeof(float);
+  const int b0 = stream_idx < 0 ? 0 : stream_idx, nb = stream_idx < 0 ? e->B : 1;
+  float* d = dev + static_cast<size_t>(b0) * e->sstride;
+  if (to_host) HIP_TRY(hipMemcpy2D(host, hpitch, d, dpitch, hpitch, nb, hipMemcpyDeviceToHost));
+  else HIP_TRY(hipMemcpy2D(d, dpitch, host, hpitch, hpitch, nb, hipMemcpyHostToDevice));
   return NUTLS_OK;
 }
 
@@ -308,12 +349,9 @@ static int add_state(Engine* e, const std::string& prev, const std::string& cur,
   st.name_cur = cur;
   st.d0 = d0;
   st.d1 = d1;
-  for (int i = 0; i < 2; ++i) {
-    int rc = dev_alloc(e, static_cast<size_t>(e->B) * d0 * d1, &st.buf[i], true);
-    if (rc) return rc;
-  }
   const int idx = static_cast<int>(e->states.size());
   e->states.push_back(st);
+  for (int i = 0; i < 2; ++i) slot_reserve(e, static_cast<size_t>(d0) * d1, &e->states[idx].buf[i]);
   e->state_index[prev] = idx;
   e->state_index[cur] = idx;
   return idx;
@@ -370,7 +408,7 @@ static void push_conv(Engine* e, std::vector<Launch>* plan, const std::string& w
   p.src0 = src0; p.src1 = src1; p.wpk = w.wpk; p.bias = w.bias; p.gamma = w.gamma; p.beta = w.beta;
   p.dst0 = dst0; p.dst1 = dst1; p.src_ld = src_ld; p.ld0 = ld0; p.ld1 = ld1;
   p.B = e->B; p.F_in = f_in; p.F_out = f_out; p.log2_fout = ilog2(f_out);
-  p.row_mul = row_mul; p.row_add = row_add; p.alpha = w.alpha;
+  p.row_mul = row_mul; p.row_add = row_add; p.alpha = w.alpha; p.sstride = static_cast<long long>(e->sstride);
   plan->push_back(L);
 }
 
@@ -386,7 +424,7 @@ static void push_lstm(Engine* e, std::vector<Launch>* plan, const std::string& l
   p.h_in = e->states[h_idx].buf[1 - par]; p.c_in = e->states[c_idx].buf[1 - par];
   p.h_out = e->states[h_idx].buf[par]; p.c_out = e->states[c_idx].buf[par];
   p.dst = dst; p.dst_ld = dst_ld; p.dst_rows = dst_rows; p.dst_cols = dst_cols;
-  p.Din = w.din; p.Dout = w.dout; p.B = e->B;
+  p.Din = w.din; p.Dout = w.dout; p.B = e->B; p.sstride = static_cast<long long>(e->sstride);
   plan->push_back(L);
 }
 
@@ -451,7 +489,7 @@ static void build_stage(Engine* e, std::vector<Launch>* plan, int side, int s, i
   c.x = dD; c.x_ld = dD_ld; c.e0 = cur(ss.conv[0]); c.e0_ld = c1; c.y = y_dst; c.y_ld = y_ld;
   c.ta_w1T = ta.w1T; c.ta_b1 = ta.b1; c.ta_w2T = ta.w2T; c.ta_b2 = ta.b2;
   c.fa_w1T = fa.w1T; c.fa_b1 = fa.b1; c.fa_w2T = fa.w2T; c.fa_b2 = fa.b2;
-  c.B = e->B; c.F = st.f0;
+  c.B = e->B; c.F = st.f0; c.sstride = static_cast<long long>(e->sstride);
   plan->push_back(L);
 }
 
@@ -462,7 +500,8 @@ static void build_plan(Engine* e, int par) {
     Launch L{};
     L.kind = Launch::INLAYER;
     L.name = "input_layer";
-    L.inl = InLayerParams{e->io_in, e->t_inlayer, e->in_w, e->in_b, e->in_g, e->in_bt, e->in_alpha, e->B * NUTLS_BINS};
+    L.inl = InLayerParams{e->io_in, e->t_inlayer, e->in_w, e->in_b, e->in_g, e->in_bt, e->in_alpha, e->B * NUTLS_BINS,
+                          static_cast<long long>(e->sstride)};
     plan->push_back(L);
   }
   const float* x = e->t_inlayer;
@@ -491,7 +530,7 @@ static void build_plan(Engine* e, int par) {
   Launch L{};
   L.kind = Launch::OUTCONV;
   L.name = "out_conv";
-  L.outc = OutConvParams{e->t_y, 64, e->io_out, e->out_w, e->out_bias, e->B * NUTLS_BINS};
+  L.outc = OutConvParams{e->t_y, 64, e->io_out, e->out_w, e->out_bias, e->B * NUTLS_BINS, static_cast<long long>(e->sstride)};
   plan->push_back(L);
 }
 
@@ -621,8 +660,8 @@ static int upload_device_plans(Engine* e) {
     e->dplan[par] = static_cast<DevLaunch*>(p);
   }
   void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, (e->plan[0].size() * 9 + 1) * sizeof(unsigned long long)));   // layer stamps + 8 sub-stamps per layer
-  HIP_TRY(hipMemset(q, 0, (e->plan[0].size() * 9 + 1) * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&q, (e->plan[0].size() * 9 + 3) * sizeof(unsigned long long)));   // layer stamps + 8 sub-stamps per layer + 2 clock64
+  HIP_TRY(hipMemset(q, 0, (e->plan[0].size() * 9 + 3) * sizeof(unsigned long long)));
   e->allocs.push_back(q);
   e->dprof = static_cast<unsigned long long*>(q);
   return NUTLS_OK;
@@ -689,16 +728,17 @@ int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, in
   HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   int rc;
   if ((rc = prep_weights(e, wm))) return rc;
+  e->states.reserve(160);
   if ((rc = build_states(e))) return rc;
   const size_t B = static_cast<size_t>(batch);
   if ((rc = dev_alloc(e, B * NUTLS_BINS, &e->io_in, true))) return rc;
   if ((rc = dev_alloc(e, B * NUTLS_BINS, &e->io_out, true))) return rc;
-  if ((rc = dev_alloc(e, B * 256 * 64, &e->t_inlayer, true))) return rc;
-  if ((rc = dev_alloc(e, B * 256 * 64, &e->t_y, true))) return rc;
-  if ((rc = dev_alloc(e, B * 256 * 64, &e->t_d, true))) return rc;
-  if ((rc = dev_alloc(e, B * 256 * 128, &e->t_up, true))) return rc;
-  for (int s = 0; s < 6; ++s)
-    if ((rc = dev_alloc(e, B * (kDecoder[s].f0 / 2) * 128, &e->upcat[s], true))) return rc;
+  slot_reserve(e, 256 * 64, &e->t_inlayer);
+  slot_reserve(e, 256 * 64, &e->t_y);
+  slot_reserve(e, 256 * 64, &e->t_d);
+  slot_reserve(e, 256 * 128, &e->t_up);
+  for (int s = 0; s < 6; ++s) slot_reserve(e, static_cast<size_t>(kDecoder[s].f0 / 2) * 128, &e->upcat[s]);
+  if ((rc = arena_commit(e))) return rc;
   build_plan(e, 0);
   build_plan(e, 1);
   if ((rc = upload_device_plans(e))) return rc;
@@ -815,8 +855,7 @@ int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(host_buf, st->buf[1 - e->next_parity], n_floats * sizeof(float), hipMemcpyDeviceToHost));
-  return NUTLS_OK;
+  return copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), host_buf, true);
 }
 
 int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, size_t n_floats) {
@@ -827,8 +866,7 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(st->buf[1 - e->next_parity], host_buf, n_floats * sizeof(float), hipMemcpyHostToDevice));
-  return NUTLS_OK;
+  return copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), const_cast<float*>(host_buf), false);
 }
 
 int nutls_reset(nutls_handle* h, int stream_idx) {
@@ -837,11 +875,9 @@ int nutls_reset(nutls_handle* h, int stream_idx) {
   if (stream_idx >= e->B) return fail(NUTLS_ERR_ARG, "nutls_reset: stream index out of range");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  for (StateTensor& st : e->states)
-    for (int i = 0; i < 2; ++i) {
-      if (stream_idx < 0) HIP_TRY(hipMemset(st.buf[i], 0, st.per_stream() * e->B * sizeof(float)));
-      else HIP_TRY(hipMemset(st.buf[i] + st.per_stream() * stream_idx, 0, st.per_stream() * sizeof(float)));
-    }
+  // a stream's whole slice of the arena (state of both parities + scratch) is contiguous
+  if (stream_idx < 0) HIP_TRY(hipMemset(e->arena, 0, e->sstride * sizeof(float) * e->B));
+  else HIP_TRY(hipMemset(e->arena + e->sstride * stream_idx, 0, e->sstride * sizeof(float)));
   HIP_TRY(hipDeviceSynchronize());
   return NUTLS_OK;
 }
@@ -854,8 +890,7 @@ int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n
   if (n_floats != it->second.second * e->B) return fail(NUTLS_ERR_ARG, std::string("size mismatch for debug tensor ") + name);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(host_buf, it->second.first, n_floats * sizeof(float), hipMemcpyDeviceToHost));
-  return NUTLS_OK;
+  return copy_stream_tensor(e, it->second.first, it->second.second, host_buf, true);
 }
 
 static const char* family_name(const Launch& L, int B) {
@@ -957,12 +992,19 @@ int nutls_profile_persistent(nutls_handle* h, double* us, int n) {
     std::vector<unsigned long long> sub(static_cast<size_t>(n_ops) * 8);
     HIP_TRY(hipMemcpy(sub.data(), e->dprof + n_ops + 1, sub.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (FILE* f = fopen(dump, "w")) {
+      unsigned long long ck[2];
+      (void)hipMemcpy(ck, e->dprof + static_cast<size_t>(n_ops) * 9 + 1, sizeof(ck), hipMemcpyDeviceToHost);
+      fprintf(f, "# shader clock: %.0f MHz over the step (%llu cycles in %.1f us)\n",
+              static_cast<double>(ck[1] - ck[0]) / (static_cast<double>(t[n_ops] - t[0]) * 1000.0 / khz), ck[1] - ck[0],
+              static_cast<double>(t[n_ops] - t[0]) * 1000.0 / khz);
       for (int i = 0; i < n_ops; ++i) {
         if (e->plan[par][i].kind != Launch::CONV) continue;
         fprintf(f, "%-24s", e->plan[par][i].name.c_str());
         fprintf(f, " init %6.2f", static_cast<double>(sub[8 * i] - t[i]) * 1000.0 / khz);
         const char* nm[5] = {"stage", "mfma", "pwrite", "epi", "bar"};
         for (int k = 0; k < 5; ++k) fprintf(f, " %s %6.2f", nm[k], static_cast<double>(sub[8 * i + k + 1] - sub[8 * i + k]) * 1000.0 / khz);
+        fprintf(f, " | params %5.2f tohook %5.2f afterhook %5.2f", static_cast<double>(sub[8 * i + 6] - sub[8 * i + 1]) * 1000.0 / khz,
+                static_cast<double>(sub[8 * i + 7] - sub[8 * i + 6]) * 1000.0 / khz, static_cast<double>(sub[8 * i + 2] - sub[8 * i + 7]) * 1000.0 / khz);
         fprintf(f, "\n");
       }
       fclose(f);

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(const ConvParams p) 
         const int gr = STRIDE * f0 - PADL + lr;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (b < p.B && gr >= 0 && gr < p.F_in)
-          v = *reinterpret_cast<const f32x4*>(src + (static_cast<size_t>(b) * p.F_in + gr) * p.src_ld + ch * CC + 4 * c4);
+          v = *reinterpret_cast<const f32x4*>(src + static_cast<size_t>(b) * p.sstride + static_cast<size_t>(gr) * p.src_ld + ch * CC + 4 * c4);
         const int la = (STRIDE == 1) ? ((sg * RS + lr) * PITCH + 4 * c4)
                                      : ((sg * RS + (lr >> 1)) * PITCH + (lr & 1) * CC + 4 * c4);
         *reinterpret_cast<f32x4*>(lds + la) = v;
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(const ConvParams p) 
   const int P = P0 + ploc;
   const bool valid = P < total_pos;
   const int b = P >> log2f, f = P & (F_out - 1);
-  const size_t row0 = static_cast<size_t>(b) * (F_out * p.row_mul) + f * p.row_mul + p.row_add;
+  const size_t soff = static_cast<size_t>(b) * p.sstride;
+  const size_t row0 = static_cast<size_t>(f) * p.row_mul + p.row_add;
 #pragma unroll
   for (int gi = 0; gi < R; ++gi) {
     float v[G][16];
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(const ConvParams p) 
         for (int q = 0; q < 4; ++q) {
           const f32x4 o = {v[tg][4 * q], v[tg][4 * q + 1], v[tg][4 * q + 2], v[tg][4 * q + 3]};
           const int c = tg * 32 + 8 * q + 4 * h;
-          *reinterpret_cast<f32x4*>(p.dst0 + row * p.ld0 + c) = o;
-          if (p.dst1) *reinterpret_cast<f32x4*>(p.dst1 + row * p.ld1 + c) = o;
+          *reinterpret_cast<f32x4*>(p.dst0 + soff + row * p.ld0 + c) = o;
+          if (p.dst1) *reinterpret_cast<f32x4*>(p.dst1 + soff + row * p.ld1 + c) = o;
         }
     }
   }
@@ -277,9 +278,9 @@ __global__ __launch_bounds__(128) void lstm_dense_kernel(const LstmParams p) {
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int k = tid; k < p.Din; k += 128) {
     const int f = k / p.x_cols, c = k - f * p.x_cols;
-    v[k] = p.x[(static_cast<size_t>(b) * p.x_rows + f) * p.x_ld + c];
+    v[k] = p.x[static_cast<size_t>(b) * p.sstride + static_cast<size_t>(f) * p.x_ld + c];
   }
-  if (tid < LSTM_UNITS) hs[tid] = p.h_in[static_cast<size_t>(b) * LSTM_UNITS + tid];
+  if (tid < LSTM_UNITS) hs[tid] = p.h_in[static_cast<size_t>(b) * p.sstride + tid];
   __syncthreads();
   if (tid < LSTM_GATES) {
     float a = p.bias[tid];
@@ -294,11 +295,11 @@ __global__ __launch_bounds__(128) void lstm_dense_kernel(const LstmParams p) {
     const float gf = sigmoid_f(z[LSTM_UNITS + tid]);
     const float gg = tanhf(z[2 * LSTM_UNITS + tid]);
     const float go = sigmoid_f(z[3 * LSTM_UNITS + tid]);
-    const float c_old = p.c_in[static_cast<size_t>(b) * LSTM_UNITS + tid];
+    const float c_old = p.c_in[static_cast<size_t>(b) * p.sstride + tid];
     const float c_new = gf * c_old + gi * gg;
     const float h_new = go * tanhf(c_new);
-    p.c_out[static_cast<size_t>(b) * LSTM_UNITS + tid] = c_new;
-    p.h_out[static_cast<size_t>(b) * LSTM_UNITS + tid] = h_new;
+    p.c_out[static_cast<size_t>(b) * p.sstride + tid] = c_new;
+    p.h_out[static_cast<size_t>(b) * p.sstride + tid] = h_new;
     hn[tid] = h_new;
   }
   __syncthreads();
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(128) void lstm_dense_kernel(const LstmParams p) {
 #pragma unroll
     for (int u = 0; u < LSTM_UNITS; ++u) a = fmaf(p.wdT[u * p.Dout + m], hn[u], a);
     const int f = m / p.dst_cols, c = m - f * p.dst_cols;
-    p.dst[(static_cast<size_t>(b) * p.dst_rows + f) * p.dst_ld + c] = a;
+    p.dst[static_cast<size_t>(b) * p.sstride + static_cast<size_t>(f) * p.dst_ld + c] = a;
   }
 }
 
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void ctfa_kernel(const CtfaParams p) {
   __shared__ __attribute__((aligned(16))) float gate[64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int c4 = tid & 15, rg = tid >> 4;
-  const float* xb = p.x + static_cast<size_t>(b) * p.F * p.x_ld;
+  const float* xb = p.x + static_cast<size_t>(b) * p.sstride;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int f = rg; f < p.F; f += 16) s += *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
   *reinterpret_cast<f32x4*>(&part[rg][4 * c4]) = s;
@@ -373,8 +374,8 @@ __global__ __launch_bounds__(256) void ctfa_kernel(const CtfaParams p) {
   }
   __syncthreads();
   const f32x4 g4 = *reinterpret_cast<const f32x4*>(&gate[4 * c4]);
-  const float* eb = p.e0 + static_cast<size_t>(b) * p.F * p.e0_ld;
-  float* yb = p.y + static_cast<size_t>(b) * p.F * p.y_ld;
+  const float* eb = p.e0 + static_cast<size_t>(b) * p.sstride;
+  float* yb = p.y + static_cast<size_t>(b) * p.sstride;
   for (int f = rg; f < p.F; f += 16) {
     const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
     const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void input_layer_kernel(const InLayerParams p)
     const float t = y[i] * rstd * gm[i] + bt[i];
     o[i] = t >= 0.f ? t : p.alpha * t;
   }
-  if (valid) *reinterpret_cast<f32x4*>(p.y + static_cast<size_t>(pos) * 64 + 4 * c4) = o;
+  if (valid) *reinterpret_cast<f32x4*>(p.y + static_cast<size_t>(pos >> 8) * p.sstride + static_cast<size_t>(pos & 255) * 64 + 4 * c4) = o;
 }
 
 hipError_t launch_input_layer(const InLayerParams& p, hipStream_t s) {
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvParams p) {
   const bool valid = pos < p.n_pos;
   float s = 0.f;
   if (valid) {
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + static_cast<size_t>(pos) * p.x_ld + 4 * c4);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + static_cast<size_t>(pos >> 8) * p.sstride + static_cast<size_t>(pos & 255) * p.x_ld + 4 * c4);
     const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + 4 * c4);
     s = xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
   }

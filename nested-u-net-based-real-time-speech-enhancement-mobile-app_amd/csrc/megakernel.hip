@@ -1,5 +1,5 @@
 // Persistent "one workgroup per stream" kernel: the whole NUNet-TLS-LSTM frame step of one stream
-// runs inside ONE 1024-thread workgroup (16 waves = 4 per SIMD, one workgroup per CU), layer after
+// runs inside ONE 512-thread workgroup (8 waves = 2 per SIMD, one workgroup per CU), layer after
 // layer, driven by the device-resident plan (DevLaunch[]).  Streams are independent (SURVEY.md
 // section 8e), so no inter-workgroup synchronisation exists: a layer boundary is a
 // __syncthreads(), not a kernel boundary.  At B = 256 this is exactly one stream per CU.
@@ -12,7 +12,8 @@
 //     global loads were issued before that layer's MFMA work ("hand-off": no global round trip and
 //     no staging step on the critical path);
 //   * the GEMM  D[ch,pos] = W[ch,k] X[k,pos]  is cut into (position tile, channel tile, K slice)
-//     tasks of 32x32 outputs, one per wave, so even a 4-position layer keeps 12..16 waves busy
+//     tasks of 32x32 outputs (two position tiles per wave, sharing the weight fragments, when a layer
+//     has 16 tiles), so even a 4-position layer keeps 6..8 waves busy
 //     (split-K); v_mfma_f32_32x32x2_f32 (exact fp32); weight fragments stream from L2 through a
 //     double-buffered 4-fragment register ring, the first chunk already fetched by the previous layer;
 //   * partial tiles meet in an LDS exchange buffer [k-slice][position][channel];
@@ -42,12 +43,16 @@ __device__ __forceinline__ gcf_t GF(const float* p) { return (gcf_t)(unsigned lo
 __device__ __forceinline__ gf_t GFW(float* p) { return (gf_t)(unsigned long long)p; }
 
 #define MK_LN_EPS 1e-8f
-constexpr int MK_THREADS = 1024;
-constexpr int MK_WAVES = 16;
-constexpr int MK_MAXPF = 4;                   // float4 prefetch registers per thread
+constexpr int MK_WAVES = MK_NWAVES;           // 8 waves = 2 per SIMD: 256 VGPRs per lane, half the per-layer bookkeeping of 16
+constexpr int MK_THREADS = 64 * MK_WAVES;
+constexpr int MK_MAXPF = MK_STAGE_ITEMS / MK_THREADS;   // float4 prefetch registers per thread (8)
 constexpr int MK_LDS_IN = MK_LDS_IN_FLOATS;
 constexpr int MK_LDS_OUT = 16 * 32 * 36;      // floats: 16 tasks x 32 positions x (32+4)
 constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT) * sizeof(float);
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does NOT drain vmcnt,
+// so global loads issued earlier (next layer's image rows, weight fragments) stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define MK_STAMP(k) do { if (sub && tid == 0) sub[k] = wall_clock64(); } while (0)
 
@@ -84,8 +89,8 @@ __device__ __forceinline__ bool is_fwd(const FwdWin& f, const ItemAddr& a) {
 
 __device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& c, int stream, int ph0, int nphases, int tid,
                                            f32x4 (&pf)[MK_MAXPF]) {
-  const float* s0 = p.src0 + static_cast<size_t>(stream) * p.F_in * p.src_ld;
-  const float* s1 = p.src1 ? p.src1 + static_cast<size_t>(stream) * p.F_in * p.src_ld : s0;
+  const float* s0 = p.src0 + static_cast<size_t>(stream) * p.sstride;
+  const float* s1 = p.src1 ? p.src1 + static_cast<size_t>(stream) * p.sstride : s0;
   const int n = nphases << c.n4p_shift;
   const int wave_q0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #pragma unroll
@@ -142,15 +147,29 @@ __device__ __forceinline__ void load_chunk(f32x4 (&w)[4], gc4_t ptr, int wstep, 
   for (int u = 0; u < 4; ++u) w[u] = ptr[u * wstep + lane];
 }
 
-__device__ __forceinline__ void mfma_round(f32x16& acc, f32x4 (&wa)[4], const WeightCursor& wc, int rd, bool last_round,
-                                           const ConvPlan& c, const float* lds_lane, int ks, int lane) {
-  const int nchunks = c.gpk >> 2;
-  gc4_t wp = wc.base + static_cast<size_t>(rd) * wc.round_step;
-  // wave-uniform cursor over the resident image: (local phase, frequency tap, first group of the chunk)
+// cursor over the resident image for one task: (local phase, frequency tap, channel group), wave-uniform
+struct KCursor { int phl, kf, gg; };
+
+__device__ __forceinline__ KCursor kcursor_init(const ConvPlan& c, int ks) {
   const int g_first = ks * c.gpk;
   const int seg = g_first / c.gpc;
-  int gg = g_first - seg * c.gpc;
-  int phl = seg / c.kf, kf = seg - phl * c.kf;
+  KCursor k;
+  k.gg = g_first - seg * c.gpc;
+  k.phl = seg / c.kf;
+  k.kf = seg - k.phl * c.kf;
+  return k;
+}
+
+// All chunks of round rd for one task (TW = 1 or 2 position tiles, sharing the weight fragments).
+// `hook()` runs once, right after the layer's LAST weight prefetch has been issued: the place for
+// loads that must be younger than every load this loop still waits for (vmcnt retires in order).
+template <int TW, class Hook>
+__device__ __forceinline__ void mfma_round(f32x16 (&acc)[2], f32x4 (&wa)[4], const WeightCursor& wc, int rd, bool last_round,
+                                           const ConvPlan& c, const float* lds_lane0, const float* lds_lane1, int ks, int lane,
+                                           Hook&& hook) {
+  const int nchunks = c.gpk >> 2;
+  KCursor k = kcursor_init(c, ks);
+  gc4_t wp = wc.base + static_cast<size_t>(rd) * wc.round_step;
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
     // prefetch the next chunk: next in this slice, else the first chunk of the next round's slice
@@ -161,22 +180,32 @@ __device__ __forceinline__ void mfma_round(f32x16& acc, f32x4 (&wa)[4], const We
       gc4_t np = (ch + 1 < nchunks) ? wp + 4 * wc.wstep : wc.base + static_cast<size_t>(rd + 1) * wc.round_step;
       load_chunk(wb, np, wc.wstep, lane);
     }
-    const int koff = (c.stride == 1) ? kf * c.pitch : ((kf >> 1) * c.pitch + (kf & 1) * c.cc);
-    const float* bp = lds_lane + phl * c.phase_floats + koff + 8 * gg;
-    f32x4 b[4];
+    if (last_round && ch + 1 == nchunks) hook();
+    const int koff = (c.stride == 1) ? k.kf * c.pitch : ((k.kf >> 1) * c.pitch + (k.kf & 1) * c.cc);
+    const int boff = k.phl * c.phase_floats + koff + 8 * k.gg;
+    // B fragments: one ds_read_b128 per tile per group, fetched one group ahead of its MFMAs
+    f32x4 b0 = *reinterpret_cast<const f32x4*>(lds_lane0 + boff), b1 = b0;
+    if (TW == 2) b1 = *reinterpret_cast<const f32x4*>(lds_lane1 + boff);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const f32x4*>(bp + 8 * u);
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 c0 = b0, c1 = b1;
+      if (u < 3) {
+        b0 = *reinterpret_cast<const f32x4*>(lds_lane0 + boff + 8 * (u + 1));
+        if (TW == 2) b1 = *reinterpret_cast<const f32x4*>(lds_lane1 + boff + 8 * (u + 1));
+      }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], b[u][j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], c0[j], acc[0], 0, 0, 0);
+        if (TW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], c1[j], acc[1], 0, 0, 0);
+      }
+    }
     if (more) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) wa[u] = wb[u];
     }
     wp += 4 * wc.wstep;
-    gg += 4;
-    if (gg == c.gpc) { gg = 0; if (++kf == c.kf) { kf = 0; ++phl; } }
+    k.gg += 4;
+    if (k.gg == c.gpc) { k.gg = 0; if (++k.kf == c.kf) { k.kf = 0; ++k.phl; } }
   }
 }
 
@@ -191,8 +220,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPla
   constexpr int GC = LPG * 4;
   const int li = tid & (LPG - 1);
   const int units = p.F_out * c.R;
-  float* d0 = p.dst0 + static_cast<size_t>(stream) * (p.F_out * p.row_mul) * p.ld0;
-  float* d1 = p.dst1 ? p.dst1 + static_cast<size_t>(stream) * (p.F_out * p.row_mul) * p.ld1 : nullptr;
+  float* d0 = p.dst0 + static_cast<size_t>(stream) * p.sstride;
+  float* d1 = p.dst1 ? p.dst1 + static_cast<size_t>(stream) * p.sstride : nullptr;
   // forwarded block inside the next image: float4 column (coff4 + li) of the current-frame phase
   int f_ph = 0, f_c4 = 0;
   if (nx && fwd_sel) {
@@ -238,12 +267,14 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SGPR
   const int pl = lane & 31, h = lane >> 5;
-  const bool active = wave < c.tiles * c.KS;
-  const int ks = wave >> c.tiles_shift, tl = wave & (c.tiles - 1);
-  const int pt = tl >> c.nt_shift, nt = tl & (c.nt - 1);
-  int pc = pt * 32 + pl;
-  if (pc > p.F_out - 1) pc = p.F_out - 1;          // padding lanes recompute the last position
-  const float* lds_lane = lds_in + pc * c.pitch + 4 * h;
+  const bool active = wave < c.tasks * c.KS;
+  const int ks = wave >> c.tasks_shift, tl = wave & (c.tasks - 1);
+  const int pt = (tl >> c.nt_shift) * c.tw, nt = tl & (c.nt - 1);     // first position tile, channel tile
+  int pc0 = pt * 32 + pl, pc1 = pc0 + 32;
+  if (pc0 > p.F_out - 1) pc0 = p.F_out - 1;        // padding lanes recompute the last position
+  if (pc1 > p.F_out - 1) pc1 = p.F_out - 1;
+  const float* lds_lane0 = lds_in + pc0 * c.pitch + 4 * h;
+  const float* lds_lane1 = lds_in + pc1 * c.pitch + 4 * h;
   const FwdWin nofw = {0, 0, 1, 0};
 
   WeightCursor wc;
@@ -267,50 +298,21 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
     f32x4 pf[MK_MAXPF];
     image_load(p, c, stream, 0, nstage, tid, pf);
     image_store(c, lds_in, 0, nstage, 0, nofw, tid, pf);
-    __syncthreads();
+    lds_barrier();
   }
   MK_STAMP(1);
 
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-#pragma unroll 1
-  for (int rd = 0; rd < c.rounds; ++rd) {
-    const bool last = rd + 1 == c.rounds;
-    f32x4 pfr[MK_MAXPF];
-    if (!last) image_load(p, c, stream, rd + 1, 1, tid, pfr);      // next phase of THIS layer
-    if (active) mfma_round(acc, wa, wc, rd, last, c, lds_lane, ks, lane);
-    if (!last) {
-      __syncthreads();           // every wave is done reading this phase's LDS rows
-      image_store(c, lds_in, rd + 1, 1, rd + 1, nofw, tid, pfr);
-      __syncthreads();
-    }
-  }
-  MK_STAMP(2);
-
-  // ---- what this layer owes the next one; all loads below are issued before the exchange barrier
+  // ---- what this layer owes the next one
   const bool nconv = N && N->op == DEV_OP_CONV;
   const bool hand = nconv && c.hand_next;
   FwdWin fw = nofw;
   if (hand && c.fwd_sel) { fw.lo4 = c.fwd_coff4; fw.hi4 = c.fwd_coff4 + c.lpg; fw.rmul = c.fwd_rmul; fw.radd = c.fwd_radd; }
   const int n_hand = hand ? (N->cp.merged ? N->cp.nph : 1) : 0;
 
-  // next layer's first weight chunk (single load site; a layer with no conv successor re-reads its own)
-  {
-    const DevLaunch& W = nconv ? *N : L;
-    const ConvPlan& n = W.cp;
-    const bool nact = wave < n.tiles * n.KS;
-    const int nks = nact ? (wave >> n.tiles_shift) : 0;
-    const int nnt = nact ? (wave & (n.nt - 1)) : 0;
-    load_chunk(wnext, (gc4_t)(unsigned long long)W.conv.wpk + (static_cast<size_t>(nks * n.gpk) * n.nt + nnt) * 64, n.nt * 64, lane);
-    have_w = nconv;
-  }
-  // the part of the next layer's LDS image this layer does not produce itself (previous-frame tap,
-  // skip-connection channels): HBM/L2 -> registers now, registers -> LDS after the epilogue
-  f32x4 pfn[MK_MAXPF];
-  if (hand) image_load(N->conv, N->cp, stream, 0, n_hand, tid, pfn);
-  // epilogue parameters
+  // Global loads are issued oldest-needed-first (vmcnt retires in order): epilogue parameters, then
+  // the next layer's first weight chunk, then -- after this layer's own last weight prefetch -- the
+  // rows of the next layer's LDS image that this layer does not produce (previous-frame tap,
+  // skip-connection channels; HBM, long latency).  None of the barriers in between drains vmcnt.
   const int lpg = c.lpg;
   const int li = tid & (lpg - 1);
   const int gi_mine = (c.R == 2) ? ((tid / lpg) & 1) : 0;
@@ -320,17 +322,60 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
     gm = *G4(p.gamma + 4 * li);
     bt = *G4(p.beta + 4 * li);
   }
+  MK_STAMP(6);
+  f32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  // one register set serves both prefetches: the next phase of THIS layer (rounds before the last)
+  // and, in the last round, the next layer's image rows
+  f32x4 pfx[MK_MAXPF];
+  auto next_image_hook = [&]() {
+    if (hand) image_load(N->conv, N->cp, stream, 0, n_hand, tid, pfx);   // youngest loads of the layer
+    MK_STAMP(7);
+  };
+
+#pragma unroll 1
+  for (int rd = 0; rd < c.rounds; ++rd) {
+    const bool last = rd + 1 == c.rounds;
+    if (!last) image_load(p, c, stream, rd + 1, 1, tid, pfx);       // next phase of THIS layer
+    if (active) {
+      if (c.tw == 2) mfma_round<2>(acc, wa, wc, rd, last, c, lds_lane0, lds_lane1, ks, lane, next_image_hook);
+      else mfma_round<1>(acc, wa, wc, rd, last, c, lds_lane0, lds_lane1, ks, lane, next_image_hook);
+    } else if (last) {
+      next_image_hook();
+    }
+    if (!last) {
+      lds_barrier();             // every wave is done reading this phase's LDS rows
+      image_store(c, lds_in, rd + 1, 1, rd + 1, nofw, tid, pfx);
+      lds_barrier();
+    }
+  }
+  {   // next layer's first weight chunk (single load site; a layer with no conv successor re-reads its own)
+    const DevLaunch& W = nconv ? *N : L;
+    const ConvPlan& n = W.cp;
+    const bool nact = wave < n.tasks * n.KS;
+    const int nks = nact ? (wave >> n.tasks_shift) : 0;
+    const int nnt = nact ? (wave & (n.nt - 1)) : 0;
+    load_chunk(wnext, (gc4_t)(unsigned long long)W.conv.wpk + (static_cast<size_t>(nks * n.gpk) * n.nt + nnt) * 64, n.nt * 64, lane);
+    have_w = nconv;
+  }
+  MK_STAMP(2);
 
   // ---- partial tiles -> LDS exchange buffer [ks][pos][32*NT (+4)]
   if (active) {
-    float* o = lds_out + ks * c.slot_floats + (pt * 32 + pl) * c.opitch + nt * 32 + 4 * h;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-      *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+    for (int t = 0; t < 2; ++t) {
+      if (t < c.tw) {
+        float* o = lds_out + ks * c.slot_floats + ((pt + t) * 32 + pl) * c.opitch + nt * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+          *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+        }
+      }
     }
   }
-  __syncthreads();               // also: every wave has finished reading lds_in
+  lds_barrier();                 // also: every wave has finished reading lds_in
   MK_STAMP(3);
 
   const ConvPlan* nx = (hand && c.fwd_sel) ? &N->cp : nullptr;
@@ -342,7 +387,7 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
     else conv_epilogue<32, false>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
   }
   // ---- hand-off: the prefetched part of the next layer's image (the forwarded rows were written above)
-  if (hand) image_store(N->cp, lds_in, 0, n_hand, 0, fw, tid, pfn);
+  if (hand) image_store(N->cp, lds_in, 0, n_hand, 0, fw, tid, pfx);
   MK_STAMP(4);
   __syncthreads();               // HBM stores visible to the workgroup; next image complete; exchange buffer free
   MK_STAMP(5);
@@ -357,16 +402,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // LSTM cell + Dense for one stream (models/proposed.py:70-119; converter_proposed.py:234-237):
-// 8 K-slices x 128 gate slots, reduced through LDS.  Weight loads are issued ahead of the barriers
+// 4 K-slices x 128 gate slots, reduced through LDS.  Weight loads are issued ahead of the barriers
 // that separate the stages so only one memory latency is exposed per stage.
 __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, float* lds, int tid) {
   float* v = lds;              // [256]
   float* hs = lds + 256;       // [32]
-  float* part = lds + 288;     // [8][84]
+  float* part = lds + 288;     // [4][84]
   float* z = lds + 288 + 8 * 84;   // [96]
   float* hn = z + 96;          // [32]
   const int n = tid & 127, sl = tid >> 7;
-  const int kn = p.Din >> 3, k0 = sl * kn;       // kn in {4, 8, 16, 32}
+  const int kn = p.Din >> 2, k0 = sl * kn;       // kn in {8, 16, 32, 64}
   float w[8];
   if (n < 84) {
 #pragma unroll
@@ -374,12 +419,12 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
   }
   for (int k = tid; k < p.Din; k += MK_THREADS) {
     const int f = k / p.x_cols, c = k - f * p.x_cols;
-    v[k] = GF(p.x)[(static_cast<size_t>(stream) * p.x_rows + f) * p.x_ld + c];
+    v[k] = GF(p.x)[static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(f) * p.x_ld + c];
   }
   float c_old = 0.f;
   if (tid < 21) {
-    hs[tid] = GF(p.h_in)[static_cast<size_t>(stream) * 21 + tid];
-    c_old = GF(p.c_in)[static_cast<size_t>(stream) * 21 + tid];
+    hs[tid] = GF(p.h_in)[static_cast<size_t>(stream) * p.sstride + tid];
+    c_old = GF(p.c_in)[static_cast<size_t>(stream) * p.sstride + tid];
   }
   __syncthreads();
   if (n < 84) {
@@ -407,7 +452,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
   if (tid < 84) {
     float a = bias;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) a += part[s * 84 + tid];
+    for (int s = 0; s < 4; ++s) a += part[s * 84 + tid];
     z[tid] = a + r;
   }
   // dense weights for the output row this thread owns (Dout <= 256 -> one row per thread)
@@ -424,8 +469,8 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
     const float gg = tanhf(z[42 + tid]), go = mk_sigmoid(z[63 + tid]);
     const float c_new = gf * c_old + gi * gg;
     const float h_new = go * tanhf(c_new);
-    GFW(p.c_out)[static_cast<size_t>(stream) * 21 + tid] = c_new;
-    GFW(p.h_out)[static_cast<size_t>(stream) * 21 + tid] = h_new;
+    GFW(p.c_out)[static_cast<size_t>(stream) * p.sstride + tid] = c_new;
+    GFW(p.h_out)[static_cast<size_t>(stream) * p.sstride + tid] = h_new;
     hn[tid] = h_new;
   }
   __syncthreads();
@@ -434,7 +479,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
 #pragma unroll
     for (int u = 0; u < 21; ++u) a = fmaf(wd[u], hn[u], a);
     const int f = tid / p.dst_cols, c = tid - f * p.dst_cols;
-    GFW(p.dst)[(static_cast<size_t>(stream) * p.dst_rows + f) * p.dst_ld + c] = a;
+    GFW(p.dst)[static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(f) * p.dst_ld + c] = a;
   }
   __syncthreads();
 }
@@ -443,15 +488,17 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
 // Wave u computes hidden unit u of the 64->16 layers (one product per lane + wave reduction);
 // the MLP weights are fetched before the mean-over-F reduction so their latency is hidden.
 __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, float* lds, int tid) {
-  float* part = lds;               // [64][64]
+  float* part = lds;               // [32][64]
   float* m = lds + 4096;           // [64]
   float* hid = m + 64;             // [16]
   float* ta = hid + 16;            // [64]
   float* gate = ta + 64;           // [64]
-  const int c4 = tid & 15, rg = tid >> 4;
-  const int lane = tid & 63, wave = tid >> 6;
-  const float w1_ta = GF(p.ta_w1T)[lane * 16 + wave], w1_fa = GF(p.fa_w1T)[lane * 16 + wave];
-  const float b1_ta = GF(p.ta_b1)[wave], b1_fa = GF(p.fa_b1)[wave];
+  const int c4 = tid & 15, rg = tid >> 4;            // 32 row groups x 16 float4 columns
+  const int lane = tid & 63, wave = tid >> 6;        // wave w owns hidden units w and w + 8
+  const float w1_ta0 = GF(p.ta_w1T)[lane * 16 + wave], w1_ta1 = GF(p.ta_w1T)[lane * 16 + wave + 8];
+  const float w1_fa0 = GF(p.fa_w1T)[lane * 16 + wave], w1_fa1 = GF(p.fa_w1T)[lane * 16 + wave + 8];
+  const float b1_ta0 = GF(p.ta_b1)[wave], b1_ta1 = GF(p.ta_b1)[wave + 8];
+  const float b1_fa0 = GF(p.fa_b1)[wave], b1_fa1 = GF(p.fa_b1)[wave + 8];
   float w2_ta[16], w2_fa[16];
   float b2_ta = 0.f, b2_fa = 0.f;
   if (tid < 64) {
@@ -463,21 +510,21 @@ __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, floa
     b2_ta = GF(p.ta_b2)[tid];
     b2_fa = GF(p.fa_b2)[tid];
   }
-  const float* xb = p.x + static_cast<size_t>(stream) * p.F * p.x_ld;
+  const float* xb = p.x + static_cast<size_t>(stream) * p.sstride;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int f = rg; f < p.F; f += 64) s += *G4(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
+  for (int f = rg; f < p.F; f += 32) s += *G4(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
   *reinterpret_cast<f32x4*>(part + rg * 64 + 4 * c4) = s;
   __syncthreads();
   if (tid < 64) {
     float a = 0.f;
 #pragma unroll 16
-    for (int r = 0; r < 64; ++r) a += part[r * 64 + tid];
+    for (int r = 0; r < 32; ++r) a += part[r * 64 + tid];
     m[tid] = a / static_cast<float>(p.F);
   }
   __syncthreads();
   {
-    const float t = wave_sum(w1_ta * m[lane]);
-    if (lane == 0) hid[wave] = fmaxf(t + b1_ta, 0.f);
+    const float t0 = wave_sum(w1_ta0 * m[lane]), t1 = wave_sum(w1_ta1 * m[lane]);
+    if (lane == 0) { hid[wave] = fmaxf(t0 + b1_ta0, 0.f); hid[wave + 8] = fmaxf(t1 + b1_ta1, 0.f); }
   }
   __syncthreads();
   float ta_c = 0.f;
@@ -490,9 +537,10 @@ __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, floa
   }
   __syncthreads();
   {
-    const float t = wave_sum(w1_fa * (ta[lane] * (1.0f / 32.0f)));
+    const float tv = ta[lane] * (1.0f / 32.0f);
+    const float t0 = wave_sum(w1_fa0 * tv), t1 = wave_sum(w1_fa1 * tv);
     __syncthreads();             // everyone has read hid (TA pass) before it is overwritten
-    if (lane == 0) hid[wave] = fmaxf(t + b1_fa, 0.f);
+    if (lane == 0) { hid[wave] = fmaxf(t0 + b1_fa0, 0.f); hid[wave + 8] = fmaxf(t1 + b1_fa1, 0.f); }
   }
   __syncthreads();
   if (tid < 64) {
@@ -503,9 +551,9 @@ __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, floa
   }
   __syncthreads();
   const f32x4 g4 = *reinterpret_cast<const f32x4*>(gate + 4 * c4);
-  const float* eb = p.e0 + static_cast<size_t>(stream) * p.F * p.e0_ld;
-  float* yb = p.y + static_cast<size_t>(stream) * p.F * p.y_ld;
-  for (int f = rg; f < p.F; f += 64) {
+  const float* eb = p.e0 + static_cast<size_t>(stream) * p.sstride;
+  float* yb = p.y + static_cast<size_t>(stream) * p.sstride;
+  for (int f = rg; f < p.F; f += 32) {
     const f32x4 xv = *G4(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
     const f32x4 ev = *G4(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
     *G4W(yb + static_cast<size_t>(f) * p.y_ld + 4 * c4) = xv * g4 + ev;
@@ -536,7 +584,7 @@ __device__ __forceinline__ void input_layer_op(const InLayerParams& p, int strea
       const float t = y[i] * rstd * gm[i] + bt[i];
       o4[i] = t >= 0.f ? t : p.alpha * t;
     }
-    *G4W(p.y + (static_cast<size_t>(stream) * NUTLS_DEV_BINS + pos) * 64 + 4 * c4) = o4;
+    *G4W(p.y + static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(pos) * 64 + 4 * c4) = o4;
   }
   __syncthreads();
 }
@@ -545,7 +593,7 @@ __device__ __forceinline__ void out_conv_op(const OutConvParams& p, int stream, 
   const int c4 = tid & 15;
   const f32x4 w = *G4(p.w + 4 * c4);
   for (int pos = tid >> 4; pos < NUTLS_DEV_BINS; pos += MK_THREADS / 16) {
-    const f32x4 xv = *G4(p.x + (static_cast<size_t>(stream) * NUTLS_DEV_BINS + pos) * p.x_ld + 4 * c4);
+    const f32x4 xv = *G4(p.x + static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(pos) * p.x_ld + 4 * c4);
     float s = xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
@@ -559,17 +607,23 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Dev
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
   float* lds_out = lds + MK_LDS_IN;
-  const int tid = threadIdx.x;
+  // `fresh_tid()` re-materialises the thread id behind an opaque asm at every layer: without it the
+  // compiler hoists dozens of tid-derived per-thread constants out of the layer loop, keeps them live
+  // across the whole kernel and spills them -- and a scratch reload is a vmcnt wait, which in this
+  // kernel means "wait for every prefetch in flight".
+  auto fresh_tid = []() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
   for (int stream = blockIdx.x; stream < B; stream += gridDim.x) {
     int i = 0;
+    if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[n_ops * 9 + 1] = clock64();
 #pragma unroll 1
     while (i < n_ops) {
       if (plan[i].op == DEV_OP_CONV) {
-        // a run of consecutive conv layers: prefetch registers (activations, first weight chunk) live only here
+        // a run of consecutive conv layers: the first weight chunk of the next layer lives in registers
         f32x4 wnext[4];
         bool have_w = false;
 #pragma unroll 1
         while (i < n_ops && plan[i].op == DEV_OP_CONV) {
+          const int tid = fresh_tid();
           if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
           unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
           conv_layer(plan[i], (i + 1 < n_ops) ? &plan[i + 1] : nullptr, stream, lds_in, lds_out, tid, wnext, have_w, sub);
@@ -577,6 +631,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Dev
         }
       } else {
         const DevLaunch& L = plan[i];
+        const int tid = fresh_tid();
         if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
         switch (L.op) {
           case DEV_OP_LSTM: lstm_layer(L.lstm, stream, lds_out, tid); break;
@@ -587,7 +642,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Dev
         ++i;
       }
     }
-    if (prof && blockIdx.x == 0 && tid == 0) prof[n_ops] = wall_clock64();
+    if (prof && blockIdx.x == 0 && threadIdx.x == 0) { prof[n_ops] = wall_clock64(); prof[n_ops * 9 + 2] = clock64(); }
   }
 }
 

@@ -25,6 +25,10 @@ using WeightMap = std::map<std::string, HostTensor>;
 bool parse_weight_blob(const void* blob, size_t n, WeightMap* out, std::string* err);
 
 // ------------------------------------------------------------------ kernel parameters ---------
+// Memory layout: every per-stream tensor (state, scratch) lives in ONE arena laid out stream-major,
+// element (stream b, row r, channel c) of a tensor at  base + b*sstride + r*ld + c.  A stream's
+// whole working set (~2.6 MB) is contiguous, so the workgroup that owns the stream stays inside a
+// couple of 2 MiB pages.
 // Generic "tap-GEMM" convolution over channels-last rows (see kernels.hip for the tiling).
 struct ConvParams {
   const float* src0;   // time tap 0 (previous frame) -- or the only input when TT == 1
@@ -41,6 +45,7 @@ struct ConvParams {
   int log2_fout;
   int row_mul, row_add;  // output row of position f, group g:  f*row_mul + row_add + g
   float alpha;           // PReLU slope
+  long long sstride;     // floats between consecutive streams (all per-stream tensors share one arena stride)
 };
 
 enum ConvKind : int {
@@ -76,6 +81,7 @@ struct LstmParams {
   const float* h_in; const float* c_in; float* h_out; float* c_out;   // [B,21]
   float* dst; int dst_ld, dst_rows, dst_cols;  // y[f*dst_cols+c] -> dst[(b*dst_rows+f)*dst_ld + c]
   int Din, Dout, B;
+  long long sstride;
 };
 hipError_t launch_lstm(const LstmParams& p, hipStream_t s);
 
@@ -86,6 +92,7 @@ struct CtfaParams {
   const float* ta_w1T; const float* ta_b1; const float* ta_w2T; const float* ta_b2;  // [64][16],[16],[16][64],[64]
   const float* fa_w1T; const float* fa_b1; const float* fa_w2T; const float* fa_b2;
   int B, F;
+  long long sstride;
 };
 hipError_t launch_ctfa(const CtfaParams& p, hipStream_t s);
 
@@ -94,6 +101,7 @@ struct InLayerParams {   // input_layer: 1x1 conv 1->64 + LN + PReLU
   float* y;              // [B,256,64]
   const float* w; const float* b; const float* gamma; const float* beta; float alpha;
   int n_pos;             // B*256
+  long long sstride;     // stream stride of y (x is the plain [B,256] input)
 };
 hipError_t launch_input_layer(const InLayerParams& p, hipStream_t s);
 
@@ -102,6 +110,7 @@ struct OutConvParams {   // 1x1 conv 64->1
   float* y;                   // [B,256]
   const float* w; float bias;
   int n_pos;
+  long long sstride;          // stream stride of x (y is the plain [B,256] output)
 };
 hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
 
@@ -119,7 +128,10 @@ struct ConvPlan {
   int cc, cc4_shift, pitch, rows, vrows, n4p_shift, nch_shift, nph, phase_floats;
   // task decomposition over the 16 waves
   int merged;            // every phase resident at once (rounds == 1)
-  int rounds, RG, KS, gpk, gpc, PT, tiles, tiles_shift, nt_shift;
+  int rounds, RG, KS, gpk, gpc, PT, tiles, nt_shift;
+  int tw;                // 32x32 output tiles per wave: 2 (position-tile pairs sharing the weight fragments) when the
+                         // layer has more tiles than waves, else 1
+  int tasks, tasks_shift; // wave tasks per K slice = tiles / tw
   int opitch, slot_floats, R, lpg;
   // hand-off between consecutive layers
   int staged_by_prev;    // the previous layer's epilogue already completed this layer's LDS image
@@ -145,7 +157,8 @@ struct DevLaunch {
   ConvPlan cp;   // valid when op == DEV_OP_CONV
 };
 constexpr int MK_LDS_IN_FLOATS = 17920;   // staged input: >= 256 rows x 68, 129 row pairs x 132, 2 x 130 rows x 68
-constexpr int MK_STAGE_ITEMS = 4096;      // float4 a merged layer may stage through registers (4 per thread)
+constexpr int MK_STAGE_ITEMS = 4096;      // float4 a merged layer may stage through registers (8 per thread)
+constexpr int MK_NWAVES = 8;              // waves per workgroup of the persistent kernel (512 threads, 2 per SIMD)
 // Fills everything of ConvPlan except the hand-off fields.
 ConvPlan make_conv_plan(ConvKind k, const ConvParams& p);
 // grid = number of workgroups (each loops over streams blockIdx.x, +grid, ...); prof (nullable)

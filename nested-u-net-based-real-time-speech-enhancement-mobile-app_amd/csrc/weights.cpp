@@ -125,12 +125,14 @@ ConvPlan make_conv_plan(ConvKind k, const ConvParams& p) {
   c.RG = nstage * sh.kf * c.gpc;
   c.PT = (p.F_out + 31) / 32;
   c.tiles = c.PT * sh.nt;
-  c.tiles_shift = ilog2_exact(c.tiles);
   c.nt_shift = ilog2_exact(sh.nt);
-  // K split: the largest slice count that keeps <= 16 tasks, whole 4-group chunks per slice, and
+  c.tw = c.tiles > MK_NWAVES ? 2 : 1;                 // 16-tile layers: two position tiles per wave
+  c.tasks = c.tiles / c.tw;
+  c.tasks_shift = ilog2_exact(c.tasks);
+  // K split: the largest slice count that keeps <= 8 wave tasks, whole 4-group chunks per slice, and
   // slices that are either one chunk or whole frequency-tap segments
   int best = 1;
-  for (int ks = 1; ks <= 16 / c.tiles; ++ks) {
+  for (int ks = 1; ks <= MK_NWAVES / c.tasks; ++ks) {
     if (c.RG % ks) continue;
     const int gpk = c.RG / ks;
     if (gpk % 4) continue;
