@@ -92,6 +92,8 @@ struct Engine {
   int B = 0, device = 0;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
+  float* warena = nullptr;       // all weights, one allocation
+  size_t wcursor = 0;
   float* arena = nullptr;        // stream-major arena: stream b's tensors at arena + b*sstride + slot offset
   size_t sstride = 0;            // floats per stream
   size_t arena_cursor = 0;       // next free slot offset (floats) while the layout is being built
@@ -106,7 +108,7 @@ struct Engine {
   float* upcat[6] = {nullptr};
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
   int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel
-  DevLaunch* dplan[2] = {nullptr, nullptr};
+  CompactOp* dplan[2] = {nullptr, nullptr};
   unsigned long long* dprof = nullptr;
   int n_cu = 256;
   hipGraphExec_t gexec[2] = {nullptr, nullptr};
@@ -178,9 +180,22 @@ static int copy_stream_tensor(Engine* e, float* dev, size_t per_stream, float* h
   return NUTLS_OK;
 }
 
+// All weights live in ONE device allocation (bump-allocated, 256-byte aligned pieces) so the
+// persistent kernel can address them with 32-bit offsets from a single base.
+static constexpr size_t kWeightArenaFloats = 8u << 20;   // 32 MiB: 11.5 MB of parameters + packing padding
+
 static int upload(Engine* e, const std::vector<float>& v, float** out) {
-  int rc = dev_alloc(e, v.size() < 4 ? 4 : v.size(), out, false);
-  if (rc) return rc;
+  if (!e->warena) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, kWeightArenaFloats * sizeof(float)));
+    e->allocs.push_back(p);
+    HIP_TRY(hipMemset(p, 0, kWeightArenaFloats * sizeof(float)));
+    e->warena = static_cast<float*>(p);
+  }
+  const size_t n = (v.size() + 63) & ~static_cast<size_t>(63);
+  if (e->wcursor + n > kWeightArenaFloats) return fail(NUTLS_ERR_WEIGHTS, "weight arena exhausted");
+  *out = e->warena + e->wcursor;
+  e->wcursor += n;
   HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
   return NUTLS_OK;
 }
@@ -653,11 +668,14 @@ static int upload_device_plans(Engine* e) {
                   c.staged_by_prev, c.pf_phase0_ready, c.hand_next, c.fwd_sel, c.fwd_coff4, c.fwd_rmul, c.fwd_radd, c.pre_next_phase0);
         }
     }
+    if (dv.size() > static_cast<size_t>(MK_MAX_OPS)) return fail(NUTLS_ERR_ARG, "plan too long for the LDS-resident form");
+    std::vector<CompactOp> cv(dv.size());
+    for (size_t i = 0; i < dv.size(); ++i) cv[i] = encode_op(dv[i], e->arena, e->warena);
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, dv.size() * sizeof(DevLaunch)));
+    HIP_TRY(hipMalloc(&p, cv.size() * sizeof(CompactOp)));
     e->allocs.push_back(p);
-    HIP_TRY(hipMemcpy(p, dv.data(), dv.size() * sizeof(DevLaunch), hipMemcpyHostToDevice));
-    e->dplan[par] = static_cast<DevLaunch*>(p);
+    HIP_TRY(hipMemcpy(p, cv.data(), cv.size() * sizeof(CompactOp), hipMemcpyHostToDevice));
+    e->dplan[par] = static_cast<CompactOp*>(p);
   }
   void* q = nullptr;
   HIP_TRY(hipMalloc(&q, (e->plan[0].size() * 9 + 3) * sizeof(unsigned long long)));   // layer stamps + 8 sub-stamps per layer + 2 clock64
@@ -669,7 +687,9 @@ static int upload_device_plans(Engine* e) {
 
 static int run_persistent(Engine* e, int par, hipStream_t s, bool prof) {
   const int grid = e->B;   // one workgroup per stream; the hardware runs as many as fit (1 per CU)
-  hipError_t err = launch_stream_step(e->dplan[par], static_cast<int>(e->plan[par].size()), e->B, grid, prof ? e->dprof : nullptr, s);
+  StepArgs a{e->dplan[par], static_cast<int>(e->plan[par].size()), e->B, e->arena, static_cast<long long>(e->sstride), e->warena,
+             e->io_in, e->io_out, prof ? e->dprof : nullptr};
+  hipError_t err = launch_stream_step(a, grid, s);
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("persistent step launch: ") + hipGetErrorString(err));
   return NUTLS_OK;
 }

@@ -48,13 +48,83 @@ constexpr int MK_THREADS = 64 * MK_WAVES;
 constexpr int MK_MAXPF = MK_STAGE_ITEMS / MK_THREADS;   // float4 prefetch registers per thread (8)
 constexpr int MK_LDS_IN = MK_LDS_IN_FLOATS;
 constexpr int MK_LDS_OUT = 16 * 32 * 36;      // floats: 16 tasks x 32 positions x (32+4)
-constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT) * sizeof(float);
+constexpr int MK_LDS_PLAN = MK_MAX_OPS * MK_OP_WORDS;   // dwords: the whole compact plan
+constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT + MK_LDS_PLAN) * sizeof(float);
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does NOT drain vmcnt,
 // so global loads issued earlier (next layer's image rows, weight fragments) stay in flight across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define MK_STAMP(k) do { if (sub && tid == 0) sub[k] = wall_clock64(); } while (0)
+
+// ---------------------------------------------------------------------------------------------
+//  Compact plan decode (layout: encode_op() in weights.cpp).  All values are wave-uniform; the
+//  readfirstlane moves them to SGPRs so the layer code branches and addresses on scalars.
+// ---------------------------------------------------------------------------------------------
+struct OpWords { unsigned w[MK_OP_WORDS]; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ OpWords load_op(const unsigned* lds_plan, int i) {
+  OpWords o;
+  const u32x4* q = reinterpret_cast<const u32x4*>(lds_plan + i * MK_OP_WORDS);
+#pragma unroll
+  for (int k = 0; k < MK_OP_WORDS / 4; ++k) {
+    const u32x4 v = q[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.w[4 * k + j] = __builtin_amdgcn_readfirstlane(v[j]);
+  }
+  return o;
+}
+__device__ __forceinline__ int b0(unsigned w) { return w & 255; }
+__device__ __forceinline__ int b1(unsigned w) { return (w >> 8) & 255; }
+__device__ __forceinline__ int b2(unsigned w) { return (w >> 16) & 255; }
+__device__ __forceinline__ int b3(unsigned w) { return w >> 24; }
+__device__ __forceinline__ int h0(unsigned w) { return w & 0xFFFF; }
+__device__ __forceinline__ int h1(unsigned w) { return w >> 16; }
+__device__ __forceinline__ float* aptr(float* base, unsigned off) { return off == MK_NULL_OFF ? nullptr : base + off; }
+__device__ __forceinline__ const float* wptr(const float* base, unsigned off) { return off == MK_NULL_OFF ? nullptr : base + off; }
+
+__device__ __forceinline__ void decode_conv(const OpWords& o, const StepArgs& a, ConvParams& p, ConvPlan& c) {
+  p.src0 = aptr(a.arena, o.w[0]); p.src1 = aptr(a.arena, o.w[1]);
+  p.dst0 = aptr(a.arena, o.w[2]); p.dst1 = aptr(a.arena, o.w[3]);
+  p.wpk = wptr(a.wbase, o.w[4]); p.bias = wptr(a.wbase, o.w[5]); p.gamma = wptr(a.wbase, o.w[6]); p.beta = wptr(a.wbase, o.w[7]);
+  p.alpha = __uint_as_float(o.w[8]);
+  p.src_ld = b0(o.w[9]); p.ld0 = b1(o.w[9]); p.ld1 = b2(o.w[9]);
+  const int fl = b3(o.w[9]);
+  p.row_mul = fl & 3; p.row_add = (fl >> 2) & 1;
+  c.stride = ((fl >> 3) & 1) + 1; c.tt = ((fl >> 4) & 1) + 1; c.epi_ln = (fl >> 5) & 1; c.merged = (fl >> 6) & 1;
+  c.staged_by_prev = (fl >> 7) & 1;
+  p.F_in = h0(o.w[10]); p.F_out = h1(o.w[10]);
+  p.B = a.B; p.sstride = a.sstride; p.log2_fout = 0;
+  c.kf = b0(o.w[11]); c.padl = b1(o.w[11]); c.g = b2(o.w[11]); c.nt = b3(o.w[11]);
+  c.cc = b0(o.w[12]); c.cc4_shift = b1(o.w[12]); c.n4p_shift = b2(o.w[12]); c.nch_shift = b3(o.w[12]);
+  c.pitch = h0(o.w[13]); c.rows = h1(o.w[13]);
+  c.vrows = h0(o.w[14]); c.nph = b2(o.w[14]); c.rounds = b3(o.w[14]);
+  c.phase_floats = h0(o.w[15]); c.slot_floats = h1(o.w[15]);
+  c.RG = b0(o.w[16]); c.KS = b1(o.w[16]); c.gpk = b2(o.w[16]); c.gpc = b3(o.w[16]);
+  c.PT = b0(o.w[17]); c.tiles = b1(o.w[17]); c.nt_shift = b2(o.w[17]); c.tw = b3(o.w[17]);
+  c.tasks = b0(o.w[18]); c.tasks_shift = b1(o.w[18]); c.opitch = h1(o.w[18]);
+  c.R = b0(o.w[19]); c.lpg = b1(o.w[19]); c.hand_next = b2(o.w[19]); c.fwd_sel = b3(o.w[19]);
+  c.fwd_coff4 = b0(o.w[20]); c.fwd_rmul = b1(o.w[20]); c.fwd_radd = b2(o.w[20]); c.cin = b3(o.w[20]);
+  c.pf_phase0_ready = 0; c.pre_next_phase0 = 0;
+}
+
+__device__ __forceinline__ void decode_lstm(const OpWords& o, const StepArgs& a, LstmParams& p) {
+  p.x = aptr(a.arena, o.w[0]); p.x_ld = h0(o.w[1]); p.x_cols = h1(o.w[1]); p.x_rows = 0;
+  p.wxT = wptr(a.wbase, o.w[2]); p.whT = wptr(a.wbase, o.w[3]); p.bias = wptr(a.wbase, o.w[4]);
+  p.wdT = wptr(a.wbase, o.w[5]); p.bd = wptr(a.wbase, o.w[6]);
+  p.h_in = aptr(a.arena, o.w[7]); p.c_in = aptr(a.arena, o.w[8]); p.h_out = aptr(a.arena, o.w[9]); p.c_out = aptr(a.arena, o.w[10]);
+  p.dst = aptr(a.arena, o.w[11]); p.dst_ld = h0(o.w[12]); p.dst_cols = h1(o.w[12]); p.dst_rows = 0;
+  p.Din = h0(o.w[13]); p.Dout = h1(o.w[13]); p.B = a.B; p.sstride = a.sstride;
+}
+
+__device__ __forceinline__ void decode_ctfa(const OpWords& o, const StepArgs& a, CtfaParams& p) {
+  p.x = aptr(a.arena, o.w[0]); p.e0 = aptr(a.arena, o.w[1]); p.y = aptr(a.arena, o.w[2]);
+  p.x_ld = b0(o.w[3]); p.e0_ld = b1(o.w[3]); p.y_ld = b2(o.w[3]);
+  p.ta_w1T = wptr(a.wbase, o.w[4]); p.ta_b1 = wptr(a.wbase, o.w[5]); p.ta_w2T = wptr(a.wbase, o.w[6]); p.ta_b2 = wptr(a.wbase, o.w[7]);
+  p.fa_w1T = wptr(a.wbase, o.w[8]); p.fa_b1 = wptr(a.wbase, o.w[9]); p.fa_w2T = wptr(a.wbase, o.w[10]); p.fa_b2 = wptr(a.wbase, o.w[11]);
+  p.F = static_cast<int>(o.w[12]); p.B = a.B; p.sstride = a.sstride;
+}
 
 // LDS float offset of (image row lr, float4 column c4) inside one phase
 __device__ __forceinline__ int img_addr(const ConvPlan& c, int lr, int c4) {
@@ -215,7 +285,7 @@ __device__ __forceinline__ void mfma_round(f32x16 (&acc)[2], f32x4 (&wa)[4], con
 // ---------------------------------------------------------------------------------------------
 template <int LPG, bool LN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPlan& c, int stream, const float* lds_out, int tid,
-                                              f32x4 bias, f32x4 gm, f32x4 bt, const ConvPlan* nx, float* lds_next, int fwd_sel,
+                                              f32x4 bias, f32x4 gm, f32x4 bt, bool do_fwd, const ConvPlan& nx, float* lds_next,
                                               int fwd_coff4) {
   constexpr int GC = LPG * 4;
   const int li = tid & (LPG - 1);
@@ -224,10 +294,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPla
   float* d1 = p.dst1 ? p.dst1 + static_cast<size_t>(stream) * p.sstride : nullptr;
   // forwarded block inside the next image: float4 column (coff4 + li) of the current-frame phase
   int f_ph = 0, f_c4 = 0;
-  if (nx && fwd_sel) {
+  if (do_fwd) {
     const int chan4 = fwd_coff4 + li;
-    f_ph = ((nx->tt - 1) << nx->nch_shift) + (chan4 >> nx->cc4_shift);
-    f_c4 = chan4 & ((1 << nx->cc4_shift) - 1);
+    f_ph = ((nx.tt - 1) << nx.nch_shift) + (chan4 >> nx.cc4_shift);
+    f_c4 = chan4 & ((1 << nx.cc4_shift) - 1);
   }
   for (int u = tid / LPG; u < units; u += MK_THREADS / LPG) {
     const int pos = (c.R == 2) ? (u >> 1) : u, gi = (c.R == 2) ? (u & 1) : 0;
@@ -253,17 +323,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPla
     const int row = pos * p.row_mul + p.row_add + gi;
     *G4W(d0 + static_cast<size_t>(row) * p.ld0 + 4 * li) = v;
     if (d1) *G4W(d1 + static_cast<size_t>(row) * p.ld1 + 4 * li) = v;
-    if (nx && fwd_sel) *reinterpret_cast<f32x4*>(lds_next + f_ph * nx->phase_floats + img_addr(*nx, nx->padl + row, f_c4)) = v;
+    if (do_fwd) *reinterpret_cast<f32x4*>(lds_next + f_ph * nx.phase_floats + img_addr(nx, nx.padl + row, f_c4)) = v;
   }
 }
 
 // One conv-like layer for one stream.
 //   wnext  in : this task's first weight chunk (fetched while the previous layer ran) when `have_w`
 //          out: the next layer's first chunk (single static load site -> no copies of pending loads)
-__device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* N, int stream, float* lds_in, float* lds_out, int tid,
-                                           f32x4 (&wnext)[4], bool& have_w, unsigned long long* sub) {
-  const ConvParams& p = L.conv;
-  const ConvPlan& c = L.cp;
+__device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& c, bool nconv, const ConvParams& np, const ConvPlan& ncp,
+                                           int stream, float* lds_in, float* lds_out, int tid, f32x4 (&wnext)[4], bool& have_w,
+                                           unsigned long long* sub) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SGPR
   const int pl = lane & 31, h = lane >> 5;
@@ -303,11 +372,10 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
   MK_STAMP(1);
 
   // ---- what this layer owes the next one
-  const bool nconv = N && N->op == DEV_OP_CONV;
   const bool hand = nconv && c.hand_next;
   FwdWin fw = nofw;
   if (hand && c.fwd_sel) { fw.lo4 = c.fwd_coff4; fw.hi4 = c.fwd_coff4 + c.lpg; fw.rmul = c.fwd_rmul; fw.radd = c.fwd_radd; }
-  const int n_hand = hand ? (N->cp.merged ? N->cp.nph : 1) : 0;
+  const int n_hand = hand ? (ncp.merged ? ncp.nph : 1) : 0;
 
   // Global loads are issued oldest-needed-first (vmcnt retires in order): epilogue parameters, then
   // the next layer's first weight chunk, then -- after this layer's own last weight prefetch -- the
@@ -330,7 +398,7 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
   // and, in the last round, the next layer's image rows
   f32x4 pfx[MK_MAXPF];
   auto next_image_hook = [&]() {
-    if (hand) image_load(N->conv, N->cp, stream, 0, n_hand, tid, pfx);   // youngest loads of the layer
+    if (hand) image_load(np, ncp, stream, 0, n_hand, tid, pfx);   // youngest loads of the layer
     MK_STAMP(7);
   };
 
@@ -351,12 +419,14 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
     }
   }
   {   // next layer's first weight chunk (single load site; a layer with no conv successor re-reads its own)
-    const DevLaunch& W = nconv ? *N : L;
-    const ConvPlan& n = W.cp;
-    const bool nact = wave < n.tasks * n.KS;
-    const int nks = nact ? (wave >> n.tasks_shift) : 0;
-    const int nnt = nact ? (wave & (n.nt - 1)) : 0;
-    load_chunk(wnext, (gc4_t)(unsigned long long)W.conv.wpk + (static_cast<size_t>(nks * n.gpk) * n.nt + nnt) * 64, n.nt * 64, lane);
+    // (field-wise selects: a reference/pointer select between the two structs would force both to memory)
+    const float* nw = nconv ? np.wpk : p.wpk;
+    const int n_tasks = nconv ? ncp.tasks : c.tasks, n_ks = nconv ? ncp.KS : c.KS, n_shift = nconv ? ncp.tasks_shift : c.tasks_shift;
+    const int n_nt = nconv ? ncp.nt : c.nt, n_gpk = nconv ? ncp.gpk : c.gpk;
+    const bool nact = wave < n_tasks * n_ks;
+    const int nks = nact ? (wave >> n_shift) : 0;
+    const int nnt = nact ? (wave & (n_nt - 1)) : 0;
+    load_chunk(wnext, (gc4_t)(unsigned long long)nw + (static_cast<size_t>(nks * n_gpk) * n_nt + nnt) * 64, n_nt * 64, lane);
     have_w = nconv;
   }
   MK_STAMP(2);
@@ -378,16 +448,16 @@ __device__ __forceinline__ void conv_layer(const DevLaunch& L, const DevLaunch* 
   lds_barrier();                 // also: every wave has finished reading lds_in
   MK_STAMP(3);
 
-  const ConvPlan* nx = (hand && c.fwd_sel) ? &N->cp : nullptr;
+  const bool do_fwd = hand && c.fwd_sel;
   if (c.epi_ln) {
-    if (c.g == 1) conv_epilogue<8, true>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
-    else conv_epilogue<16, true>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
+    if (c.g == 1) conv_epilogue<8, true>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
+    else conv_epilogue<16, true>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
   } else {
-    if (c.g == 2) conv_epilogue<16, false>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
-    else conv_epilogue<32, false>(p, c, stream, lds_out, tid, bias, gm, bt, nx, lds_in, c.fwd_sel, c.fwd_coff4);
+    if (c.g == 2) conv_epilogue<16, false>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
+    else conv_epilogue<32, false>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
   }
   // ---- hand-off: the prefetched part of the next layer's image (the forwarded rows were written above)
-  if (hand) image_store(N->cp, lds_in, 0, n_hand, 0, fw, tid, pfx);
+  if (hand) image_store(ncp, lds_in, 0, n_hand, 0, fw, tid, pfx);
   MK_STAMP(4);
   __syncthreads();               // HBM stores visible to the workgroup; next image complete; exchange buffer free
   MK_STAMP(5);
@@ -561,7 +631,11 @@ __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, floa
   __syncthreads();
 }
 
-__device__ __forceinline__ void input_layer_op(const InLayerParams& p, int stream, int tid) {
+__device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs& a, int stream, int tid) {
+  InLayerParams p;
+  p.x = a.io_in; p.y = aptr(a.arena, o.w[0]);
+  p.w = wptr(a.wbase, o.w[1]); p.b = wptr(a.wbase, o.w[2]); p.gamma = wptr(a.wbase, o.w[3]); p.beta = wptr(a.wbase, o.w[4]);
+  p.alpha = __uint_as_float(o.w[5]); p.sstride = a.sstride;
   const int c4 = tid & 15;
   const f32x4 w = *G4(p.w + 4 * c4);
   const f32x4 bb = *G4(p.b + 4 * c4);
@@ -589,7 +663,10 @@ __device__ __forceinline__ void input_layer_op(const InLayerParams& p, int strea
   __syncthreads();
 }
 
-__device__ __forceinline__ void out_conv_op(const OutConvParams& p, int stream, int tid) {
+__device__ __forceinline__ void out_conv_op(const OpWords& o, const StepArgs& a, int stream, int tid) {
+  OutConvParams p;
+  p.x = aptr(a.arena, o.w[0]); p.x_ld = static_cast<int>(o.w[1]); p.y = a.io_out;
+  p.w = wptr(a.wbase, o.w[2]); p.bias = __uint_as_float(o.w[3]); p.sstride = a.sstride;
   const int c4 = tid & 15;
   const f32x4 w = *G4(p.w + 4 * c4);
   for (int pos = tid >> 4; pos < NUTLS_DEV_BINS; pos += MK_THREADS / 16) {
@@ -602,42 +679,68 @@ __device__ __forceinline__ void out_conv_op(const OutConvParams& p, int stream, 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const DevLaunch* __restrict__ plan, int n_ops, int B,
-                                                                       unsigned long long* prof) {
+__global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
   float* lds_out = lds + MK_LDS_IN;
+  unsigned* lds_plan = reinterpret_cast<unsigned*>(lds + MK_LDS_IN + MK_LDS_OUT);
+  const int n_ops = a.n_ops;
+  unsigned long long* prof = a.prof;
+  // the whole compact plan -> LDS, once
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.plan);
+    for (int q = threadIdx.x; q < n_ops * (MK_OP_WORDS / 4); q += MK_THREADS)
+      reinterpret_cast<u32x4*>(lds_plan)[q] = src[q];
+    __syncthreads();
+  }
   // `fresh_tid()` re-materialises the thread id behind an opaque asm at every layer: without it the
   // compiler hoists dozens of tid-derived per-thread constants out of the layer loop, keeps them live
   // across the whole kernel and spills them -- and a scratch reload is a vmcnt wait, which in this
   // kernel means "wait for every prefetch in flight".
   auto fresh_tid = []() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
-  for (int stream = blockIdx.x; stream < B; stream += gridDim.x) {
+  for (int stream = blockIdx.x; stream < a.B; stream += gridDim.x) {
     int i = 0;
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[n_ops * 9 + 1] = clock64();
 #pragma unroll 1
     while (i < n_ops) {
-      if (plan[i].op == DEV_OP_CONV) {
+      const OpWords o = load_op(lds_plan, i);
+      const int op = static_cast<int>(o.w[23]);
+      if (op == DEV_OP_CONV) {
         // a run of consecutive conv layers: the first weight chunk of the next layer lives in registers
         f32x4 wnext[4];
         bool have_w = false;
+        OpWords cur = o;
 #pragma unroll 1
-        while (i < n_ops && plan[i].op == DEV_OP_CONV) {
+        while (true) {
           const int tid = fresh_tid();
           if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
           unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
-          conv_layer(plan[i], (i + 1 < n_ops) ? &plan[i + 1] : nullptr, stream, lds_in, lds_out, tid, wnext, have_w, sub);
+          const OpWords nxt = load_op(lds_plan, i + 1 < n_ops ? i + 1 : i);
+          const bool nconv = (i + 1 < n_ops) && static_cast<int>(nxt.w[23]) == DEV_OP_CONV;
+          ConvParams p, np;
+          ConvPlan c, ncp;
+          decode_conv(cur, a, p, c);
+          decode_conv(nxt, a, np, ncp);
+          conv_layer(p, c, nconv, np, ncp, stream, lds_in, lds_out, tid, wnext, have_w, sub);
           ++i;
+          if (!nconv) break;
+          cur = nxt;
         }
       } else {
-        const DevLaunch& L = plan[i];
         const int tid = fresh_tid();
         if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
-        switch (L.op) {
-          case DEV_OP_LSTM: lstm_layer(L.lstm, stream, lds_out, tid); break;
-          case DEV_OP_CTFA: ctfa_layer(L.ctfa, stream, lds_out, tid); break;
-          case DEV_OP_INLAYER: input_layer_op(L.inl, stream, tid); break;
-          default: out_conv_op(L.outc, stream, tid); break;
+        if (op == DEV_OP_LSTM) {
+          LstmParams p;
+          decode_lstm(o, a, p);
+          lstm_layer(p, stream, lds_out, tid);
+        } else if (op == DEV_OP_CTFA) {
+          CtfaParams p;
+          decode_ctfa(o, a, p);
+          ctfa_layer(p, stream, lds_out, tid);
+        } else if (op == DEV_OP_INLAYER) {
+          input_layer_op(o, a, stream, tid);
+        } else {
+          out_conv_op(o, a, stream, tid);
         }
         ++i;
       }
@@ -646,7 +749,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Dev
   }
 }
 
-hipError_t launch_stream_step(const DevLaunch* plan, int n_ops, int B, int grid, unsigned long long* prof, hipStream_t s) {
+hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nutls_stream_step_kernel),
@@ -654,7 +757,7 @@ hipError_t launch_stream_step(const DevLaunch* plan, int n_ops, int B, int grid,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(nutls_stream_step_kernel, dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, plan, n_ops, B, prof);
+  hipLaunchKernelGGL(nutls_stream_step_kernel, dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
   return hipGetLastError();
 }
 

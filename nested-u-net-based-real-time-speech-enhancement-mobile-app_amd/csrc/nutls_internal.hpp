@@ -161,9 +161,29 @@ constexpr int MK_STAGE_ITEMS = 4096;      // float4 a merged layer may stage thr
 constexpr int MK_NWAVES = 8;              // waves per workgroup of the persistent kernel (512 threads, 2 per SIMD)
 // Fills everything of ConvPlan except the hand-off fields.
 ConvPlan make_conv_plan(ConvKind k, const ConvParams& p);
+// Compact, LDS-resident form of the plan: 24 dwords per op, pointers as 32-bit float offsets from
+// the stream arena / the weight arena.  The persistent kernel copies the whole plan into LDS once
+// and every wave decodes the current and the next op from there (a handful of ds_reads) instead of
+// chasing ~12 scalar-cache misses per layer through the full-size structs.
+constexpr int MK_OP_WORDS = 24;
+struct CompactOp { uint32_t w[MK_OP_WORDS]; };
+constexpr uint32_t MK_NULL_OFF = 0xFFFFFFFFu;
+constexpr int MK_MAX_OPS = 168;
+struct StepArgs {            // kernel arguments of the persistent kernel
+  const CompactOp* plan;
+  int n_ops, B;
+  float* arena;              // stream-0 base of the per-stream arena
+  long long sstride;         // floats per stream
+  const float* wbase;        // weight arena
+  const float* io_in;        // [B,256]
+  float* io_out;             // [B,256]
+  unsigned long long* prof;  // nullable
+};
+CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase);
+hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s);
+
 // grid = number of workgroups (each loops over streams blockIdx.x, +grid, ...); prof (nullable)
 // receives wall_clock64() at every layer boundary of workgroup 0 (n_ops + 1 entries).
-hipError_t launch_stream_step(const DevLaunch* plan, int n_ops, int B, int grid, unsigned long long* prof, hipStream_t s);
 
 // Packs OHWI conv weights [Cout][th][kw][Cin] into the order the MFMA loop streams them.
 //   perm[n'] = original output channel feeding packed channel n'

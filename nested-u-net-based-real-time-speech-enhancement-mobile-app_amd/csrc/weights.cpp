@@ -148,4 +148,80 @@ ConvPlan make_conv_plan(ConvKind k, const ConvParams& p) {
   return c;
 }
 
+static uint32_t off_of(const float* p, const float* base) {
+  return p ? static_cast<uint32_t>(p - base) : MK_NULL_OFF;
+}
+static uint32_t pack4(int a, int b, int c, int d) {
+  return (static_cast<uint32_t>(a) & 255u) | ((static_cast<uint32_t>(b) & 255u) << 8) | ((static_cast<uint32_t>(c) & 255u) << 16) |
+         ((static_cast<uint32_t>(d) & 255u) << 24);
+}
+static uint32_t pack2(int lo, int hi) { return (static_cast<uint32_t>(lo) & 0xFFFFu) | (static_cast<uint32_t>(hi) << 16); }
+static uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// Word layout (keep in sync with the decode_* functions of megakernel.hip); w[23] = op code.
+CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) {
+  CompactOp o{};
+  o.w[23] = static_cast<uint32_t>(d.op);
+  switch (d.op) {
+    case DEV_OP_CONV: {
+      const ConvParams& p = d.conv;
+      const ConvPlan& c = d.cp;
+      o.w[0] = off_of(p.src0, arena); o.w[1] = off_of(p.src1, arena);
+      o.w[2] = off_of(p.dst0, arena); o.w[3] = off_of(p.dst1, arena);
+      o.w[4] = off_of(p.wpk, wbase); o.w[5] = off_of(p.bias, wbase);
+      o.w[6] = off_of(p.gamma, wbase); o.w[7] = off_of(p.beta, wbase);
+      o.w[8] = fbits(p.alpha);
+      const int flags = (p.row_mul & 3) | ((p.row_add & 1) << 2) | ((c.stride - 1) << 3) | ((c.tt - 1) << 4) | (c.epi_ln << 5) |
+                        (c.merged << 6) | (c.staged_by_prev << 7);
+      o.w[9] = pack4(p.src_ld, p.ld0, p.ld1, flags);
+      o.w[10] = pack2(p.F_in, p.F_out);
+      o.w[11] = pack4(c.kf, c.padl, c.g, c.nt);
+      o.w[12] = pack4(c.cc, c.cc4_shift, c.n4p_shift, c.nch_shift);
+      o.w[13] = pack2(c.pitch, c.rows);
+      o.w[14] = pack2(c.vrows, c.nph | (c.rounds << 8));
+      o.w[15] = pack2(c.phase_floats, c.slot_floats);
+      o.w[16] = pack4(c.RG, c.KS, c.gpk, c.gpc);
+      o.w[17] = pack4(c.PT, c.tiles, c.nt_shift, c.tw);
+      o.w[18] = pack2(c.tasks | (c.tasks_shift << 8), c.opitch);
+      o.w[19] = pack4(c.R, c.lpg, c.hand_next, c.fwd_sel);
+      o.w[20] = pack4(c.fwd_coff4, c.fwd_rmul, c.fwd_radd, c.cin);
+      break;
+    }
+    case DEV_OP_LSTM: {
+      const LstmParams& p = d.lstm;
+      o.w[0] = off_of(p.x, arena); o.w[1] = pack2(p.x_ld, p.x_cols);
+      o.w[2] = off_of(p.wxT, wbase); o.w[3] = off_of(p.whT, wbase); o.w[4] = off_of(p.bias, wbase);
+      o.w[5] = off_of(p.wdT, wbase); o.w[6] = off_of(p.bd, wbase);
+      o.w[7] = off_of(p.h_in, arena); o.w[8] = off_of(p.c_in, arena);
+      o.w[9] = off_of(p.h_out, arena); o.w[10] = off_of(p.c_out, arena);
+      o.w[11] = off_of(p.dst, arena); o.w[12] = pack2(p.dst_ld, p.dst_cols);
+      o.w[13] = pack2(p.Din, p.Dout);
+      break;
+    }
+    case DEV_OP_CTFA: {
+      const CtfaParams& p = d.ctfa;
+      o.w[0] = off_of(p.x, arena); o.w[1] = off_of(p.e0, arena); o.w[2] = off_of(p.y, arena);
+      o.w[3] = pack4(p.x_ld, p.e0_ld, p.y_ld, 0);
+      o.w[4] = off_of(p.ta_w1T, wbase); o.w[5] = off_of(p.ta_b1, wbase); o.w[6] = off_of(p.ta_w2T, wbase); o.w[7] = off_of(p.ta_b2, wbase);
+      o.w[8] = off_of(p.fa_w1T, wbase); o.w[9] = off_of(p.fa_b1, wbase); o.w[10] = off_of(p.fa_w2T, wbase); o.w[11] = off_of(p.fa_b2, wbase);
+      o.w[12] = static_cast<uint32_t>(p.F);
+      break;
+    }
+    case DEV_OP_INLAYER: {
+      const InLayerParams& p = d.inl;
+      o.w[0] = off_of(p.y, arena);
+      o.w[1] = off_of(p.w, wbase); o.w[2] = off_of(p.b, wbase); o.w[3] = off_of(p.gamma, wbase); o.w[4] = off_of(p.beta, wbase);
+      o.w[5] = fbits(p.alpha);
+      break;
+    }
+    default: {
+      const OutConvParams& p = d.outc;
+      o.w[0] = off_of(p.x, arena); o.w[1] = static_cast<uint32_t>(p.x_ld);
+      o.w[2] = off_of(p.w, wbase); o.w[3] = fbits(p.bias);
+      break;
+    }
+  }
+  return o;
+}
+
 }  // namespace nutls
