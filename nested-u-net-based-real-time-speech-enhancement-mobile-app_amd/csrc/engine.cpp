@@ -596,11 +596,12 @@ static void plan_handoffs(const std::vector<Launch>& plan, std::vector<DevLaunch
   for (size_t i = 0; i < plan.size(); ++i) collect_writes(plan[i], static_cast<int>(i), &writes);
   const bool disabled = getenv("NUTLS_NO_HANDOFF") != nullptr;
   for (size_t i = 0; i + 1 < plan.size(); ++i) {
-    if (plan[i].kind != Launch::CONV || plan[i + 1].kind != Launch::CONV) continue;
+    if (plan[i + 1].kind != Launch::CONV || plan[i].kind == Launch::OUTCONV) continue;
     DevLaunch& L = (*dv)[i];
     DevLaunch& N = (*dv)[i + 1];
     const ConvParams& np = N.conv;
     const float* ncur = (N.cp.tt == 2) ? np.src1 : np.src0;
+    const bool lconv = plan[i].kind == Launch::CONV;
     bool ok = N.cp.merged && !disabled;
     int fwd_sel = 0, fwd_coff = 0, covered = 0;
     if (ok) {
@@ -611,7 +612,7 @@ static void plan_handoffs(const std::vector<Launch>& plan, std::vector<DevLaunch
         covered += w.nchan;
         if (w.launch > static_cast<int>(i)) ok = false;    // produced later than L (cannot happen, guard)
         if (w.launch == static_cast<int>(i)) {
-          const int sel = (w.ptr == L.conv.dst0) ? 1 : 2;
+          const int sel = (!lconv || w.ptr == L.conv.dst0) ? 1 : 2;
           if (fwd_sel && fwd_sel != sel) ok = false;
           fwd_sel = sel;
           fwd_coff = static_cast<int>(off);
@@ -619,12 +620,13 @@ static void plan_handoffs(const std::vector<Launch>& plan, std::vector<DevLaunch
       }
       // up-sampling writes alternate rows with two launches: each covers all channels once
       if (covered < N.cp.cin) ok = false;
-      if (fwd_sel) {
+      if (fwd_sel && lconv) {
         const int rows_l = L.conv.F_out * L.conv.row_mul;
         if (rows_l != np.F_in || (fwd_coff % 4)) ok = false;
       }
+      if (!lconv && !fwd_sel) ok = false;                  // a non-conv op only hands over what it feeds itself
     }
-    if (ok) {
+    if (ok && lconv) {
       L.cp.hand_next = 1;
       L.cp.fwd_sel = fwd_sel;
       L.cp.fwd_coff4 = fwd_coff / 4;
@@ -632,7 +634,11 @@ static void plan_handoffs(const std::vector<Launch>& plan, std::vector<DevLaunch
       L.cp.fwd_rmul = all_rows ? 1 : L.conv.row_mul;
       L.cp.fwd_radd = all_rows ? 0 : L.conv.row_add;
       N.cp.staged_by_prev = 1;
-    } else if (N.cp.tt == 2 && !N.cp.merged && !disabled) {
+    } else if (ok) {
+      L.nc_hand = 1;
+      L.nc_fwd_coff = fwd_coff;
+      N.cp.staged_by_prev = 1;
+    } else if (lconv && N.cp.tt == 2 && !N.cp.merged && !disabled) {
       // un-merged two-tap layer: round 0 is the previous-frame tap of chunk 0, which never depends on
       // this frame -> hand over that single phase
       L.cp.hand_next = 1;
@@ -666,6 +672,8 @@ static int upload_device_plans(Engine* e) {
           fprintf(stderr, "%-24s F %3d->%3d merged %d rounds %d RG %2d KS %2d gpk %2d tiles %2d | staged_by_prev %d pf0 %d hand %d fwd %d@%d r%%%d==%d pre0 %d\n",
                   e->plan[par][i].name.c_str(), dv[i].conv.F_in, dv[i].conv.F_out, c.merged, c.rounds, c.RG, c.KS, c.gpk, c.tiles,
                   c.staged_by_prev, c.pf_phase0_ready, c.hand_next, c.fwd_sel, c.fwd_coff4, c.fwd_rmul, c.fwd_radd, c.pre_next_phase0);
+        } else {
+          fprintf(stderr, "%-24s (op %d) nc_hand %d fwd_coff %d\n", e->plan[par][i].name.c_str(), dv[i].op, dv[i].nc_hand, dv[i].nc_fwd_coff);
         }
     }
     if (dv.size() > static_cast<size_t>(MK_MAX_OPS)) return fail(NUTLS_ERR_ARG, "plan too long for the LDS-resident form");

@@ -42,6 +42,23 @@ __device__ __forceinline__ g4_t G4W(float* p) { return (g4_t)(unsigned long long
 __device__ __forceinline__ gcf_t GF(const float* p) { return (gcf_t)(unsigned long long)p; }
 __device__ __forceinline__ gf_t GFW(float* p) { return (gf_t)(unsigned long long)p; }
 
+// Wave-uniform base (SGPR pair) + 32-bit unsigned float offset (VGPR): lowers to the
+// "global_load v, v_off, s[base]" addressing form -- no 64-bit VALU address arithmetic.
+typedef const char __attribute__((address_space(1))) * gcb_t;
+typedef char __attribute__((address_space(1))) * gb_t;
+__device__ __forceinline__ f32x4 ld4(const float* ubase, unsigned foff) {
+  return *(gc4_t)((gcb_t)(unsigned long long)ubase + static_cast<unsigned long long>(foff * 4u));
+}
+__device__ __forceinline__ float ld1(const float* ubase, unsigned foff) {
+  return *(gcf_t)((gcb_t)(unsigned long long)ubase + static_cast<unsigned long long>(foff * 4u));
+}
+__device__ __forceinline__ void st4(float* ubase, unsigned foff, f32x4 v) {
+  *(g4_t)((gb_t)(unsigned long long)ubase + static_cast<unsigned long long>(foff * 4u)) = v;
+}
+__device__ __forceinline__ void st1(float* ubase, unsigned foff, float v) {
+  *(gf_t)((gb_t)(unsigned long long)ubase + static_cast<unsigned long long>(foff * 4u)) = v;
+}
+
 #define MK_LN_EPS 1e-8f
 constexpr int MK_WAVES = MK_NWAVES;           // 8 waves = 2 per SIMD: 256 VGPRs per lane, half the per-layer bookkeeping of 16
 constexpr int MK_THREADS = 64 * MK_WAVES;
@@ -159,8 +176,12 @@ __device__ __forceinline__ bool is_fwd(const FwdWin& f, const ItemAddr& a) {
 
 __device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& c, int stream, int ph0, int nphases, int tid,
                                            f32x4 (&pf)[MK_MAXPF]) {
-  const float* s0 = p.src0 + static_cast<size_t>(stream) * p.sstride;
-  const float* s1 = p.src1 ? p.src1 + static_cast<size_t>(stream) * p.sstride : s0;
+  // both time taps live in the same stream slice: one uniform base, the tap picks a 32-bit offset
+  const float* lo = (p.src1 && p.src1 < p.src0) ? p.src1 : p.src0;
+  const float* s0 = lo + static_cast<size_t>(stream) * p.sstride;
+  const unsigned tap0 = static_cast<unsigned>(p.src0 - lo);
+  const unsigned tap1 = p.src1 ? static_cast<unsigned>(p.src1 - lo) : tap0;
+  const unsigned ld = static_cast<unsigned>(p.src_ld);
   const int n = nphases << c.n4p_shift;
   const int wave_q0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
 #pragma unroll
@@ -171,8 +192,8 @@ __device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& 
       int q = tid + i * MK_THREADS;
       q = q < n ? q : n - 1;
       const ItemAddr a = item_of(c, q + (ph0 << c.n4p_shift));
-      const float* src = ((a.ph >> c.nch_shift) == 1) ? s1 : s0;
-      pf[i] = *G4(src + static_cast<size_t>(a.row) * p.src_ld + 4 * a.chan4);
+      const unsigned off = ((a.ph >> c.nch_shift) == 1 ? tap1 : tap0) + static_cast<unsigned>(a.row) * ld + 4u * static_cast<unsigned>(a.chan4);
+      pf[i] = ld4(s0, off);
     }
   }
 }
@@ -197,9 +218,24 @@ __device__ __forceinline__ void image_store(const ConvPlan& c, float* lds_in, in
     const int hr_all = tid >> c.cc4_shift;
     const int phl = hr_all / hrows, hr = hr_all - phl * hrows;
     const int lr = hr < c.padl ? hr : c.vrows + hr;         // top halo rows first, then the bottom ones
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    // (a zero the compiler cannot hoist out of the layer loop -- it would spill it, and a scratch
+    //  reload costs a vmcnt(0) wait right here)
+    float zf = 0.f;
+    asm volatile("" : "+v"(zf));
+    const f32x4 z = {zf, zf, zf, zf};
     *reinterpret_cast<f32x4*>(lds_in + (ph0 - ph_base + phl) * c.phase_floats + img_addr(c, lr, c4)) = z;
   }
+}
+
+// Direct writes into the NEXT layer's LDS image (current-frame tap): a float4 column / a single channel of row `row`
+__device__ __forceinline__ void img_put4(const ConvPlan& n, float* lds_in, int row, int chan4, f32x4 v) {
+  const int ph = ((n.tt - 1) << n.nch_shift) + (chan4 >> n.cc4_shift);
+  *reinterpret_cast<f32x4*>(lds_in + ph * n.phase_floats + img_addr(n, n.padl + row, chan4 & ((1 << n.cc4_shift) - 1))) = v;
+}
+__device__ __forceinline__ void img_put1(const ConvPlan& n, float* lds_in, int row, int chan, float v) {
+  const int chan4 = chan >> 2;
+  const int ph = ((n.tt - 1) << n.nch_shift) + (chan4 >> n.cc4_shift);
+  lds_in[ph * n.phase_floats + img_addr(n, n.padl + row, chan4 & ((1 << n.cc4_shift) - 1)) + (chan & 3)] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -213,8 +249,18 @@ struct WeightCursor {   // wave-uniform
 };
 
 __device__ __forceinline__ void load_chunk(f32x4 (&w)[4], gc4_t ptr, int wstep, int lane) {
+  // ptr is wave-uniform; the per-lane part is a 32-bit byte offset
 #pragma unroll
-  for (int u = 0; u < 4; ++u) w[u] = ptr[u * wstep + lane];
+  for (int u = 0; u < 4; ++u)
+    w[u] = *(gc4_t)((gcb_t)ptr + static_cast<unsigned long long>(static_cast<unsigned>(u * wstep + lane) * 16u));
+}
+
+// first weight chunk of the next conv layer for this wave's task (single static load site per op kind)
+__device__ __forceinline__ void load_next_weights(const ConvParams& np, const ConvPlan& ncp, int wave, int lane, f32x4 (&wnext)[4]) {
+  const bool nact = wave < ncp.tasks * ncp.KS;
+  const int nks = nact ? (wave >> ncp.tasks_shift) : 0;
+  const int nnt = nact ? (wave & (ncp.nt - 1)) : 0;
+  load_chunk(wnext, (gc4_t)(unsigned long long)np.wpk + (static_cast<size_t>(nks * ncp.gpk) * ncp.nt + nnt) * 64, ncp.nt * 64, lane);
 }
 
 // cursor over the resident image for one task: (local phase, frequency tap, channel group), wave-uniform
@@ -321,8 +367,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPla
       }
     }
     const int row = pos * p.row_mul + p.row_add + gi;
-    *G4W(d0 + static_cast<size_t>(row) * p.ld0 + 4 * li) = v;
-    if (d1) *G4W(d1 + static_cast<size_t>(row) * p.ld1 + 4 * li) = v;
+    st4(d0, static_cast<unsigned>(row * p.ld0 + 4 * li), v);
+    if (d1) st4(d1, static_cast<unsigned>(row * p.ld1 + 4 * li), v);
     if (do_fwd) *reinterpret_cast<f32x4*>(lds_next + f_ph * nx.phase_floats + img_addr(nx, nx.padl + row, f_c4)) = v;
   }
 }
@@ -471,85 +517,95 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// LSTM cell + Dense for one stream (models/proposed.py:70-119; converter_proposed.py:234-237):
-// 4 K-slices x 128 gate slots, reduced through LDS.  Weight loads are issued ahead of the barriers
-// that separate the stages so only one memory latency is exposed per stage.
-__device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, float* lds, int tid) {
-  float* v = lds;              // [256]
-  float* hs = lds + 256;       // [32]
-  float* part = lds + 288;     // [4][84]
-  float* z = lds + 288 + 8 * 84;   // [96]
-  float* hn = z + 96;          // [32]
-  const int n = tid & 127, sl = tid >> 7;
-  const int kn = p.Din >> 2, k0 = sl * kn;       // kn in {8, 16, 32, 64}
-  float w[8];
-  if (n < 84) {
+// LSTM cell + Dense for one stream (models/proposed.py:70-119; converter_proposed.py:234-237).
+// Thread (n4, sl): gate outputs 4*n4..4*n4+3 (84 = 21 float4) x K slice sl of 16; every global load of
+// the op (input, weights of all three products, states, and the next conv layer's image rows) is issued
+// before the first barrier, so one memory latency is exposed.  When `hand`, the op also completes the
+// next conv layer's LDS image: its own output is written straight into it.
+__device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, float* lds, float* lds_in, int tid, bool hand, int fwd_coff,
+                                           const ConvParams& np, const ConvPlan& ncp) {
+  float* part = lds;               // [16][84]
+  float* z = lds + 16 * 84;        // [96]
+  float* hn = z + 96;              // [32]
+  const float* sb = p.x + static_cast<size_t>(stream) * p.sstride;         // stream slice of the input tensor
+  const int n4 = tid % 21, sl = tid / 21;                                    // sl < 16 for tid < 336
+  const int kn = p.Din >> 4, k0 = sl * kn;                                   // kn in {2, 4, 8, 16}
+  const bool mv = tid < 336;
+  // ---- x . Wx: weights + inputs of this thread's K slice
+  f32x4 w4[16];
+  float xv[16];
+  if (mv) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = (k < kn) ? GF(p.wxT)[(k0 + k) * 84 + n] : 0.f;
+    for (int j = 0; j < 16; ++j)
+      if (j < kn) {
+        const int k = k0 + j;
+        w4[j] = ld4(p.wxT, static_cast<unsigned>(k * 84 + 4 * n4));
+        const int f = k / p.x_cols, c = k - f * p.x_cols;
+        xv[j] = ld1(sb, static_cast<unsigned>(f * p.x_ld + c));
+      }
   }
-  for (int k = tid; k < p.Din; k += MK_THREADS) {
-    const int f = k / p.x_cols, c = k - f * p.x_cols;
-    v[k] = GF(p.x)[static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(f) * p.x_ld + c];
-  }
-  float c_old = 0.f;
-  if (tid < 21) {
-    hs[tid] = GF(p.h_in)[static_cast<size_t>(stream) * p.sstride + tid];
-    c_old = GF(p.c_in)[static_cast<size_t>(stream) * p.sstride + tid];
-  }
-  __syncthreads();
-  if (n < 84) {
-    float a = 0.f;
-#pragma unroll 1
-    for (int kb = 0; kb < kn; kb += 8) {
-      float wn[8];
+  // ---- recurrent product, bias, cell state, dense weights (threads < 84 / < 21 / < Dout)
+  float wh[21], hprev[21];
+  float bias = 0.f, c_old = 0.f;
+  if (tid < 84) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) wn[k] = (kb + 8 + k < kn) ? GF(p.wxT)[(k0 + kb + 8 + k) * 84 + n] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (kb + k < kn) a = fmaf(w[k], v[k0 + kb + k], a);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) w[k] = wn[k];
+    for (int u = 0; u < 21; ++u) {
+      wh[u] = ld1(p.whT, static_cast<unsigned>(u * 84 + tid));
+      hprev[u] = ld1(p.h_in + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(u));
     }
-    part[sl * 84 + n] = a;
+    bias = ld1(p.bias, static_cast<unsigned>(tid));
   }
-  float bias = 0.f, r = 0.f;
-  if (tid < 84) {
-    bias = GF(p.bias)[tid];
-#pragma unroll
-    for (int u = 0; u < 21; ++u) r = fmaf(GF(p.whT)[u * 84 + tid], hs[u], r);
-  }
-  __syncthreads();
-  if (tid < 84) {
-    float a = bias;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a += part[s * 84 + tid];
-    z[tid] = a + r;
-  }
-  // dense weights for the output row this thread owns (Dout <= 256 -> one row per thread)
+  if (tid < 21) c_old = ld1(p.c_in + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(tid));
   float wd[21];
   float bd = 0.f;
   if (tid < p.Dout) {
 #pragma unroll
-    for (int u = 0; u < 21; ++u) wd[u] = GF(p.wdT)[u * p.Dout + tid];
-    bd = GF(p.bd)[tid];
+    for (int u = 0; u < 21; ++u) wd[u] = ld1(p.wdT, static_cast<unsigned>(u * p.Dout + tid));
+    bd = ld1(p.bd, static_cast<unsigned>(tid));
   }
-  __syncthreads();
+  // ---- next conv layer's image rows this op does not produce
+  f32x4 pfx[MK_MAXPF];
+  if (hand) image_load(np, ncp, stream, 0, ncp.nph, tid, pfx);
+
+  if (mv) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < kn) a += w4[j] * xv[j];
+    *reinterpret_cast<f32x4*>(part + sl * 84 + 4 * n4) = a;
+  }
+  lds_barrier();
+  if (tid < 84) {
+    float a = bias;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) a += part[s2 * 84 + tid];
+    float r = 0.f;
+#pragma unroll
+    for (int u = 0; u < 21; ++u) r = fmaf(wh[u], hprev[u], r);
+    z[tid] = a + r;
+  }
+  lds_barrier();
   if (tid < 21) {
     const float gi = mk_sigmoid(z[tid]), gf = mk_sigmoid(z[21 + tid]);
     const float gg = tanhf(z[42 + tid]), go = mk_sigmoid(z[63 + tid]);
     const float c_new = gf * c_old + gi * gg;
     const float h_new = go * tanhf(c_new);
-    GFW(p.c_out)[static_cast<size_t>(stream) * p.sstride + tid] = c_new;
-    GFW(p.h_out)[static_cast<size_t>(stream) * p.sstride + tid] = h_new;
+    st1(p.c_out + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(tid), c_new);
+    st1(p.h_out + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(tid), h_new);
     hn[tid] = h_new;
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < p.Dout) {
     float a = bd;
 #pragma unroll
     for (int u = 0; u < 21; ++u) a = fmaf(wd[u], hn[u], a);
     const int f = tid / p.dst_cols, c = tid - f * p.dst_cols;
-    GFW(p.dst)[static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(f) * p.dst_ld + c] = a;
+    st1(p.dst + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(f * p.dst_ld + c), a);
+    if (hand) img_put1(ncp, lds_in, f, fwd_coff + c, a);
+  }
+  if (hand) {
+    const FwdWin fw = {fwd_coff >> 2, (fwd_coff + p.dst_cols) >> 2, 1, 0};
+    image_store(ncp, lds_in, 0, ncp.nph, 0, fw, tid, pfx);
   }
   __syncthreads();
 }
@@ -557,7 +613,10 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
 // CTFA gate + residual for one stream (ctfa_rt, models/proposed.py:162-196).
 // Wave u computes hidden unit u of the 64->16 layers (one product per lane + wave reduction);
 // the MLP weights are fetched before the mean-over-F reduction so their latency is hidden.
-__device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, float* lds, int tid) {
+__device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, float* lds, float* lds_in, int tid, bool hand, int fwd_coff,
+                                           const ConvParams& np, const ConvPlan& ncp) {
+  f32x4 pfx[MK_MAXPF];
+  if (hand) image_load(np, ncp, stream, 0, ncp.nph, tid, pfx);
   float* part = lds;               // [32][64]
   float* m = lds + 4096;           // [64]
   float* hid = m + 64;             // [16]
@@ -584,19 +643,19 @@ __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, floa
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int f = rg; f < p.F; f += 32) s += *G4(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
   *reinterpret_cast<f32x4*>(part + rg * 64 + 4 * c4) = s;
-  __syncthreads();
+  lds_barrier();
   if (tid < 64) {
     float a = 0.f;
 #pragma unroll 16
     for (int r = 0; r < 32; ++r) a += part[r * 64 + tid];
     m[tid] = a / static_cast<float>(p.F);
   }
-  __syncthreads();
+  lds_barrier();
   {
     const float t0 = wave_sum(w1_ta0 * m[lane]), t1 = wave_sum(w1_ta1 * m[lane]);
     if (lane == 0) { hid[wave] = fmaxf(t0 + b1_ta0, 0.f); hid[wave + 8] = fmaxf(t1 + b1_ta1, 0.f); }
   }
-  __syncthreads();
+  lds_barrier();
   float ta_c = 0.f;
   if (tid < 64) {
     float a = b2_ta;
@@ -605,33 +664,40 @@ __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, floa
     ta_c = mk_sigmoid(a);
     ta[tid] = ta_c;
   }
-  __syncthreads();
+  lds_barrier();
   {
     const float tv = ta[lane] * (1.0f / 32.0f);
     const float t0 = wave_sum(w1_fa0 * tv), t1 = wave_sum(w1_fa1 * tv);
-    __syncthreads();             // everyone has read hid (TA pass) before it is overwritten
+    lds_barrier();             // everyone has read hid (TA pass) before it is overwritten
     if (lane == 0) { hid[wave] = fmaxf(t0 + b1_fa0, 0.f); hid[wave + 8] = fmaxf(t1 + b1_fa1, 0.f); }
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < 64) {
     float a = b2_fa;
 #pragma unroll
     for (int u = 0; u < 16; ++u) a = fmaf(w2_fa[u], hid[u], a);
     gate[tid] = mk_sigmoid(a) * ta_c;
   }
-  __syncthreads();
+  lds_barrier();
   const f32x4 g4 = *reinterpret_cast<const f32x4*>(gate + 4 * c4);
   const float* eb = p.e0 + static_cast<size_t>(stream) * p.sstride;
   float* yb = p.y + static_cast<size_t>(stream) * p.sstride;
   for (int f = rg; f < p.F; f += 32) {
     const f32x4 xv = *G4(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
     const f32x4 ev = *G4(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
-    *G4W(yb + static_cast<size_t>(f) * p.y_ld + 4 * c4) = xv * g4 + ev;
+    const f32x4 yv = xv * g4 + ev;
+    *G4W(yb + static_cast<size_t>(f) * p.y_ld + 4 * c4) = yv;
+    if (hand) img_put4(ncp, lds_in, f, (fwd_coff >> 2) + c4, yv);
+  }
+  if (hand) {
+    const FwdWin fw = {fwd_coff >> 2, (fwd_coff >> 2) + 16, 1, 0};
+    image_store(ncp, lds_in, 0, ncp.nph, 0, fw, tid, pfx);
   }
   __syncthreads();
 }
 
-__device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs& a, int stream, int tid) {
+__device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs& a, int stream, float* lds_in, int tid, bool hand,
+                                               const ConvPlan& ncp) {
   InLayerParams p;
   p.x = a.io_in; p.y = aptr(a.arena, o.w[0]);
   p.w = wptr(a.wbase, o.w[1]); p.b = wptr(a.wbase, o.w[2]); p.gamma = wptr(a.wbase, o.w[3]); p.beta = wptr(a.wbase, o.w[4]);
@@ -659,6 +725,7 @@ __device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs&
       o4[i] = t >= 0.f ? t : p.alpha * t;
     }
     *G4W(p.y + static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(pos) * 64 + 4 * c4) = o4;
+    if (hand) img_put4(ncp, lds_in, pos, c4, o4);     // the whole image of msfe6_en_in is this op's output
   }
   __syncthreads();
 }
@@ -699,51 +766,52 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
   // kernel means "wait for every prefetch in flight".
   auto fresh_tid = []() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
   for (int stream = blockIdx.x; stream < a.B; stream += gridDim.x) {
-    int i = 0;
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[n_ops * 9 + 1] = clock64();
+    // the first weight chunk of the next conv layer travels in registers from op to op
+    f32x4 wnext[4];
+    bool have_w = false;
+    OpWords cur = load_op(lds_plan, 0);
 #pragma unroll 1
-    while (i < n_ops) {
-      const OpWords o = load_op(lds_plan, i);
-      const int op = static_cast<int>(o.w[23]);
+    for (int i = 0; i < n_ops; ++i) {
+      const int tid = fresh_tid();
+      const int lane = tid & 63;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
+      const OpWords nxt = load_op(lds_plan, i + 1 < n_ops ? i + 1 : i);
+      const bool nconv = (i + 1 < n_ops) && static_cast<int>(nxt.w[23]) == DEV_OP_CONV;
+      ConvParams np;
+      ConvPlan ncp;
+      decode_conv(nxt, a, np, ncp);
+      const int op = static_cast<int>(cur.w[23]);
+      const bool nc_hand = nconv && b0(cur.w[22]) != 0;      // non-conv op -> conv hand-off
+      const int nc_coff = b1(cur.w[22]);
       if (op == DEV_OP_CONV) {
-        // a run of consecutive conv layers: the first weight chunk of the next layer lives in registers
-        f32x4 wnext[4];
-        bool have_w = false;
-        OpWords cur = o;
-#pragma unroll 1
-        while (true) {
-          const int tid = fresh_tid();
-          if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
-          unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
-          const OpWords nxt = load_op(lds_plan, i + 1 < n_ops ? i + 1 : i);
-          const bool nconv = (i + 1 < n_ops) && static_cast<int>(nxt.w[23]) == DEV_OP_CONV;
-          ConvParams p, np;
-          ConvPlan c, ncp;
-          decode_conv(cur, a, p, c);
-          decode_conv(nxt, a, np, ncp);
-          conv_layer(p, c, nconv, np, ncp, stream, lds_in, lds_out, tid, wnext, have_w, sub);
-          ++i;
-          if (!nconv) break;
-          cur = nxt;
-        }
+        unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
+        ConvParams p;
+        ConvPlan c;
+        decode_conv(cur, a, p, c);
+        conv_layer(p, c, nconv, np, ncp, stream, lds_in, lds_out, tid, wnext, have_w, sub);
       } else {
-        const int tid = fresh_tid();
-        if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
         if (op == DEV_OP_LSTM) {
           LstmParams p;
-          decode_lstm(o, a, p);
-          lstm_layer(p, stream, lds_out, tid);
+          decode_lstm(cur, a, p);
+          lstm_layer(p, stream, lds_out, lds_in, tid, nc_hand, nc_coff, np, ncp);
         } else if (op == DEV_OP_CTFA) {
           CtfaParams p;
-          decode_ctfa(o, a, p);
-          ctfa_layer(p, stream, lds_out, tid);
+          decode_ctfa(cur, a, p);
+          ctfa_layer(p, stream, lds_out, lds_in, tid, nc_hand, nc_coff, np, ncp);
         } else if (op == DEV_OP_INLAYER) {
-          input_layer_op(o, a, stream, tid);
+          input_layer_op(cur, a, stream, lds_in, tid, nc_hand, ncp);
         } else {
-          out_conv_op(o, a, stream, tid);
+          out_conv_op(cur, a, stream, tid);
         }
-        ++i;
+        have_w = false;
+        if (nconv) {
+          load_next_weights(np, ncp, wave, lane, wnext);
+          have_w = true;
+        }
       }
+      cur = nxt;
     }
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) { prof[n_ops] = wall_clock64(); prof[n_ops * 9 + 2] = clock64(); }
   }

@@ -155,6 +155,9 @@ struct DevLaunch {
     OutConvParams outc;
   };
   ConvPlan cp;   // valid when op == DEV_OP_CONV
+  // hand-off of a NON-conv op (LSTM / CTFA / input layer) to the conv layer that follows it
+  int nc_hand;       // 1: this op completes the next conv layer's LDS image
+  int nc_fwd_coff;   // channel offset (floats) of this op's output inside the next layer's input row
 };
 constexpr int MK_LDS_IN_FLOATS = 17920;   // staged input: >= 256 rows x 68, 129 row pairs x 132, 2 x 130 rows x 68
 constexpr int MK_STAGE_ITEMS = 4096;      // float4 a merged layer may stage through registers (8 per thread)

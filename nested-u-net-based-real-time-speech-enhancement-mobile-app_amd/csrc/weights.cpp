@@ -129,14 +129,12 @@ ConvPlan make_conv_plan(ConvKind k, const ConvParams& p) {
   c.tw = c.tiles > MK_NWAVES ? 2 : 1;                 // 16-tile layers: two position tiles per wave
   c.tasks = c.tiles / c.tw;
   c.tasks_shift = ilog2_exact(c.tasks);
-  // K split: the largest slice count that keeps <= 8 wave tasks, whole 4-group chunks per slice, and
-  // slices that are either one chunk or whole frequency-tap segments
+  // K split: the largest slice count that keeps <= 8 wave tasks with whole 4-group chunks per slice
   int best = 1;
   for (int ks = 1; ks <= MK_NWAVES / c.tasks; ++ks) {
     if (c.RG % ks) continue;
     const int gpk = c.RG / ks;
-    if (gpk % 4) continue;
-    if (!(gpk % c.gpc == 0 || c.gpc % gpk == 0)) continue;
+    if (gpk % 4) continue;      // whole 4-group chunks; chunks never straddle a frequency-tap segment (gpc is 4 or 8)
     best = ks;
   }
   c.KS = best;
@@ -162,6 +160,7 @@ static uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) {
   CompactOp o{};
   o.w[23] = static_cast<uint32_t>(d.op);
+  o.w[22] = pack4(d.nc_hand, d.nc_fwd_coff, 0, 0);     // non-conv ops: hand-off to the following conv layer
   switch (d.op) {
     case DEV_OP_CONV: {
       const ConvParams& p = d.conv;
