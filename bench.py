@@ -148,9 +148,15 @@ def main():
             torch.cuda.synchronize()
             avg_ms = ev[0].elapsed_time(ev[1]) / args.steps
             achieved = step_flops / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):           # HBM bytes per launch from the committed rocprofv3 PMC passes
+                t = json.load(open(tpath))
+                if t.get("batch") == B and t.get("mode") == args.mode:
+                    traffic = t["traffic_bytes"]
             roofline = {"kernel": "nutls_stream_step_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": None, "launches_per_step": 1, "avg_launch_ms": round(avg_ms, 5),
+                        "traffic": traffic, "launches_per_step": 1, "avg_launch_ms": round(avg_ms, 5),
                         "flops_per_launch": step_flops}
             # in-kernel timeline of workgroup 0 (wall clock stamps at every layer boundary)
             reps = 10

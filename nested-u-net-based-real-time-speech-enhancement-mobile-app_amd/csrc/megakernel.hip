@@ -267,11 +267,13 @@ __device__ __forceinline__ void load_next_weights(const ConvParams& np, const Co
 struct KCursor { int phl, kf, gg; };
 
 __device__ __forceinline__ KCursor kcursor_init(const ConvPlan& c, int ks) {
+  // (no integer divisions: gpc is 4 or 8, kf is 1, 2 or 3, seg < 64)
   const int g_first = ks * c.gpk;
-  const int seg = g_first / c.gpc;
+  const int gshift = c.gpc == 8 ? 3 : 2;
+  const int seg = g_first >> gshift;
   KCursor k;
-  k.gg = g_first - seg * c.gpc;
-  k.phl = seg / c.kf;
+  k.gg = g_first & (c.gpc - 1);
+  k.phl = c.kf == 3 ? ((seg * 43) >> 7) : (c.kf == 2 ? (seg >> 1) : seg);
   k.kf = seg - k.phl * c.kf;
   return k;
 }
