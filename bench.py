@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
     ap.add_argument("--mode", default="persistent", choices=["persistent", "graph", "launches"])
+    ap.add_argument("--variant", default="lstm", choices=["lstm", "baseline"],
+                    help="baseline = dilated-dense bottleneck with synthetic weights, seed 4321 (BASELINE configs[2])")
+    ap.add_argument("--host-io", action="store_true",
+                    help="streaming serving (BASELINE configs[4]): one step per host call, host buffers in/out (H2D + D2H timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default="", help="write the per-launch HIP-event timeline here")
     args = ap.parse_args()
@@ -103,7 +107,11 @@ def main():
     from nunet_amd.sharding import reduce_throughput
 
     B = args.batch
-    eng = nunet_amd.NutlsEngine(batch=B, device=local_rank, mode=args.mode)
+    weights = None
+    if args.variant == "baseline":
+        from nunet_amd.weights import synthetic_weights, write_blob
+        weights = write_blob(synthetic_weights("baseline", seed=4321))
+    eng = nunet_amd.NutlsEngine(weights, batch=B, device=local_rank, mode=args.mode, variant=args.variant)
     pool_host = synthetic_pool(B, 8, 1234 + rank)
     pool = torch.from_numpy(pool_host).cuda()            # inputs resident in HBM
     out = torch.empty(B, 256, device="cuda")
@@ -115,19 +123,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_step(s):
+        if args.host_io:
+            return eng.step(pool_host[s % 8])            # numpy in / numpy out: H2D + step + D2H, synchronous
+        return eng.step(pool[s % 8], out)
+
     for s in range(args.warmup):
-        eng.step(pool[s % 8], out)
+        one_step(s)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        eng.step(pool[s % 8], out)
+        one_step(s)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
     frames = B * args.steps
     total_frames, max_elapsed = reduce_throughput(frames, elapsed, dist if world > 1 else None,
                                                   torch.device("cuda", local_rank))
-    assert bool(torch.isfinite(out).all())
+    assert args.host_io or bool(torch.isfinite(out).all())
 
     if rank == 0:
         import re
@@ -202,12 +215,16 @@ def main():
                            "families": fam, "timeline_step_ms": float(ms.sum())}, f, indent=1)
         value = total_frames / max_elapsed
         line = {
-            "metric": "STFT frames/sec (512-pt, 50% hop) through the NUNet-TLS-LSTM frame step",
+            "metric": "STFT frames/sec (512-pt, 50% hop) through the NUNet-TLS frame step",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * max_elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic magnitudes 0.25*|N(0,1)|, trained weights de-quantised from the reference's nutls_lstm.tflite",
-            "config": {"workload": "NUNet-TLS-LSTM (proposed) frame step, batch=%d streams per GPU, 256-bin frames (BASELINE configs[1])" % B,
+            "data": "synthetic magnitudes 0.25*|N(0,1)|, " + ("trained weights de-quantised from the reference's nutls_lstm.tflite"
+                                                                 if args.variant == "lstm" else "synthetic weights (no trained baseline weights exist)"),
+            "config": {"workload": ("NUNet-TLS-LSTM (proposed) frame step, batch=%d streams per GPU, 256-bin frames (BASELINE configs[1])" % B)
+                       if args.variant == "lstm" else
+                       ("NUNet-TLS dilated-dense baseline frame step, synthetic weights seed 4321, batch=%d streams per GPU (BASELINE configs[2])" % B),
+                       "variant": args.variant, "host_io": bool(args.host_io),
                        "streams_per_gpu": B, "total_streams": B * world, "parallelism": "stream-sharded x%d" % world,
                        "mode": args.mode, "layers_per_step": len(plan)},
             "rtf_per_stream": round(1e3 * max_elapsed / args.steps / 16.0, 5),
@@ -216,7 +233,10 @@ def main():
             "roofline": roofline,
             "encoder_conv_stack": encoder_stack,
         }
-        if not args.no_cpu_baseline:
+        if args.host_io:
+            line["step_latency_ms"] = line["ms_per_step"]
+            line["real_time_budget_ms"] = 16.0
+        if not args.no_cpu_baseline and args.variant == "lstm":
             line["cpu_baseline"] = cpu_baseline()
             line["parity_rms_vs_oracle"] = parity_check(nunet_amd.NutlsEngine, pool_host)
         print(json.dumps(line))

@@ -42,7 +42,9 @@ enum {
 };
 
 enum {
-  NUTLS_VARIANT_LSTM = 0   /* NUNet-TLS-LSTM, "proposed" (models/proposed.py) */
+  NUTLS_VARIANT_LSTM = 0,     /* NUNet-TLS-LSTM, "proposed" (models/proposed.py; signature 'nutls_lstm_sm', 130 states) */
+  NUTLS_VARIANT_BASELINE = 1  /* NUNet-TLS with the dilated-dense bottleneck (models/nunet_tls.py; signature 'nutls'
+                               * of converter_nunet_tls.py:1542, 208 states).  No trained weights exist for it. */
 };
 
 #define NUTLS_BINS 256        /* network bins per frame (DC dropped, interpreter_proposed.py:212-213) */

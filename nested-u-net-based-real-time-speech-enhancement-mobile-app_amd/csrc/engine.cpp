@@ -61,19 +61,22 @@ static int decoder_of_encoder(int enc) { return 5 - enc; }
 
 struct StateTensor {
   std::string name_prev, name_cur;
-  int d0, d1;        // per-stream dims: (F, C) for conv states, (21, 1) for LSTM states
-  float* buf[2];     // ping-pong, each [B, d0, d1]
+  int d0, d1;        // per-stream dims: (F, C) for conv states, (21, 1) for LSTM states, (d*F, k*G) for ring states
+  float* buf[2];     // ping-pong, each [B, d0, d1]; ring / in-place states: buf[0] == buf[1]
+  int ring_d = 0;    // > 0: dilated-dense history ring of ring_d frames (physical slot = (step + j) mod d)
   size_t per_stream() const { return static_cast<size_t>(d0) * d1; }
 };
 
 struct Launch {
-  enum Kind { CONV, LSTM, CTFA, INLAYER, OUTCONV } kind;
+  enum Kind { CONV, LSTM, CTFA, INLAYER, OUTCONV, DDB } kind;
   ConvKind ck;
   ConvParams conv;
   LstmParams lstm;
   CtfaParams ctfa;
   InLayerParams inl;
   OutConvParams outc;
+  DdbParams ddb;
+  int ddb_index = -1;
   std::string name;
   bool encoder_strided = false;   // one of the 26 encoder (2,3) stride-2 convs (the "encoder conv stack")
 };
@@ -90,6 +93,15 @@ struct CtfaW { float *w1T, *b1, *w2T, *b2; };
 
 struct Engine {
   int B = 0, device = 0;
+  int variant = 0;               // NUTLS_VARIANT_LSTM / NUTLS_VARIANT_BASELINE
+  long long steps = 0;           // frames processed (ring position of the baseline's dilated-dense history)
+  int* d_step = nullptr;         // the same counter on the device
+  std::vector<DdbParams> ddbs;   // baseline: the 13 dilated-dense blocks (host copy, per parity identical)
+  DdbParams* d_ddb = nullptr;
+  struct DdbStates { int in, blk[6], out; };
+  DdbStates ddb_st[13];
+  struct DdbW { float *w_in, *b_in, *wg[6], *bg[6], *w1[6], *b1[6], *gamma[6], *beta[6], *w_out, *b_out; float a_in, a_out, alpha[6]; };
+  DdbW ddbw[13];
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
   float* warena = nullptr;       // all weights, one allocation
@@ -167,6 +179,8 @@ static int arena_commit(Engine* e) {
   e->arena = static_cast<float*>(p);
   for (float** f : e->arena_fixups) *f = e->arena + reinterpret_cast<size_t>(*f) / sizeof(float);
   e->arena_fixups.clear();
+  for (StateTensor& st : e->states)
+    if (st.ring_d > 0) st.buf[1] = st.buf[0];
   return NUTLS_OK;
 }
 
@@ -268,6 +282,61 @@ static std::vector<int> perm_shuffle128() {
   return p;
 }
 
+// [O][2][3][I] (OHWI) -> [t][kw][i][o]: the output channel becomes the fastest index
+static std::vector<float> ohwi_to_tkio(const HostTensor& w) {
+  const int O = w.dims[0], T = w.dims[1], K = w.dims[2], I = w.dims[3];
+  std::vector<float> o(w.data.size());
+  for (int oc = 0; oc < O; ++oc)
+    for (int t = 0; t < T; ++t)
+      for (int k = 0; k < K; ++k)
+        for (int i = 0; i < I; ++i) o[((static_cast<size_t>(t) * K + k) * I + i) * O + oc] = w.data[((static_cast<size_t>(oc) * T + t) * K + k) * I + i];
+  return o;
+}
+
+static int prep_ddb_weights(Engine* e, const WeightMap& wm) {
+  std::string err;
+  int rc;
+  for (int b = 0; b < 13; ++b) {
+    const bool central = b == 6;
+    const std::string tag = central ? "ddb" : std::string((b < 6 ? kEncoder[b] : kDecoder[b - 7]).prefix) + "_ddb";
+    Engine::DdbW& W = e->ddbw[b];
+    auto conv_prelu = [&](const std::string& n, float** w, float** bias, float* alpha) -> int {
+      const HostTensor* tw = find(wm, n + ".w", &err);
+      const HostTensor* tb = find(wm, n + ".b", &err);
+      const HostTensor* ta = find(wm, n + ".alpha", &err);
+      if (!tw || !tb || !ta || tw->dims.size() != 4) return fail(NUTLS_ERR_WEIGHTS, err.empty() ? "bad ddb conv " + n : err);
+      int r;
+      if ((r = upload(e, ohwi_to_tkio(*tw), w))) return r;
+      if ((r = upload(e, tb->data, bias))) return r;
+      *alpha = ta->data[0];
+      return NUTLS_OK;
+    };
+    if ((rc = conv_prelu(tag + "_in", &W.w_in, &W.b_in, &W.a_in))) return rc;
+    if ((rc = conv_prelu(tag + "_out", &W.w_out, &W.b_out, &W.a_out))) return rc;
+    for (int k = 1; k <= 6; ++k) {
+      const std::string n = tag + "_" + std::to_string(k);
+      const HostTensor* wg = find(wm, n + ".wg", &err);
+      const HostTensor* bg = find(wm, n + ".bg", &err);
+      const HostTensor* w1 = find(wm, n + ".w1", &err);
+      const HostTensor* b1 = find(wm, n + ".b1", &err);
+      const HostTensor* gm = find(wm, n + ".gamma", &err);
+      const HostTensor* bt = find(wm, n + ".beta", &err);
+      const HostTensor* al = find(wm, n + ".alpha", &err);
+      if (!wg || !bg || !w1 || !b1 || !gm || !bt || !al) return fail(NUTLS_ERR_WEIGHTS, err);
+      if (wg->dims.size() != 4 || wg->dims[3] != k) return fail(NUTLS_ERR_WEIGHTS, "unexpected grouped-conv shape " + n);
+      const int G = wg->dims[0];
+      if ((rc = upload(e, ohwi_to_tkio(*wg), &W.wg[k - 1]))) return rc;
+      if ((rc = upload(e, bg->data, &W.bg[k - 1]))) return rc;
+      if ((rc = upload(e, transpose2d(*w1, G, G), &W.w1[k - 1]))) return rc;
+      if ((rc = upload(e, b1->data, &W.b1[k - 1]))) return rc;
+      if ((rc = upload(e, gm->data, &W.gamma[k - 1]))) return rc;
+      if ((rc = upload(e, bt->data, &W.beta[k - 1]))) return rc;
+      W.alpha[k - 1] = al->data[0];
+    }
+  }
+  return NUTLS_OK;
+}
+
 static int prep_weights(Engine* e, const WeightMap& wm) {
   std::string err;
   int rc;
@@ -314,11 +383,15 @@ static int prep_weights(Engine* e, const WeightMap& wm) {
         e->ctfaw[P + br] = cw;
       }
     }
+  if (e->variant == NUTLS_VARIANT_BASELINE) {
+    if ((rc = prep_ddb_weights(e, wm))) return rc;
+  }
   // LSTM + Dense pairs (13)
   std::vector<std::pair<std::string, std::string>> lstms;
   for (int s = 0; s < 6; ++s) lstms.push_back({std::string(kEncoder[s].prefix) + "_lstm", std::string(kEncoder[s].prefix) + "_dense"});
   lstms.push_back({"lstm", "dense"});
   for (int s = 0; s < 6; ++s) lstms.push_back({std::string(kDecoder[s].prefix) + "_lstm", std::string(kDecoder[s].prefix) + "_dense"});
+  if (e->variant != NUTLS_VARIANT_LSTM) lstms.clear();
   for (auto& ld : lstms) {
     const HostTensor* wx = find(wm, ld.first + ".wx", &err);
     const HostTensor* wh = find(wm, ld.first + ".wh", &err);
@@ -358,15 +431,21 @@ static int prep_weights(Engine* e, const WeightMap& wm) {
 }
 
 // ------------------------------------------------------------------------------- state --------
-static int add_state(Engine* e, const std::string& prev, const std::string& cur, int d0, int d1) {
+static int add_state(Engine* e, const std::string& prev, const std::string& cur, int d0, int d1, int ring_d = 0) {
   StateTensor st;
+  st.ring_d = ring_d;
   st.name_prev = prev;
   st.name_cur = cur;
   st.d0 = d0;
   st.d1 = d1;
   const int idx = static_cast<int>(e->states.size());
   e->states.push_back(st);
-  for (int i = 0; i < 2; ++i) slot_reserve(e, static_cast<size_t>(d0) * d1, &e->states[idx].buf[i]);
+  if (ring_d > 0) {
+    slot_reserve(e, static_cast<size_t>(d0) * d1, &e->states[idx].buf[0]);   // single buffer, updated in place
+    e->states[idx].buf[1] = nullptr;                                        // aliased to buf[0] after arena_commit
+  } else {
+    for (int i = 0; i < 2; ++i) slot_reserve(e, static_cast<size_t>(d0) * d1, &e->states[idx].buf[i]);
+  }
   e->state_index[prev] = idx;
   e->state_index[cur] = idx;
   return idx;
@@ -394,6 +473,25 @@ static int build_states(Engine* e) {
         ss.spconv.push_back(idx);
       }
     }
+  if (e->variant == NUTLS_VARIANT_BASELINE) {
+    // dilated-dense block states (converter_nunet_tls.py:173-180, :228-235): 13 bottlenecks in
+    // network order -- 6 encoder stages, the central block ("ddb"), 6 decoder stages
+    for (int b = 0; b < 13; ++b) {
+      const bool central = b == 6;
+      const StageDesc* st = central ? nullptr : (b < 6 ? &kEncoder[b] : &kDecoder[b - 7]);
+      const int F = central ? 4 : (st->f0 >> st->depth), C = central ? 64 : 32, G = C / 2;
+      const std::string tag = central ? "ddb" : std::string(st->prefix) + "_ddb";
+      Engine::DdbStates& ds = e->ddb_st[b];
+      if ((ds.in = add_state(e, tag + "_prev_in", tag + "_cur_in", F, C, 1)) < 0) return ds.in;
+      for (int k = 1; k <= 6; ++k) {
+        const int d = 1 << (k - 1);
+        if ((ds.blk[k - 1] = add_state(e, tag + "_prev" + std::to_string(k), tag + "_cur" + std::to_string(k), d * F, k * G, d)) < 0)
+          return ds.blk[k - 1];
+      }
+      if ((ds.out = add_state(e, tag + "_prev_out", tag + "_cur_out", F, G, 1)) < 0) return ds.out;
+    }
+    return NUTLS_OK;
+  }
   auto add_hc = [&](const std::string& base, int* h, int* c) -> int {
     *h = add_state(e, base + "_h", base + "_h", NUTLS_LSTM_UNITS, 1);
     if (*h < 0) return *h;
@@ -425,6 +523,33 @@ static void push_conv(Engine* e, std::vector<Launch>* plan, const std::string& w
   p.B = e->B; p.F_in = f_in; p.F_out = f_out; p.log2_fout = ilog2(f_out);
   p.row_mul = row_mul; p.row_add = row_add; p.alpha = w.alpha; p.sstride = static_cast<long long>(e->sstride);
   plan->push_back(L);
+}
+
+// Baseline bottleneck b (0..12): same input / output placement as the LSTM + Dense it replaces.
+static void push_ddb(Engine* e, std::vector<Launch>* plan, int par, int b, const std::string& name, const float* x, int x_ld, float* dst,
+                     int dst_ld, int F, int C) {
+  const Engine::DdbW& W = e->ddbw[b];
+  const Engine::DdbStates& S = e->ddb_st[b];
+  DdbParams p{};
+  p.x = x; p.x_ld = x_ld; p.dst = dst; p.dst_ld = dst_ld;
+  p.st_in = e->states[S.in].buf[0];
+  for (int k = 0; k < 6; ++k) p.st_blk[k] = e->states[S.blk[k]].buf[0];
+  p.st_out = e->states[S.out].buf[0];
+  p.w_in = W.w_in; p.b_in = W.b_in; p.a_in = W.a_in;
+  for (int k = 0; k < 6; ++k) {
+    p.wg[k] = W.wg[k]; p.bg[k] = W.bg[k]; p.w1[k] = W.w1[k]; p.b1[k] = W.b1[k];
+    p.gamma[k] = W.gamma[k]; p.beta[k] = W.beta[k]; p.alpha[k] = W.alpha[k];
+  }
+  p.w_out = W.w_out; p.b_out = W.b_out; p.a_out = W.a_out;
+  p.step = e->d_step; p.F = F; p.C = C; p.B = e->B; p.sstride = static_cast<long long>(e->sstride);
+  Launch L{};
+  L.kind = Launch::DDB;
+  L.name = name;
+  L.ddb = p;
+  L.ddb_index = par * 13 + b;          // x / dst live in parity-specific state tensors: one table entry per parity
+  plan->push_back(L);
+  if (e->ddbs.size() < 26) e->ddbs.resize(26);
+  e->ddbs[L.ddb_index] = p;
 }
 
 static void push_lstm(Engine* e, std::vector<Launch>* plan, const std::string& lname, const float* x, int x_ld, int x_rows,
@@ -473,7 +598,10 @@ static void build_stage(Engine* e, std::vector<Launch>* plan, int side, int s, i
               d1, l1, 1, 0, side == 0);
   }
   // d_0 = Dense(LSTM(flatten(e_D)))  -> channels [0,32) of the first sub-pixel conv's input
-  push_lstm(e, plan, P + "_lstm", cur(ss.spconv[0]) + 32, 64, FD, 32, cur(ss.spconv[0]), 64, FD, 32, ss.h, ss.c, par);
+  if (e->variant == NUTLS_VARIANT_BASELINE)
+    push_ddb(e, plan, par, side ? 7 + s : s, P + "_ddb", cur(ss.spconv[0]) + 32, 64, cur(ss.spconv[0]), 64, FD, 32);
+  else
+    push_lstm(e, plan, P + "_lstm", cur(ss.spconv[0]) + 32, 64, FD, 32, cur(ss.spconv[0]), 64, FD, 32, ss.h, ss.c, par);
   // d_j = DL_j([prev_j ; cur_j])
   const float* dD = nullptr;
   int dD_ld = 0;
@@ -531,7 +659,10 @@ static void build_plan(Engine* e, int par) {
     x_ld = 128;
   }
   // central LSTM over flatten([4,64]) (converter_proposed.py:456-459)
-  push_lstm(e, plan, "lstm", e->upcat[0] + 64, 128, 4, 64, e->upcat[0], 128, 4, 64, e->central_h, e->central_c, par);
+  if (e->variant == NUTLS_VARIANT_BASELINE)
+    push_ddb(e, plan, par, 6, "ddb", e->upcat[0] + 64, 128, e->upcat[0], 128, 4, 64);
+  else
+    push_lstm(e, plan, "lstm", e->upcat[0] + 64, 128, 4, 64, e->upcat[0], 128, 4, 64, e->central_h, e->central_c, par);
   for (int s = 0; s < 6; ++s) {
     const StageDesc& st = kDecoder[s];
     const int fin = st.f0 / 2;
@@ -556,6 +687,7 @@ static hipError_t run_launch(const Launch& L, hipStream_t s) {
     case Launch::CTFA: return launch_ctfa(L.ctfa, s);
     case Launch::INLAYER: return launch_input_layer(L.inl, s);
     case Launch::OUTCONV: return launch_out_conv(L.outc, s);
+    case Launch::DDB: return launch_ddb(L.ddb, s);
   }
   return hipErrorInvalidValue;
 }
@@ -565,6 +697,7 @@ static int run_plan(Engine* e, int par, hipStream_t s) {
     hipError_t err = run_launch(L, s);
     if (err != hipSuccess) return fail(NUTLS_ERR_HIP, "launch " + L.name + ": " + hipGetErrorString(err));
   }
+  if (e->variant == NUTLS_VARIANT_BASELINE) HIP_TRY(launch_incr_step(e->d_step, s));   // ring position of the dilated-dense history
   return NUTLS_OK;
 }
 
@@ -584,6 +717,7 @@ static void collect_writes(const Launch& L, int idx, std::vector<WriteRegion>* o
     case Launch::CTFA: out->push_back({L.ctfa.y, L.ctfa.y_ld, 64, idx}); break;
     case Launch::INLAYER: out->push_back({L.inl.y, 64, 64, idx}); break;
     case Launch::OUTCONV: break;
+    case Launch::DDB: out->push_back({L.ddb.dst, L.ddb.dst_ld, L.ddb.C, idx}); break;
   }
 }
 
@@ -596,7 +730,7 @@ static void plan_handoffs(const std::vector<Launch>& plan, std::vector<DevLaunch
   for (size_t i = 0; i < plan.size(); ++i) collect_writes(plan[i], static_cast<int>(i), &writes);
   const bool disabled = getenv("NUTLS_NO_HANDOFF") != nullptr;
   for (size_t i = 0; i + 1 < plan.size(); ++i) {
-    if (plan[i + 1].kind != Launch::CONV || plan[i].kind == Launch::OUTCONV) continue;
+    if (plan[i + 1].kind != Launch::CONV || plan[i].kind == Launch::OUTCONV || plan[i].kind == Launch::DDB) continue;
     DevLaunch& L = (*dv)[i];
     DevLaunch& N = (*dv)[i + 1];
     const ConvParams& np = N.conv;
@@ -662,6 +796,7 @@ static int upload_device_plans(Engine* e) {
         case Launch::CTFA: d.op = DEV_OP_CTFA; d.ctfa = L.ctfa; break;
         case Launch::INLAYER: d.op = DEV_OP_INLAYER; d.inl = L.inl; break;
         case Launch::OUTCONV: d.op = DEV_OP_OUTCONV; d.outc = L.outc; break;
+        case Launch::DDB: d.op = DEV_OP_DDB; d.ddb_index = L.ddb_index; break;
       }
     }
     plan_handoffs(e->plan[par], &dv);
@@ -685,6 +820,13 @@ static int upload_device_plans(Engine* e) {
     HIP_TRY(hipMemcpy(p, cv.data(), cv.size() * sizeof(CompactOp), hipMemcpyHostToDevice));
     e->dplan[par] = static_cast<CompactOp*>(p);
   }
+  if (!e->ddbs.empty()) {
+    void* t = nullptr;
+    HIP_TRY(hipMalloc(&t, e->ddbs.size() * sizeof(DdbParams)));
+    e->allocs.push_back(t);
+    HIP_TRY(hipMemcpy(t, e->ddbs.data(), e->ddbs.size() * sizeof(DdbParams), hipMemcpyHostToDevice));
+    e->d_ddb = static_cast<DdbParams*>(t);
+  }
   void* q = nullptr;
   HIP_TRY(hipMalloc(&q, (e->plan[0].size() * 9 + 3) * sizeof(unsigned long long)));   // layer stamps + 8 sub-stamps per layer + 2 clock64
   HIP_TRY(hipMemset(q, 0, (e->plan[0].size() * 9 + 3) * sizeof(unsigned long long)));
@@ -696,9 +838,10 @@ static int upload_device_plans(Engine* e) {
 static int run_persistent(Engine* e, int par, hipStream_t s, bool prof) {
   const int grid = e->B;   // one workgroup per stream; the hardware runs as many as fit (1 per CU)
   StepArgs a{e->dplan[par], static_cast<int>(e->plan[par].size()), e->B, e->arena, static_cast<long long>(e->sstride), e->warena,
-             e->io_in, e->io_out, prof ? e->dprof : nullptr};
+             e->io_in, e->io_out, prof ? e->dprof : nullptr, e->d_ddb};
   hipError_t err = launch_stream_step(a, grid, s);
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("persistent step launch: ") + hipGetErrorString(err));
+  if (e->variant == NUTLS_VARIANT_BASELINE) HIP_TRY(launch_incr_step(e->d_step, s));
   return NUTLS_OK;
 }
 
@@ -736,7 +879,7 @@ const char* nutls_version(void) { return "nutls-hip 0.1 (gfx950, fp32 MFMA)"; }
 
 int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, int device, nutls_handle** out) {
   if (!weights || !out || batch < 1) return fail(NUTLS_ERR_ARG, "nutls_create: null pointer or batch < 1");
-  if (variant != NUTLS_VARIANT_LSTM) return fail(NUTLS_ERR_ARG, "nutls_create: unknown variant");
+  if (variant != NUTLS_VARIANT_LSTM && variant != NUTLS_VARIANT_BASELINE) return fail(NUTLS_ERR_ARG, "nutls_create: unknown variant");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(NUTLS_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
@@ -753,10 +896,18 @@ int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, in
   Engine* e = &h->eng;
   e->B = batch;
   e->device = device;
+  e->variant = variant;
   HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   int rc;
   if ((rc = prep_weights(e, wm))) return rc;
-  e->states.reserve(160);
+  {
+    void* ds = nullptr;
+    HIP_TRY(hipMalloc(&ds, sizeof(int)));
+    e->allocs.push_back(ds);
+    HIP_TRY(hipMemset(ds, 0, sizeof(int)));
+    e->d_step = static_cast<int*>(ds);
+  }
+  e->states.reserve(320);   // slot_reserve keeps pointers into this vector: it must never reallocate (130 or 208 states)
   if ((rc = build_states(e))) return rc;
   const size_t B = static_cast<size_t>(batch);
   if ((rc = dev_alloc(e, B * NUTLS_BINS, &e->io_in, true))) return rc;
@@ -836,6 +987,7 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   }
   if (mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
   e->next_parity = 1 - par;
+  e->steps += 1;
   return NUTLS_OK;
 }
 
@@ -863,6 +1015,24 @@ int nutls_state_info(nutls_handle* h, int index, const char** name, int* dim0, i
   return NUTLS_OK;
 }
 
+// Ring states: the device keeps frame j of the reference's [d, F, C] history (0 = oldest) in physical
+// slot (steps + j) mod d.  to_logical: physical -> reference order (get); else reference -> physical (set).
+static void rotate_ring(Engine* e, const StateTensor& st, float* host, bool to_logical) {
+  const int d = st.ring_d;
+  const size_t frame = st.per_stream() / d;
+  std::vector<float> tmp(st.per_stream());
+  for (int b = 0; b < e->B; ++b) {
+    float* base = host + static_cast<size_t>(b) * st.per_stream();
+    for (int j = 0; j < d; ++j) {
+      const int slot = static_cast<int>((e->steps + j) % d);
+      const float* src = base + static_cast<size_t>(to_logical ? slot : j) * frame;
+      float* dst = tmp.data() + static_cast<size_t>(to_logical ? j : slot) * frame;
+      std::memcpy(dst, src, frame * sizeof(float));
+    }
+    std::memcpy(base, tmp.data(), st.per_stream() * sizeof(float));
+  }
+}
+
 static int state_lookup(Engine* e, const char* name, size_t n_floats, StateTensor** out) {
   if (!name) return fail(NUTLS_ERR_ARG, "state name is null");
   auto it = e->state_index.find(name);
@@ -883,7 +1053,9 @@ int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  return copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), host_buf, true);
+  rc = copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), host_buf, true);
+  if (rc == NUTLS_OK && st->ring_d > 1) rotate_ring(e, *st, host_buf, true);
+  return rc;
 }
 
 int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, size_t n_floats) {
@@ -894,6 +1066,11 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (st->ring_d > 1) {
+    std::vector<float> tmp(host_buf, host_buf + n_floats);
+    rotate_ring(e, *st, tmp.data(), false);
+    return copy_stream_tensor(e, st->buf[0], st->per_stream(), tmp.data(), false);
+  }
   return copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), const_cast<float*>(host_buf), false);
 }
 
@@ -936,6 +1113,7 @@ static const char* family_name(const Launch& L, int B) {
     case Launch::CTFA: return "ctfa";
     case Launch::INLAYER: return "input_layer";
     case Launch::OUTCONV: return "out_conv";
+    case Launch::DDB: return "dilated_dense";
   }
   return "?";
 }
@@ -970,6 +1148,14 @@ int nutls_launch_info(nutls_handle* h, int index, const char** layer, const char
       fl = 2.0 * L.outc.n_pos * 64;
       by = 4.0 * L.outc.n_pos * 65;
       break;
+    case Launch::DDB: {
+      const double F = L.ddb.F, C = L.ddb.C, G = C / 2;
+      double mac = 2 * 6.0 * C * G * F;                               // in + out convs
+      for (int k = 1; k <= 6; ++k) mac += F * G * (6.0 * k + G);       // grouped dilated conv + 1x1
+      fl = 2.0 * B * mac;
+      by = 4.0 * B * F * (2 * C + 2 * 321.0 * G);                     // history read + written once per step
+      break;
+    }
   }
   if (layer) *layer = L.name.c_str();
   if (family) *family = family_name(L, e->B);
@@ -992,10 +1178,12 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
     HIP_TRY(run_launch(plan[i], e->stream));
     HIP_TRY(hipEventRecord(ev[i + 1], e->stream));
   }
+  if (e->variant == NUTLS_VARIANT_BASELINE) HIP_TRY(launch_incr_step(e->d_step, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (size_t i = 0; i < plan.size(); ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
   for (auto& x : ev) (void)hipEventDestroy(x);
   e->next_parity = 1 - par;
+  e->steps += 1;
   return NUTLS_OK;
 }
 
@@ -1016,6 +1204,7 @@ int nutls_profile_persistent(nutls_handle* h, double* us, int n) {
   if (khz <= 0) khz = 100000;
   for (int i = 0; i < n_ops; ++i) us[i] = static_cast<double>(t[i + 1] - t[i]) * 1000.0 / khz;
   e->next_parity = 1 - par;
+  e->steps += 1;
   if (const char* dump = getenv("NUTLS_SUBSTAMPS")) {   // debugging aid: phase breakdown of every conv layer
     std::vector<unsigned long long> sub(static_cast<size_t>(n_ops) * 8);
     HIP_TRY(hipMemcpy(sub.data(), e->dprof + n_ops + 1, sub.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "nutls_internal.hpp"
+#include "ddb_device.hpp"
 
 namespace nutls {
 
@@ -447,6 +448,27 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvParams p) {
 hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>((static_cast<long long>(p.n_pos) * 16 + 255) / 256);
   hipLaunchKernelGGL(out_conv_kernel, dim3(grid), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// ================================================================================================
+//  Baseline variant: dilated-dense bottleneck, one workgroup per stream (ddb_device.hpp)
+// ================================================================================================
+__global__ __launch_bounds__(256) void ddb_kernel(const DdbParams p) {
+  __shared__ float lds[2 * 4 * 64 + 8 * 4 * 32];
+  ddb_block(p, blockIdx.x, lds, threadIdx.x, 256);
+}
+
+hipError_t launch_ddb(const DdbParams& p, hipStream_t s) {
+  if (p.F * p.C > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ddb_kernel, dim3(p.B), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+__global__ void incr_step_kernel(int* step) { *step += 1; }
+
+hipError_t launch_incr_step(int* step, hipStream_t s) {
+  hipLaunchKernelGGL(incr_step_kernel, dim3(1), dim3(1), 0, s, step);
   return hipGetLastError();
 }
 

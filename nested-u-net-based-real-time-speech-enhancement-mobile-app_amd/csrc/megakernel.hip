@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "nutls_internal.hpp"
+#include "ddb_device.hpp"
 
 namespace nutls {
 
@@ -804,6 +805,8 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
           ctfa_layer(p, stream, lds_out, lds_in, tid, nc_hand, nc_coff, np, ncp);
         } else if (op == DEV_OP_INLAYER) {
           input_layer_op(cur, a, stream, lds_in, tid, nc_hand, ncp);
+        } else if (op == DEV_OP_DDB) {
+          ddb_block(a.ddb[cur.w[0]], stream, lds_out, tid, MK_THREADS);
         } else {
           out_conv_op(cur, a, stream, tid);
         }

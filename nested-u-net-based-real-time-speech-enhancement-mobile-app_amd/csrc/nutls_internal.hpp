@@ -85,6 +85,26 @@ struct LstmParams {
 };
 hipError_t launch_lstm(const LstmParams& p, hipStream_t s);
 
+// Dilated-dense bottleneck of the baseline variant (see ddb_device.hpp).  Weights transposed so the
+// output channel is the fastest index (consecutive threads read consecutive floats).
+struct DdbParams {
+  const float* x; int x_ld;          // input rows [F][C]
+  float* dst; int dst_ld;            // output rows [F][C]
+  float* st_in;                      // [1][F][C]       previous input (updated in place)
+  float* st_blk[6];                  // [d][F][k*G]     ring of the last d = 2^(k-1) frames of block k's input
+  float* st_out;                     // [1][F][G]
+  const float* w_in; const float* b_in; float a_in;        // [t][kw][c][g]
+  const float* wg[6]; const float* bg[6];                  // [t][kw][j][g]
+  const float* w1[6]; const float* b1[6];                  // [gin][gout]
+  const float* gamma[6]; const float* beta[6]; float alpha[6];
+  const float* w_out; const float* b_out; float a_out;     // [t][kw][g][c]
+  const int* step;                   // device-resident frame counter (ring position)
+  int F, C, B;
+  long long sstride;
+};
+hipError_t launch_ddb(const DdbParams& p, hipStream_t s);
+hipError_t launch_incr_step(int* step, hipStream_t s);
+
 struct CtfaParams {
   const float* x; int x_ld;      // d_D  [B,F,64]
   const float* e0; int e0_ld;    // residual [B,F,64]
@@ -118,7 +138,7 @@ hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
 // ------------------------------------------------------------------ persistent kernel ---------
 // Device-resident launch plan: one entry per layer, consumed by nutls_stream_step_kernel
 // (megakernel.hip), which runs the whole frame step of one stream inside one workgroup.
-enum DevOp : int { DEV_OP_CONV = 0, DEV_OP_LSTM, DEV_OP_CTFA, DEV_OP_INLAYER, DEV_OP_OUTCONV };
+enum DevOp : int { DEV_OP_CONV = 0, DEV_OP_LSTM, DEV_OP_CTFA, DEV_OP_INLAYER, DEV_OP_OUTCONV, DEV_OP_DDB };
 constexpr int NUTLS_DEV_BINS = 256;
 // Host-precomputed execution plan of one conv-like layer inside the persistent kernel (all the
 // integer bookkeeping the kernel would otherwise redo per layer: LDS geometry, task split, hand-off).
@@ -155,6 +175,7 @@ struct DevLaunch {
     OutConvParams outc;
   };
   ConvPlan cp;   // valid when op == DEV_OP_CONV
+  int ddb_index; // DEV_OP_DDB: index into the DdbParams table
   // hand-off of a NON-conv op (LSTM / CTFA / input layer) to the conv layer that follows it
   int nc_hand;       // 1: this op completes the next conv layer's LDS image
   int nc_fwd_coff;   // channel offset (floats) of this op's output inside the next layer's input row
@@ -181,6 +202,7 @@ struct StepArgs {            // kernel arguments of the persistent kernel
   const float* io_in;        // [B,256]
   float* io_out;             // [B,256]
   unsigned long long* prof;  // nullable
+  const DdbParams* ddb;      // baseline variant: table of the 13 dilated-dense blocks (else null)
 };
 CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase);
 hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s);

@@ -213,6 +213,9 @@ CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) 
       o.w[5] = fbits(p.alpha);
       break;
     }
+    case DEV_OP_DDB:
+      o.w[0] = static_cast<uint32_t>(d.ddb_index);
+      break;
     default: {
       const OutConvParams& p = d.outc;
       o.w[0] = off_of(p.x, arena); o.w[1] = static_cast<uint32_t>(p.x_ld);

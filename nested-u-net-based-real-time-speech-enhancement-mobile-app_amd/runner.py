@@ -98,15 +98,25 @@ class NutlsEngine:
     """B streams, device-resident state.  ``step`` takes/returns ``[B,256]`` magnitudes."""
 
     MODES = {"launches": 0, "graph": 1, "persistent": 2}
+    VARIANTS = {"lstm": 0, "baseline": 1}
 
-    def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: str = "persistent"):
+    def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: str = "persistent", variant: str = "lstm"):
         """``mode``: "persistent" (default; one launch per frame, one workgroup per stream),
-        "graph" (one kernel per layer, hipGraph replay) or "launches" (one kernel per layer)."""
+        "graph" (one kernel per layer, hipGraph replay) or "launches" (one kernel per layer).
+        ``variant``: "lstm" (NUNet-TLS-LSTM, trained weights ship in weights/) or "baseline"
+        (dilated-dense bottleneck; no trained weights exist -- pass a container, e.g.
+        ``weights.write_blob(weights.synthetic_weights("baseline"))``)."""
         self._lib = load_library()
+        if variant not in self.VARIANTS:
+            raise ValueError("variant must be one of %s" % sorted(self.VARIANTS))
+        if weights is None and variant != "lstm":
+            raise ValueError("the %s variant has no shipped weights: pass a .nutlsw container" % variant)
+        self.variant = variant
         blob = read_blob(weights if weights is not None else DEFAULT_WEIGHTS)
         self._h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(blob, len(blob))
-        _check(self._lib, self._lib.nutls_create(buf, len(blob), 0, int(batch), int(device), ctypes.byref(self._h)))
+        _check(self._lib, self._lib.nutls_create(buf, len(blob), self.VARIANTS[variant], int(batch), int(device),
+                                                 ctypes.byref(self._h)))
         self.batch = int(batch)
         self.device = int(device)
         pin, pout = ctypes.c_void_p(), ctypes.c_void_p()
@@ -241,16 +251,25 @@ class NutlsRunner:
 
     signature_key = "nutls_lstm_sm"
 
-    def __init__(self, weights=None, device: int = 0, mode: str = "persistent"):
-        self.engine = NutlsEngine(weights, batch=1, device=device, mode=mode)
-        self._in_names = T.input_names()
-        self._specs = T.state_specs()
+    def __init__(self, weights=None, device: int = 0, mode: str = "persistent", variant: str = "lstm"):
+        """``variant="baseline"`` mirrors the 'nutls' signature of converter_nunet_tls.py:1542 (208 states;
+        interpreter_nunet_tls.py:549) -- weights must be supplied, none are shipped."""
+        self.engine = NutlsEngine(weights, batch=1, device=device, mode=mode, variant=variant)
+        self.signature_key = "nutls_lstm_sm" if variant == "lstm" else "nutls"
+        self._in_names = T.input_names(variant)
+        self._specs = T.state_specs(variant)
         self._last: Dict[str, np.ndarray] = {}
+
+    @staticmethod
+    def _io_shape(shp):
+        """per-stream spec -> signature tensor shape: conv states (1,F,C) -> [1,1,F,C]; dilated-dense
+        history (d,F,C) -> [1,d,F,C]; LSTM states (21,) -> [1,21]"""
+        return (1, shp[0]) if len(shp) == 1 else (1,) + tuple(shp)
 
     def get_input_details(self) -> Dict[str, Tuple[int, ...]]:
         d = {"input": (1, 1, T.N_BINS, 1)}
         for base, shp in self._specs:
-            d[base.format("prev")] = (1, shp[0]) if len(shp) == 1 else (1,) + shp
+            d[base.format("prev")] = (1, shp[0]) if len(shp) == 1 else self._io_shape(shp)
         return d
 
     def __call__(self, **feeds) -> Dict[str, np.ndarray]:
@@ -265,7 +284,7 @@ class NutlsRunner:
         for base, shp in self._specs:
             k_in, k_out = base.format("prev"), base.format("cur")
             a = feeds[k_in]
-            want = (1, shp[0]) if len(shp) == 1 else (1,) + shp
+            want = self._io_shape(shp)
             if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.shape != want:
                 raise ValueError("%s must be float32 %s" % (k_in, want))
             if self._last.get(k_out) is not a:      # not the echo of our own output: upload
@@ -275,6 +294,6 @@ class NutlsRunner:
         for base, shp in self._specs:
             k_in, k_out = base.format("prev"), base.format("cur")
             a = eng.state_get(k_in)
-            res[k_out] = a.reshape((1, shp[0]) if len(shp) == 1 else (1,) + shp)
+            res[k_out] = a.reshape(self._io_shape(shp))
         self._last = res
         return res

@@ -73,10 +73,37 @@ def spconv_state_shape(st: Stage, j: int) -> Tuple[int, int]:
     return st.fd << (j - 1), 2 * MID_CH
 
 
-def state_specs() -> List[Tuple[str, Tuple[int, ...]]]:
-    """[(base name, per-stream shape)] of the 130 state tensors.  ``base`` carries
-    ``{}`` where the signature says ``prev`` (inputs) / ``cur`` (outputs) for the
-    conv states; LSTM states have the same name on both sides."""
+# ---- dilated-dense bottleneck of the baseline variant (models/nunet_tls.py:190-359) ------------
+DDB_BLOCKS = 6                     # dilation 1, 2, 4, 8, 16, 32 in time AND frequency
+
+
+def bottlenecks() -> List[Tuple[str, int, int]]:
+    """[(prefix, F, C)] of the 13 bottlenecks in network order: 6 encoder stages, the central one
+    (prefix "ddb" / LSTM "lstm"), 6 decoder stages.  C = 32 in the stages, 64 centrally."""
+    out = [(st.prefix, st.fd, MID_CH) for st in ENCODER]
+    out.append(("", CENTRAL_F, CENTRAL_C))
+    out += [(st.prefix, st.fd, MID_CH) for st in DECODER]
+    return out
+
+
+def ddb_state_specs(prefix: str, f: int, c: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    """State tensors of one dilated-dense block, converter_nunet_tls.py:173-180 (stage) / :228-235
+    (central): prev_in [1,F,C], prev_k [d,F,k*C/2] for k = 1..6 (d = 2^(k-1) past frames, oldest
+    first), prev_out [1,F,C/2]."""
+    g = c // 2
+    tag = (prefix + "_ddb") if prefix else "ddb"
+    specs = [(tag + "_{}_in", (1, f, c))]
+    for k in range(1, DDB_BLOCKS + 1):
+        specs.append((tag + "_{}%d" % k, (1 << (k - 1), f, k * g)))
+    specs.append((tag + "_{}_out", (1, f, g)))
+    return specs
+
+
+def state_specs(variant: str = "lstm") -> List[Tuple[str, Tuple[int, ...]]]:
+    """[(base name, per-stream shape)] of the state tensors: 130 for the LSTM variant
+    (converter_proposed.py:27-186), 208 for the dilated-dense baseline
+    (converter_nunet_tls.py:41-249).  ``base`` carries ``{}`` where the signature says ``prev``
+    (inputs) / ``cur`` (outputs); LSTM states have the same name on both sides."""
     specs: List[Tuple[str, Tuple[int, ...]]] = []
     for st in STAGES:
         for i in range(1, st.depth + 1):
@@ -85,6 +112,12 @@ def state_specs() -> List[Tuple[str, Tuple[int, ...]]]:
         for j in range(1, st.depth + 1):
             f, c = spconv_state_shape(st, j)
             specs.append(("%s_{}%d" % (st.spconv_tag, j), (1, f, c)))
+    if variant == "baseline":
+        for prefix, f, c in bottlenecks():
+            specs += ddb_state_specs(prefix, f, c)
+        return specs
+    if variant != "lstm":
+        raise ValueError("variant must be 'lstm' or 'baseline'")
     for st in ENCODER:
         specs += [(st.prefix + "_h", (LSTM_UNITS,)), (st.prefix + "_c", (LSTM_UNITS,))]
     specs += [("state_h", (LSTM_UNITS,)), ("state_c", (LSTM_UNITS,))]
@@ -93,17 +126,17 @@ def state_specs() -> List[Tuple[str, Tuple[int, ...]]]:
     return specs
 
 
-def input_names() -> List[str]:
-    return ["input"] + [b.format("prev") for b, _ in state_specs()]
+def input_names(variant: str = "lstm") -> List[str]:
+    return ["input"] + [b.format("prev") for b, _ in state_specs(variant)]
 
 
-def output_names() -> List[str]:
-    return [b.format("cur") for b, _ in state_specs()] + ["model_out"]
+def output_names(variant: str = "lstm") -> List[str]:
+    return [b.format("cur") for b, _ in state_specs(variant)] + ["model_out"]
 
 
-def state_floats_per_stream() -> int:
+def state_floats_per_stream(variant: str = "lstm") -> int:
     n = 0
-    for _, shp in state_specs():
+    for _, shp in state_specs(variant):
         k = 1
         for d in shp:
             k *= d

@@ -39,8 +39,14 @@ LN_EPS = 1e-8  # proposed.py:202 (LayerNormalization(epsilon=1e-8))
 
 
 class NutlsRef:
+    """``variant="lstm"``: NUNet-TLS-LSTM (models/proposed.py, trained weights).
+    ``variant="baseline"``: NUNet-TLS with the dilated-dense bottleneck
+    (models/nunet_tls.py:277-359 blocks, converter_nunet_tls.py:374-411 streaming wiring);
+    no trained weights exist for it, pass synthetic ones."""
+
     def __init__(self, weights: Optional[Dict[str, np.ndarray]] = None, batch: int = 1,
-                 ctfa_mode: str = "frame"):
+                 ctfa_mode: str = "frame", variant: str = "lstm"):
+        self.variant = variant
         w = weights if weights is not None else load_weights()
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in w.items()}
         self.batch = batch
@@ -52,9 +58,11 @@ class NutlsRef:
     # ---------------------------------------------------------------- state -------------
     def reset(self):
         """All-zero state, as the reference seeds it (interpreter_proposed.py:36-198)."""
-        for base, shp in T.state_specs():
+        for base, shp in T.state_specs(self.variant):
             if len(shp) == 1:
                 self.state[base] = torch.zeros(self.batch, shp[0])
+            elif "_ddb_" in base or base.startswith("ddb_"):
+                self.state[base.format("prev")] = torch.zeros(self.batch, *shp)      # [B, d, F, C] oldest first
             else:
                 self.state[base.format("prev")] = torch.zeros(self.batch, shp[1], shp[2])
 
@@ -133,6 +141,53 @@ class NutlsRef:
         self._new[hname], self._new[cname] = h2, c2
         return h2 @ self.w[dense + ".w"].t() + self.w[dense + ".b"]
 
+    def _bottleneck(self, x, prefix):
+        """[B,F,C] -> [B,F,C]: LSTM + Dense (proposed) or the dilated-dense block (baseline)."""
+        B, F, C = x.shape
+        if self.variant == "lstm":
+            names = (prefix + "_lstm", prefix + "_dense", prefix + "_h", prefix + "_c") if prefix else \
+                ("lstm", "dense", "state_h", "state_c")
+            return self._lstm_dense(x.reshape(B, -1), *names).reshape(B, F, C)
+        return self._ddb(x, (prefix + "_ddb") if prefix else "ddb")
+
+    def _prelu(self, y, layer):
+        a = self.w[layer + ".alpha"].reshape(())
+        return torch.clamp(y, min=0) + a * torch.clamp(y, max=0)
+
+    def _ddb(self, x, tag):
+        """Dilated-dense block, streaming form (converter_nunet_tls.py:374-411; blocks
+        nunet_tls.py:277-359).  in: (2,3) conv C->G + PReLU.  Block k (dilation d = 2^(k-1) in time
+        AND frequency): grouped (groups = G) (2,3) conv over the dense concat [o_{k-1},...,o_0]
+        (taps: frame t-d and frame t; bins f-d, f, f+d, zero padded) -> 1x1 conv -> LN -> PReLU.
+        out: (2,3) conv G->C + PReLU.  State: one previous frame for in/out, d frames for block k
+        (ring shifted by one per step, converter_nunet_tls.py:1420-1427)."""
+        B, F, C = x.shape
+        G = C // 2
+        k_in, k_out = tag + "_prev_in", tag + "_prev_out"
+        o = [self._prelu(self._conv23(self.state[k_in][:, 0], x, tag + "_in", 1), tag + "_in")]
+        self._new[k_in] = x.unsqueeze(1)
+        for k in range(1, T.DDB_BLOCKS + 1):
+            d = 1 << (k - 1)
+            name = "%s_%d" % (tag, k)
+            cur = torch.cat(o[::-1], dim=2)                     # newest first: [o_{k-1}, ..., o_0]  [B,F,k*G]
+            hist = self.state["%s_prev%d" % (tag, k)]           # [B,d,F,k*G], index 0 = frame t-d
+            wg = self.w[name + ".wg"]                           # [G,2,3,k]
+            y = self.w[name + ".bg"].expand(B, F, G).clone()
+            for t, src in enumerate((hist[:, 0], cur)):
+                xp = torch.nn.functional.pad(src, (0, 0, d, d)).reshape(B, F + 2 * d, G, k)   # group g = channels g*k..g*k+k-1
+                for kw in range(3):
+                    y = y + (xp[:, kw * d: kw * d + F] * wg[:, t, kw, :]).sum(dim=3)
+            self._new["%s_prev%d" % (tag, k)] = torch.cat([hist[:, 1:], cur.unsqueeze(1)], dim=1)
+            z = y @ self.w[name + ".w1"].t() + self.w[name + ".b1"]
+            g, b = self.w[name + ".gamma"], self.w[name + ".beta"]
+            mu = z.mean(dim=-1, keepdim=True)
+            var = ((z - mu) ** 2).mean(dim=-1, keepdim=True)
+            zn = (z - mu) * torch.rsqrt(var + LN_EPS) * g + b
+            o.append(self._prelu(zn, name))
+        out = self._prelu(self._conv23(self.state[k_out][:, 0], o[-1], tag + "_out", 1), tag + "_out")
+        self._new[k_out] = o[-1].unsqueeze(1)
+        return out
+
     def _mlp_gate(self, m, name):
         w1, w2 = self.w[name + ".w1"], self.w[name + ".w2"]
         hid = torch.relu(m @ w1.reshape(16, 64).t() + self.w[name + ".b1"])
@@ -156,9 +211,7 @@ class NutlsRef:
             e.append(self._el(self.state[key], cur, "%s_conv%d" % (st.prefix, i)))
             self._new[key] = cur
         eD = e[st.depth]
-        B = eD.shape[0]
-        d = self._lstm_dense(eD.reshape(B, -1), st.prefix + "_lstm", st.prefix + "_dense",
-                             st.prefix + "_h", st.prefix + "_c").reshape(B, st.fd, T.MID_CH)
+        d = self._bottleneck(eD, st.prefix)
         ds = {0: d}
         for j in range(1, st.depth + 1):
             cur = torch.cat([ds[j - 1], e[st.depth - j + 1]], dim=2)
@@ -186,9 +239,7 @@ class NutlsRef:
             y, ds = self._stage(st, x)
             x = self._down(y, st.resample)
             enc_d[st.prefix], enc_down[st.prefix] = ds, x
-        B = x.shape[0]
-        u = self._lstm_dense(x.reshape(B, -1), "lstm", "dense", "state_h", "state_c").reshape(
-            B, T.CENTRAL_F, T.CENTRAL_C)
+        u = self._bottleneck(x, "")
         if self.trace is not None:
             self.trace["central.q"] = u
         for st in T.DECODER:

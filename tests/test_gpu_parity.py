@@ -199,3 +199,71 @@ def test_linearity_free_property_scale_silence():
         assert np.all(out == out[0:1])
         assert np.all(np.isfinite(out))
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+#  Baseline variant (BASELINE config 3): dilated-dense bottleneck, synthetic weights (none are
+#  trained) -> parity is HIP vs oracle B on identical weights and inputs.
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def baseline_weights():
+    from nunet_amd.weights import synthetic_weights, write_blob
+    w = synthetic_weights("baseline", seed=4321, bias_std=0.1, affine_jitter=0.1)
+    return w, write_blob(w)
+
+
+@pytest.mark.parametrize("mode", ["persistent", "launches"])
+def test_baseline_variant_matches_oracle(baseline_weights, mode):
+    w, blob = baseline_weights
+    B, steps = 3, 40                                       # 40 > 32: the deepest history ring wraps
+    mags = synthetic_mags(B, steps, seed=77)
+    eng = NutlsEngine(blob, batch=B, variant="baseline", mode=mode)
+    ref = NutlsRef(w, batch=B, variant="baseline")
+    for s in range(steps):
+        out = eng.step(mags[s])
+        want = ref.step(mags[s]).numpy()
+        assert rms(out, want) < 1e-4 * max(1.0, float(np.abs(want).max())), s
+    # the 208 state tensors, dilated-dense histories in the reference's oldest-first order
+    specs = T.state_specs("baseline")
+    assert len(eng.state_specs()) == len(specs) == 208
+    for base, shp in specs:
+        name = base.format("prev")
+        a = eng.state_get(name).reshape(B, -1)
+        b = ref.state[name].numpy().reshape(B, -1)
+        assert rms(a, b) < 2e-4 * max(1.0, float(np.abs(b).max())), name
+    eng.close()
+
+
+def test_baseline_state_set_round_trip(baseline_weights):
+    w, blob = baseline_weights
+    mags = synthetic_mags(2, 12, seed=5)
+    a = NutlsEngine(blob, batch=2, variant="baseline")
+    for s in range(7):                                      # 7 steps: ring positions are mid-cycle
+        a.step(mags[s])
+    snap = {n: a.state_get(n) for n, _ in a.state_specs()}
+    o1 = [a.step(mags[s]) for s in range(7, 12)]
+    for n, v in snap.items():
+        a.state_set(n, v)                                   # restore -> identical continuation
+    # the ring position moved on by 5 steps: set() must re-rotate the histories accordingly
+    o2 = [a.step(mags[s]) for s in range(7, 12)]
+    for x, y in zip(o1, o2):
+        assert rms(x, y) < 1e-6
+    a.close()
+
+
+def test_baseline_signature_runner(baseline_weights):
+    w, blob = baseline_weights
+    run = NutlsRunner(blob, variant="baseline")
+    assert run.signature_key == "nutls"
+    details = run.get_input_details()
+    assert len(details) == 209 and details["ddb_prev6"] == (1, 32, 4, 192) and details["msfe6_ee_prev1"] == (1, 1, 256, 64)
+    ref = NutlsRef(w, batch=1, variant="baseline")
+    feeds = {k: np.zeros(v, np.float32) for k, v in details.items()}
+    mags = synthetic_mags(1, 3, seed=9)
+    for s in range(3):
+        feeds["input"] = mags[s].reshape(1, 1, 256, 1)
+        out = run(**feeds)
+        want = ref.step(mags[s]).numpy()
+        assert rms(out["model_out"].reshape(1, 256), want) < 1e-4
+        feeds = {k.replace("_cur", "_prev"): v for k, v in out.items() if k != "model_out"}
+    assert out["ddb_cur6"].shape == (1, 32, 4, 192)

@@ -117,3 +117,68 @@ def test_oracle_a_live_reproduces_goldens(has_reference):
         assert rms(out["model_out"].reshape(-1), clip["mags_out"][i]) < 1e-7
     with pytest.raises(ValueError):
         g(input=np.zeros((1, 1, 256, 1), np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+#  Baseline variant (dilated-dense bottleneck, BASELINE config 3).  No trained weights / goldens
+#  exist anywhere, so the STREAMING restatement is pinned against an independent
+#  OFFLINE formulation of the same block: the non-"valid" Keras layers of nunet_tls.py:190-272
+#  (causal ZeroPadding2D((d,0),(d,d)) + dilated, grouped Conv2D) applied to a whole sequence.
+# ------------------------------------------------------------------------------------------------
+def _offline_ddb(w, tag, x_seq):
+    """x_seq [T,F,C] -> [T,F,C] with torch conv2d on NCHW tensors (H = time, W = frequency)."""
+    import torch
+    import torch.nn.functional as Fn
+    T_, F, C = x_seq.shape
+    G = C // 2
+
+    def prelu(y, name):
+        a = float(w[name + ".alpha"].reshape(()))
+        return torch.clamp(y, min=0) + a * torch.clamp(y, max=0)
+
+    def ohwi(name):    # [O,kh,kw,I] -> OIHW
+        return torch.from_numpy(w[name + ".w"]).permute(0, 3, 1, 2).contiguous()
+
+    x = torch.from_numpy(x_seq).permute(2, 0, 1).unsqueeze(0)                 # [1,C,T,F]
+    o = [prelu(Fn.conv2d(Fn.pad(x, (1, 1, 1, 0)), ohwi(tag + "_in"), torch.from_numpy(w[tag + "_in.b"])), tag + "_in")]
+    for k in range(1, 7):
+        d = 1 << (k - 1)
+        n = "%s_%d" % (tag, k)
+        inp = torch.cat(o[::-1], dim=1)                                        # newest first, k*G channels
+        wg = torch.from_numpy(w[n + ".wg"]).permute(0, 3, 1, 2).contiguous()  # [G,k,2,3]: groups=G, k in-ch per group
+        y = Fn.conv2d(Fn.pad(inp, (d, d, d, 0)), wg, torch.from_numpy(w[n + ".bg"]), dilation=d, groups=G)
+        z = Fn.conv2d(y, torch.from_numpy(w[n + ".w1"]).reshape(G, G, 1, 1), torch.from_numpy(w[n + ".b1"]))
+        z = z.permute(0, 2, 3, 1)                                              # channels last for LN
+        mu = z.mean(-1, keepdim=True)
+        var = ((z - mu) ** 2).mean(-1, keepdim=True)
+        z = (z - mu) * torch.rsqrt(var + 1e-8) * torch.from_numpy(w[n + ".gamma"]) + torch.from_numpy(w[n + ".beta"])
+        o.append(prelu(z.permute(0, 3, 1, 2), n))
+    out = prelu(Fn.conv2d(Fn.pad(o[-1], (1, 1, 1, 0)), ohwi(tag + "_out"), torch.from_numpy(w[tag + "_out.b"])), tag + "_out")
+    return out[0].permute(1, 2, 0).numpy()
+
+
+def test_baseline_streaming_ddb_equals_offline_dilated_conv():
+    import torch
+    from nunet_amd.weights import synthetic_weights
+    w = synthetic_weights("baseline", seed=7, bias_std=0.2, affine_jitter=0.2)
+    ref = NutlsRef(w, batch=1, variant="baseline")
+    rng = np.random.default_rng(3)
+    for tag, F, C in (("msfe6_en_ddb", 4, 32), ("msfe3_de_ddb", 1, 32), ("ddb", 4, 64)):
+        T_ = 70                                                  # > 2 * 32 frames: every ring wraps
+        xs = rng.standard_normal((T_, F, C)).astype(np.float32)
+        want = _offline_ddb(w, tag, xs)
+        got = []
+        for t in range(T_):
+            ref._new = {}
+            got.append(ref._ddb(torch.from_numpy(xs[t:t + 1]), tag).numpy()[0])
+            ref.state.update(ref._new)
+        assert rms(np.stack(got), want) < 2e-6, tag
+
+
+def test_baseline_topology_matches_reference_signature():
+    # converter_nunet_tls.py:41-249: 104 conv states + 13 x 8 dilated-dense states = 208; 411 904 floats
+    specs = T.state_specs("baseline")
+    assert len(specs) == 208 and T.state_floats_per_stream("baseline") == 411904
+    shapes = {b.format("prev"): s for b, s in specs}
+    assert shapes["msfe6_en_ddb_prev4"] == (8, 4, 64) and shapes["ddb_prev6"] == (32, 4, 192)
+    assert shapes["ddb_prev_in"] == (1, 4, 64) and shapes["msfe3_de_ddb_prev_out"] == (1, 1, 16)
