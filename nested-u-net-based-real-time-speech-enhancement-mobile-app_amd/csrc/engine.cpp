@@ -828,8 +828,8 @@ static int upload_device_plans(Engine* e) {
     e->d_ddb = static_cast<DdbParams*>(t);
   }
   void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, (e->plan[0].size() * 9 + 3) * sizeof(unsigned long long)));   // layer stamps + 8 sub-stamps per layer + 2 clock64
-  HIP_TRY(hipMemset(q, 0, (e->plan[0].size() * 9 + 3) * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&q, (e->plan[0].size() * 9 + 3 + 128) * sizeof(unsigned long long)));   // layer stamps + 8 sub-stamps per layer + 2 clock64 + 16 debug
+  HIP_TRY(hipMemset(q, 0, (e->plan[0].size() * 9 + 3 + 128) * sizeof(unsigned long long)));
   e->allocs.push_back(q);
   e->dprof = static_cast<unsigned long long*>(q);
   return NUTLS_OK;
@@ -838,7 +838,8 @@ static int upload_device_plans(Engine* e) {
 static int run_persistent(Engine* e, int par, hipStream_t s, bool prof) {
   const int grid = e->B;   // one workgroup per stream; the hardware runs as many as fit (1 per CU)
   StepArgs a{e->dplan[par], static_cast<int>(e->plan[par].size()), e->B, e->arena, static_cast<long long>(e->sstride), e->warena,
-             e->io_in, e->io_out, prof ? e->dprof : nullptr, e->d_ddb};
+             e->io_in, e->io_out, prof ? e->dprof : nullptr, e->d_ddb,
+             (prof && getenv("NUTLS_DBG_OP")) ? atoi(getenv("NUTLS_DBG_OP")) : -1};
   hipError_t err = launch_stream_step(a, grid, s);
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("persistent step launch: ") + hipGetErrorString(err));
   if (e->variant == NUTLS_VARIANT_BASELINE) HIP_TRY(launch_incr_step(e->d_step, s));
@@ -1211,6 +1212,16 @@ int nutls_profile_persistent(nutls_handle* h, double* us, int n) {
     if (FILE* f = fopen(dump, "w")) {
       unsigned long long ck[2];
       (void)hipMemcpy(ck, e->dprof + static_cast<size_t>(n_ops) * 9 + 1, sizeof(ck), hipMemcpyDeviceToHost);
+      if (getenv("NUTLS_DBG_OP")) {
+        unsigned long long dg[128];
+        (void)hipMemcpy(dg, e->dprof + static_cast<size_t>(n_ops) * 9 + 3, sizeof(dg), hipMemcpyDeviceToHost);
+        fprintf(f, "# op %s cycle stamps (delta from wave 0 op start):\n", e->plan[par][atoi(getenv("NUTLS_DBG_OP"))].name.c_str());
+        for (int w = 0; w < 8; ++w) {
+          fprintf(f, "#   wave %d: start %lld dec %lld |", w, static_cast<long long>(dg[w * 16 + 15] - dg[15]), static_cast<long long>(dg[w * 16 + 14] - dg[15]));
+          for (int k = 0; k < 12; ++k) fprintf(f, " T%d %lld", k, static_cast<long long>(dg[w * 16 + k] - dg[15]));
+          fprintf(f, "\n");
+        }
+      }
       fprintf(f, "# shader clock: %.0f MHz over the step (%llu cycles in %.1f us)\n",
               static_cast<double>(ck[1] - ck[0]) / (static_cast<double>(t[n_ops] - t[0]) * 1000.0 / khz), ck[1] - ck[0],
               static_cast<double>(t[n_ops] - t[0]) * 1000.0 / khz);

@@ -74,6 +74,8 @@ constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT + MK_LDS_PLAN) * sizeof(
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define MK_STAMP(k) do { if (sub && tid == 0) sub[k] = wall_clock64(); } while (0)
+// fine-grained cycle stamps of ONE chosen op (debug builds of the profile path only)
+#define MK_T(k) do { if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + k] = clock64(); } while (0)
 
 // ---------------------------------------------------------------------------------------------
 //  Compact plan decode (layout: encode_op() in weights.cpp).  All values are wave-uniform; the
@@ -156,45 +158,63 @@ __device__ __forceinline__ int img_addr(const ConvPlan& c, int lr, int c4) {
 //  float4 columns [fwd_lo4, fwd_hi4) of the CURRENT-frame tap are excluded: the producing
 //  layer's epilogue forwards them.
 // ---------------------------------------------------------------------------------------------
-struct ItemAddr { int ph, row, c4, chan4; bool cur; };
-__device__ __forceinline__ ItemAddr item_of(const ConvPlan& c, int q) {
-  ItemAddr a;
+// Item q = tid + 512*i (+ first phase) has disjoint bit fields (float4 column | row | channel chunk |
+// time tap), all sizes powers of two, and tid < 512 <= the step of i: the global offset and the LDS
+// address of an item are (per-lane part, computed once) + (per-pass part, wave-uniform -> SALU).
+struct FwdWin { int lo4, hi4, rmul, radd; bool on; };   // float4 columns [lo4,hi4) of rows (row % rmul == radd) are forwarded
+struct ItemBits { int ph, row, c4, t, ch; };
+__device__ __forceinline__ ItemBits item_bits(const ConvPlan& c, int q) {
+  ItemBits a;
   a.ph = q >> c.n4p_shift;
   const int r = q & ((1 << c.n4p_shift) - 1);
   a.row = r >> c.cc4_shift;
   a.c4 = r & ((1 << c.cc4_shift) - 1);
-  const int t = a.ph >> c.nch_shift, ch = a.ph & ((1 << c.nch_shift) - 1);
-  a.chan4 = (ch << c.cc4_shift) + a.c4;
-  a.cur = (t == c.tt - 1);
+  a.t = a.ph >> c.nch_shift;
+  a.ch = a.ph & ((1 << c.nch_shift) - 1);
   return a;
 }
 
-// phases [ph0, ph0+nphases) of layer (p, c) -> registers
-struct FwdWin { int lo4, hi4, rmul, radd; };   // float4 columns [lo4,hi4) of rows (row % rmul == radd) are forwarded
-__device__ __forceinline__ bool is_fwd(const FwdWin& f, const ItemAddr& a) {
-  return a.cur && a.chan4 >= f.lo4 && a.chan4 < f.hi4 && (a.row & (f.rmul - 1)) == f.radd;
+// what image_load needs of a layer; built with field-wise (scalar) selects where one load site serves two layers
+struct ImgSrc { const float* src0; const float* src1; long long sstride; int ld, n4p_shift, cc4_shift, nch_shift; };
+__device__ __forceinline__ ImgSrc img_src(const ConvParams& p, const ConvPlan& c) {
+  return ImgSrc{p.src0, p.src1, p.sstride, p.src_ld, c.n4p_shift, c.cc4_shift, c.nch_shift};
+}
+__device__ __forceinline__ ItemBits item_bits(const ImgSrc& c, int q) {
+  ItemBits a;
+  a.ph = q >> c.n4p_shift;
+  const int r = q & ((1 << c.n4p_shift) - 1);
+  a.row = r >> c.cc4_shift;
+  a.c4 = r & ((1 << c.cc4_shift) - 1);
+  a.t = a.ph >> c.nch_shift;
+  a.ch = a.ph & ((1 << c.nch_shift) - 1);
+  return a;
 }
 
-__device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& c, int stream, int ph0, int nphases, int tid,
-                                           f32x4 (&pf)[MK_MAXPF]) {
+// phases [ph0, ph0+nphases) of a layer image -> registers
+__device__ __forceinline__ void image_load(const ImgSrc& c, int stream, int ph0, int nphases, int tid, f32x4 (&pf)[MK_MAXPF]) {
+  // (opaque copy: pins the per-lane address arithmetic to this call site -- hoisted out of the
+  //  caller's loops and branches it would run, for all MK_MAXPF items, in layers that never stage)
+  asm volatile("" : "+v"(tid));
   // both time taps live in the same stream slice: one uniform base, the tap picks a 32-bit offset
-  const float* lo = (p.src1 && p.src1 < p.src0) ? p.src1 : p.src0;
-  const float* s0 = lo + static_cast<size_t>(stream) * p.sstride;
-  const unsigned tap0 = static_cast<unsigned>(p.src0 - lo);
-  const unsigned tap1 = p.src1 ? static_cast<unsigned>(p.src1 - lo) : tap0;
-  const unsigned ld = static_cast<unsigned>(p.src_ld);
+  const float* lo = (c.src1 && c.src1 < c.src0) ? c.src1 : c.src0;
+  const float* s0 = lo + static_cast<size_t>(stream) * c.sstride;
+  const unsigned tap0 = static_cast<unsigned>(c.src0 - lo);
+  const unsigned dtap = (c.src1 ? static_cast<unsigned>(c.src1 - lo) : tap0) - tap0;     // (mod 2^32)
+  const unsigned ld = static_cast<unsigned>(c.ld);
   const int n = nphases << c.n4p_shift;
   const int wave_q0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
+  // lanes past the end (only when n < 512) re-load the last item: nothing selects on a pending load
+  const ItemBits l = item_bits(c, tid < n ? tid : n - 1);
+  const unsigned g_lo = tap0 + static_cast<unsigned>(l.t) * dtap + static_cast<unsigned>(l.row) * ld +
+                        4u * static_cast<unsigned>((l.ch << c.cc4_shift) + l.c4);
 #pragma unroll
   for (int i = 0; i < MK_MAXPF; ++i) {
-    // wave-uniform guard (scalar branch); inside, every lane loads -- lanes past the end re-load the
-    // last item, forwarded items are loaded too: nothing selects on a pending load, so no early wait
-    if (wave_q0 + i * MK_THREADS < n) {
-      int q = tid + i * MK_THREADS;
-      q = q < n ? q : n - 1;
-      const ItemAddr a = item_of(c, q + (ph0 << c.n4p_shift));
-      const unsigned off = ((a.ph >> c.nch_shift) == 1 ? tap1 : tap0) + static_cast<unsigned>(a.row) * ld + 4u * static_cast<unsigned>(a.chan4);
-      pf[i] = ld4(s0, off);
+    if (wave_q0 + i * MK_THREADS < n) {       // wave-uniform guard (scalar branch)
+      const ItemBits h = item_bits(c, i * MK_THREADS + (ph0 << c.n4p_shift));           // wave-uniform
+      unsigned g_hi = static_cast<unsigned>(h.t) * dtap + static_cast<unsigned>(h.row) * ld +
+                      4u * static_cast<unsigned>(h.ch << c.cc4_shift);
+      asm volatile("" : "+s"(g_hi));          // stays one SGPR: no re-association with the lane part
+      pf[i] = ld4(s0, g_lo + g_hi);
     }
   }
 }
@@ -202,22 +222,33 @@ __device__ __forceinline__ void image_load(const ConvParams& p, const ConvPlan& 
 // registers -> LDS image (phase ph lands at lds_in + (ph - ph_base) * phase_floats) + zero halo rows
 __device__ __forceinline__ void image_store(const ConvPlan& c, float* lds_in, int ph0, int nphases, int ph_base, const FwdWin& fw,
                                             int tid, const f32x4 (&pf)[MK_MAXPF]) {
+  asm volatile("" : "+v"(tid));
   const int n = nphases << c.n4p_shift;
   const int wave_q0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
+  const ItemBits l = item_bits(c, tid < n ? tid : n - 1);
+  const int l_lo = l.ph * c.phase_floats + img_addr(c, c.padl + l.row, l.c4);
+  const int chan4_lo = (l.ch << c.cc4_shift) + l.c4;
+  const bool fwd_lane = fw.on && (l.row & (fw.rmul - 1)) == fw.radd;
 #pragma unroll
   for (int i = 0; i < MK_MAXPF; ++i) {
-    const int q = tid + i * MK_THREADS;
-    if (wave_q0 + i * MK_THREADS < n && q < n) {
-      const ItemAddr a = item_of(c, q + (ph0 << c.n4p_shift));
-      if (!is_fwd(fw, a)) *reinterpret_cast<f32x4*>(lds_in + (a.ph - ph_base) * c.phase_floats + img_addr(c, c.padl + a.row, a.c4)) = pf[i];
+    if (wave_q0 + i * MK_THREADS < n) {
+      const ItemBits h = item_bits(c, i * MK_THREADS + (ph0 << c.n4p_shift));           // wave-uniform
+      // (h.row is 0 or a multiple of 512 / cc4 >= 32: even, so it moves whole stride-2 row pairs)
+      int l_hi = (h.ph - ph_base) * c.phase_floats + (c.stride == 1 ? h.row : (h.row >> 1)) * c.pitch;
+      asm volatile("" : "+s"(l_hi));
+      // forwarded by the producing layer's epilogue: current-frame tap, float4 columns [lo4,hi4), matching rows
+      const int t = l.t | h.t;
+      const unsigned col = static_cast<unsigned>(chan4_lo + (h.ch << c.cc4_shift) - fw.lo4);
+      const bool skip = fwd_lane && t == c.tt - 1 && col < static_cast<unsigned>(fw.hi4 - fw.lo4);
+      if ((i > 0 || tid < n) && !skip) *reinterpret_cast<f32x4*>(lds_in + l_lo + l_hi) = pf[i];
     }
   }
-  const int hrows = c.rows - c.vrows;                       // <= 3 halo rows per phase
-  const int nh = (hrows * nphases) << c.cc4_shift;          // <= 3 * 4 * 16 = 192 float4
-  if (tid < nh) {
-    const int c4 = tid & ((1 << c.cc4_shift) - 1);
-    const int hr_all = tid >> c.cc4_shift;
-    const int phl = hr_all / hrows, hr = hr_all - phl * hrows;
+  // halo rows (<= 3 per phase, 4 slots): thread -> (phase, slot, float4 column), no division
+  const int hrows = c.rows - c.vrows;
+  const int c4 = tid & ((1 << c.cc4_shift) - 1);
+  const int slot = tid >> c.cc4_shift;
+  const int hr = slot & 3, phl = slot >> 2;
+  if (hr < hrows && phl < nphases) {
     const int lr = hr < c.padl ? hr : c.vrows + hr;         // top halo rows first, then the bottom ones
     // (a zero the compiler cannot hoist out of the layer loop -- it would spill it, and a scratch
     //  reload costs a vmcnt(0) wait right here)
@@ -279,52 +310,24 @@ __device__ __forceinline__ KCursor kcursor_init(const ConvPlan& c, int ks) {
   return k;
 }
 
-// All chunks of round rd for one task (TW = 1 or 2 position tiles, sharing the weight fragments).
-// `hook()` runs once, right after the layer's LAST weight prefetch has been issued: the place for
-// loads that must be younger than every load this loop still waits for (vmcnt retires in order).
-template <int TW, class Hook>
-__device__ __forceinline__ void mfma_round(f32x16 (&acc)[2], f32x4 (&wa)[4], const WeightCursor& wc, int rd, bool last_round,
-                                           const ConvPlan& c, const float* lds_lane0, const float* lds_lane1, int ks, int lane,
-                                           Hook&& hook) {
-  const int nchunks = c.gpk >> 2;
-  KCursor k = kcursor_init(c, ks);
-  gc4_t wp = wc.base + static_cast<size_t>(rd) * wc.round_step;
-#pragma unroll 1
-  for (int ch = 0; ch < nchunks; ++ch) {
-    // prefetch the next chunk: next in this slice, else the first chunk of the next round's slice
-    // (wave-uniform condition -> scalar branch; nothing is fetched after the layer's last chunk)
-    const bool more = (ch + 1 < nchunks) || !last_round;
-    f32x4 wb[4];
-    if (more) {
-      gc4_t np = (ch + 1 < nchunks) ? wp + 4 * wc.wstep : wc.base + static_cast<size_t>(rd + 1) * wc.round_step;
-      load_chunk(wb, np, wc.wstep, lane);
-    }
-    if (last_round && ch + 1 == nchunks) hook();
-    const int koff = (c.stride == 1) ? k.kf * c.pitch : ((k.kf >> 1) * c.pitch + (k.kf & 1) * c.cc);
-    const int boff = k.phl * c.phase_floats + koff + 8 * k.gg;
-    // B fragments: one ds_read_b128 per tile per group, fetched one group ahead of its MFMAs
-    f32x4 b0 = *reinterpret_cast<const f32x4*>(lds_lane0 + boff), b1 = b0;
-    if (TW == 2) b1 = *reinterpret_cast<const f32x4*>(lds_lane1 + boff);
+// The 16 (x TW) MFMAs of one 4-group chunk (TW = 1 or 2 position tiles sharing the weight fragments).
+template <int TW>
+__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[2], const f32x4 (&wa)[4], const float* lds_lane0, const float* lds_lane1, int boff) {
+  // B fragments: one ds_read_b128 per tile per group, fetched one group ahead of its MFMAs
+  f32x4 b0 = *reinterpret_cast<const f32x4*>(lds_lane0 + boff), b1 = b0;
+  if (TW == 2) b1 = *reinterpret_cast<const f32x4*>(lds_lane1 + boff);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const f32x4 c0 = b0, c1 = b1;
-      if (u < 3) {
-        b0 = *reinterpret_cast<const f32x4*>(lds_lane0 + boff + 8 * (u + 1));
-        if (TW == 2) b1 = *reinterpret_cast<const f32x4*>(lds_lane1 + boff + 8 * (u + 1));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], c0[j], acc[0], 0, 0, 0);
-        if (TW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], c1[j], acc[1], 0, 0, 0);
-      }
+  for (int u = 0; u < 4; ++u) {
+    const f32x4 c0 = b0, c1 = b1;
+    if (u < 3) {
+      b0 = *reinterpret_cast<const f32x4*>(lds_lane0 + boff + 8 * (u + 1));
+      if (TW == 2) b1 = *reinterpret_cast<const f32x4*>(lds_lane1 + boff + 8 * (u + 1));
     }
-    if (more) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) wa[u] = wb[u];
+    for (int j = 0; j < 4; ++j) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], c0[j], acc[0], 0, 0, 0);
+      if (TW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], c1[j], acc[1], 0, 0, 0);
     }
-    wp += 4 * wc.wstep;
-    k.gg += 4;
-    if (k.gg == c.gpc) { k.gg = 0; if (++k.kf == c.kf) { k.kf = 0; ++k.phl; } }
   }
 }
 
@@ -381,7 +384,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPla
 //          out: the next layer's first chunk (single static load site -> no copies of pending loads)
 __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& c, bool nconv, const ConvParams& np, const ConvPlan& ncp,
                                            int stream, float* lds_in, float* lds_out, int tid, f32x4 (&wnext)[4], bool& have_w,
-                                           unsigned long long* sub) {
+                                           unsigned long long* sub, unsigned long long* dbg) {
+  MK_T(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SGPR
   const int pl = lane & 31, h = lane >> 5;
@@ -393,7 +397,7 @@ __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& 
   if (pc1 > p.F_out - 1) pc1 = p.F_out - 1;
   const float* lds_lane0 = lds_in + pc0 * c.pitch + 4 * h;
   const float* lds_lane1 = lds_in + pc1 * c.pitch + 4 * h;
-  const FwdWin nofw = {0, 0, 1, 0};
+  const FwdWin nofw = {0, 0, 1, 0, false};
 
   WeightCursor wc;
   wc.wstep = c.nt * 64;
@@ -414,16 +418,17 @@ __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& 
   const int nstage = c.merged ? c.nph : 1;
   if (!c.staged_by_prev) {
     f32x4 pf[MK_MAXPF];
-    image_load(p, c, stream, 0, nstage, tid, pf);
+    image_load(img_src(p, c), stream, 0, nstage, tid, pf);
     image_store(c, lds_in, 0, nstage, 0, nofw, tid, pf);
     lds_barrier();
   }
   MK_STAMP(1);
+  MK_T(2);
 
   // ---- what this layer owes the next one
   const bool hand = nconv && c.hand_next;
   FwdWin fw = nofw;
-  if (hand && c.fwd_sel) { fw.lo4 = c.fwd_coff4; fw.hi4 = c.fwd_coff4 + c.lpg; fw.rmul = c.fwd_rmul; fw.radd = c.fwd_radd; }
+  if (hand && c.fwd_sel) { fw.lo4 = c.fwd_coff4; fw.hi4 = c.fwd_coff4 + c.lpg; fw.rmul = c.fwd_rmul; fw.radd = c.fwd_radd; fw.on = true; }
   const int n_hand = hand ? (ncp.merged ? ncp.nph : 1) : 0;
 
   // Global loads are issued oldest-needed-first (vmcnt retires in order): epilogue parameters, then
@@ -434,32 +439,61 @@ __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& 
   const int li = tid & (lpg - 1);
   const int gi_mine = (c.R == 2) ? ((tid / lpg) & 1) : 0;
   const f32x4 bias = *G4(p.bias + gi_mine * (4 * lpg) + 4 * li);
-  f32x4 gm = bias, bt = bias;
-  if (c.epi_ln) {
-    gm = *G4(p.gamma + 4 * li);
-    bt = *G4(p.beta + 4 * li);
-  }
+  // (always loaded -- a value select on a pending load would wait for it right here; layers without
+  //  LayerNorm re-read the bias)
+  const f32x4 gm = *G4((c.epi_ln ? p.gamma : p.bias) + 4 * li);
+  const f32x4 bt = *G4((c.epi_ln ? p.beta : p.bias) + 4 * li);
   MK_STAMP(6);
+  MK_T(3);
   f32x16 acc[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-  // one register set serves both prefetches: the next phase of THIS layer (rounds before the last)
-  // and, in the last round, the next layer's image rows
+  // One register set and ONE static load site serve both image prefetches -- the next phase of THIS
+  // layer (rounds before the last: issued with the round's first chunk) and, in the last round, the
+  // next layer's image rows (issued right after the layer's last weight prefetch: the youngest loads,
+  // vmcnt retires in order).  Two load sites would meet in phi copies of pending loads, and the copy
+  // costs a full vmcnt(0) wait.
   f32x4 pfx[MK_MAXPF];
-  auto next_image_hook = [&]() {
-    if (hand) image_load(np, ncp, stream, 0, n_hand, tid, pfx);   // youngest loads of the layer
-    MK_STAMP(7);
-  };
-
+  const int nchunks = active ? (c.gpk >> 2) : 1;     // idle waves run one empty chunk per round: they stage too
 #pragma unroll 1
   for (int rd = 0; rd < c.rounds; ++rd) {
     const bool last = rd + 1 == c.rounds;
-    if (!last) image_load(p, c, stream, rd + 1, 1, tid, pfx);       // next phase of THIS layer
-    if (active) {
-      if (c.tw == 2) mfma_round<2>(acc, wa, wc, rd, last, c, lds_lane0, lds_lane1, ks, lane, next_image_hook);
-      else mfma_round<1>(acc, wa, wc, rd, last, c, lds_lane0, lds_lane1, ks, lane, next_image_hook);
-    } else if (last) {
-      next_image_hook();
+    const int hook_ch = last ? nchunks - 1 : 0;
+    KCursor k = kcursor_init(c, ks);
+    gc4_t wp = wc.base + static_cast<size_t>(rd) * wc.round_step;
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ++ch) {
+      // prefetch the next chunk: next in this slice, else the first chunk of the next round's slice
+      // (wave-uniform condition -> scalar branch; nothing is fetched after the layer's last chunk)
+      const bool more = active && ((ch + 1 < nchunks) || !last);
+      f32x4 wb[4];
+      if (more) {
+        gc4_t nxt = (ch + 1 < nchunks) ? wp + 4 * wc.wstep : wc.base + static_cast<size_t>(rd + 1) * wc.round_step;
+        load_chunk(wb, nxt, wc.wstep, lane);
+      }
+      if (ch == hook_ch && (!last || hand)) {
+        ImgSrc is;
+        is.src0 = last ? np.src0 : p.src0; is.src1 = last ? np.src1 : p.src1; is.sstride = p.sstride;
+        is.ld = last ? np.src_ld : p.src_ld;
+        is.n4p_shift = last ? ncp.n4p_shift : c.n4p_shift; is.cc4_shift = last ? ncp.cc4_shift : c.cc4_shift;
+        is.nch_shift = last ? ncp.nch_shift : c.nch_shift;
+        image_load(is, stream, last ? 0 : rd + 1, last ? n_hand : 1, tid, pfx);
+        MK_STAMP(7);
+        MK_T(4);
+      }
+      if (active) {
+        const int koff = (c.stride == 1) ? k.kf * c.pitch : ((k.kf >> 1) * c.pitch + (k.kf & 1) * c.cc);
+        const int boff = k.phl * c.phase_floats + koff + 8 * k.gg;
+        if (c.tw == 2) chunk_mfma<2>(acc, wa, lds_lane0, lds_lane1, boff);
+        else chunk_mfma<1>(acc, wa, lds_lane0, lds_lane1, boff);
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wa[u] = wb[u];
+      }
+      wp += 4 * wc.wstep;
+      k.gg += 4;
+      if (k.gg == c.gpc) { k.gg = 0; if (++k.kf == c.kf) { k.kf = 0; ++k.phl; } }
     }
     if (!last) {
       lds_barrier();             // every wave is done reading this phase's LDS rows
@@ -467,6 +501,7 @@ __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& 
       lds_barrier();
     }
   }
+  MK_T(5);
   {   // next layer's first weight chunk (single load site; a layer with no conv successor re-reads its own)
     // (field-wise selects: a reference/pointer select between the two structs would force both to memory)
     const float* nw = nconv ? np.wpk : p.wpk;
@@ -479,6 +514,7 @@ __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& 
     have_w = nconv;
   }
   MK_STAMP(2);
+  MK_T(6);
 
   // ---- partial tiles -> LDS exchange buffer [ks][pos][32*NT (+4)]
   if (active) {
@@ -494,8 +530,10 @@ __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& 
       }
     }
   }
+  MK_T(7);
   lds_barrier();                 // also: every wave has finished reading lds_in
   MK_STAMP(3);
+  MK_T(8);
 
   const bool do_fwd = hand && c.fwd_sel;
   if (c.epi_ln) {
@@ -505,11 +543,14 @@ __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& 
     if (c.g == 2) conv_epilogue<16, false>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
     else conv_epilogue<32, false>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
   }
+  MK_T(9);
   // ---- hand-off: the prefetched part of the next layer's image (the forwarded rows were written above)
   if (hand) image_store(ncp, lds_in, 0, n_hand, 0, fw, tid, pfx);
   MK_STAMP(4);
+  MK_T(10);
   __syncthreads();               // HBM stores visible to the workgroup; next image complete; exchange buffer free
   MK_STAMP(5);
+  MK_T(11);
 }
 
 __device__ __forceinline__ float mk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -568,7 +609,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
   }
   // ---- next conv layer's image rows this op does not produce
   f32x4 pfx[MK_MAXPF];
-  if (hand) image_load(np, ncp, stream, 0, ncp.nph, tid, pfx);
+  if (hand) image_load(img_src(np, ncp), stream, 0, ncp.nph, tid, pfx);
 
   if (mv) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -607,7 +648,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
     if (hand) img_put1(ncp, lds_in, f, fwd_coff + c, a);
   }
   if (hand) {
-    const FwdWin fw = {fwd_coff >> 2, (fwd_coff + p.dst_cols) >> 2, 1, 0};
+    const FwdWin fw = {fwd_coff >> 2, (fwd_coff + p.dst_cols) >> 2, 1, 0, true};
     image_store(ncp, lds_in, 0, ncp.nph, 0, fw, tid, pfx);
   }
   __syncthreads();
@@ -619,7 +660,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
 __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, float* lds, float* lds_in, int tid, bool hand, int fwd_coff,
                                            const ConvParams& np, const ConvPlan& ncp) {
   f32x4 pfx[MK_MAXPF];
-  if (hand) image_load(np, ncp, stream, 0, ncp.nph, tid, pfx);
+  if (hand) image_load(img_src(np, ncp), stream, 0, ncp.nph, tid, pfx);
   float* part = lds;               // [32][64]
   float* m = lds + 4096;           // [64]
   float* hid = m + 64;             // [16]
@@ -693,7 +734,7 @@ __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, floa
     if (hand) img_put4(ncp, lds_in, f, (fwd_coff >> 2) + c4, yv);
   }
   if (hand) {
-    const FwdWin fw = {fwd_coff >> 2, (fwd_coff >> 2) + 16, 1, 0};
+    const FwdWin fw = {fwd_coff >> 2, (fwd_coff >> 2) + 16, 1, 0, true};
     image_store(ncp, lds_in, 0, ncp.nph, 0, fw, tid, pfx);
   }
   __syncthreads();
@@ -790,10 +831,13 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
       const int nc_coff = b1(cur.w[22]);
       if (op == DEV_OP_CONV) {
         unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
+        unsigned long long* dbg = (sub && i == a.dbg_op) ? prof + n_ops * 9 + 3 : nullptr;
+        if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 15] = clock64();
         ConvParams p;
         ConvPlan c;
         decode_conv(cur, a, p, c);
-        conv_layer(p, c, nconv, np, ncp, stream, lds_in, lds_out, tid, wnext, have_w, sub);
+        if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 14] = clock64();
+        conv_layer(p, c, nconv, np, ncp, stream, lds_in, lds_out, tid, wnext, have_w, sub, dbg);
       } else {
         if (op == DEV_OP_LSTM) {
           LstmParams p;

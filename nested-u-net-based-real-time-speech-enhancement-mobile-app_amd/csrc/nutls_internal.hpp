@@ -203,6 +203,7 @@ struct StepArgs {            // kernel arguments of the persistent kernel
   float* io_out;             // [B,256]
   unsigned long long* prof;  // nullable
   const DdbParams* ddb;      // baseline variant: table of the 13 dilated-dense blocks (else null)
+  int dbg_op;                // profiling: op index whose inner cycle stamps are recorded (-1: none)
 };
 CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase);
 hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s);

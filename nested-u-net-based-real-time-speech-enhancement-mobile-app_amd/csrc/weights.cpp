@@ -121,6 +121,8 @@ ConvPlan make_conv_plan(ConvKind k, const ConvParams& p) {
   c.merged = (c.nph * c.phase_floats <= MK_LDS_IN_FLOATS) && (c.nph * (c.vrows * (c.cc / 4)) <= MK_STAGE_ITEMS);
   const int nstage = c.merged ? c.nph : 1;
   c.rounds = c.nph / nstage;
+  // the staging code splits an item index into lane bits and pass bits: a phase-by-phase layer must start every phase on a 512 boundary
+  if (c.rounds > 1 && c.n4p_shift < 9) throw std::runtime_error("conv plan: unmerged layer with < 512 items per phase");
   c.gpc = c.cc / 8;
   c.RG = nstage * sh.kf * c.gpc;
   c.PT = (p.F_out + 31) / 32;
