@@ -66,8 +66,7 @@ constexpr int MK_THREADS = 64 * MK_WAVES;
 constexpr int MK_MAXPF = MK_STAGE_ITEMS / MK_THREADS;   // float4 prefetch registers per thread (8)
 constexpr int MK_LDS_IN = MK_LDS_IN_FLOATS;
 constexpr int MK_LDS_OUT = 16 * 32 * 36;      // floats: 16 tasks x 32 positions x (32+4)
-constexpr int MK_LDS_PLAN = MK_MAX_OPS * MK_OP_WORDS;   // dwords: the whole compact plan
-constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT + MK_LDS_PLAN) * sizeof(float);
+constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT) * sizeof(float);
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does NOT drain vmcnt,
 // so global loads issued earlier (next layer's image rows, weight fragments) stay in flight across it.
@@ -78,21 +77,20 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define MK_T(k) do { if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + k] = clock64(); } while (0)
 
 // ---------------------------------------------------------------------------------------------
-//  Compact plan decode (layout: encode_op() in weights.cpp).  All values are wave-uniform; the
-//  readfirstlane moves them to SGPRs so the layer code branches and addresses on scalars.
+//  Compact plan (layout: encode_op() in weights.cpp).  Ops are read with scalar loads straight into
+//  SGPRs (constant address space, wave-uniform index) and conv fields are extracted where they are
+//  used: a bit-field extract is one SALU instruction, an eagerly decoded struct is ~70 live SGPRs
+//  per op and a v_readlane / v_writelane spill pair for most of them.  All conv offsets are BYTES
+//  from the stream slice (`sb`) or the weight arena (`wb`): every global access is
+//  "SGPR base + 32-bit VGPR offset", no 64-bit arithmetic.
 // ---------------------------------------------------------------------------------------------
 struct OpWords { unsigned w[MK_OP_WORDS]; };
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const unsigned __attribute__((address_space(4))) * cplan_t;
 
-__device__ __forceinline__ OpWords load_op(const unsigned* lds_plan, int i) {
+__device__ __forceinline__ OpWords load_op(cplan_t plan, int i) {
   OpWords o;
-  const u32x4* q = reinterpret_cast<const u32x4*>(lds_plan + i * MK_OP_WORDS);
 #pragma unroll
-  for (int k = 0; k < MK_OP_WORDS / 4; ++k) {
-    const u32x4 v = q[k];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o.w[4 * k + j] = __builtin_amdgcn_readfirstlane(v[j]);
-  }
+  for (int k = 0; k < MK_OP_WORDS; ++k) o.w[k] = plan[i * MK_OP_WORDS + k];
   return o;
 }
 __device__ __forceinline__ int b0(unsigned w) { return w & 255; }
@@ -104,30 +102,24 @@ __device__ __forceinline__ int h1(unsigned w) { return w >> 16; }
 __device__ __forceinline__ float* aptr(float* base, unsigned off) { return off == MK_NULL_OFF ? nullptr : base + off; }
 __device__ __forceinline__ const float* wptr(const float* base, unsigned off) { return off == MK_NULL_OFF ? nullptr : base + off; }
 
-__device__ __forceinline__ void decode_conv(const OpWords& o, const StepArgs& a, ConvParams& p, ConvPlan& c) {
-  p.src0 = aptr(a.arena, o.w[0]); p.src1 = aptr(a.arena, o.w[1]);
-  p.dst0 = aptr(a.arena, o.w[2]); p.dst1 = aptr(a.arena, o.w[3]);
-  p.wpk = wptr(a.wbase, o.w[4]); p.bias = wptr(a.wbase, o.w[5]); p.gamma = wptr(a.wbase, o.w[6]); p.beta = wptr(a.wbase, o.w[7]);
-  p.alpha = __uint_as_float(o.w[8]);
-  p.src_ld = b0(o.w[9]); p.ld0 = b1(o.w[9]); p.ld1 = b2(o.w[9]);
-  const int fl = b3(o.w[9]);
-  p.row_mul = fl & 3; p.row_add = (fl >> 2) & 1;
-  c.stride = ((fl >> 3) & 1) + 1; c.tt = ((fl >> 4) & 1) + 1; c.epi_ln = (fl >> 5) & 1; c.merged = (fl >> 6) & 1;
-  c.staged_by_prev = (fl >> 7) & 1;
-  p.F_in = h0(o.w[10]); p.F_out = h1(o.w[10]);
-  p.B = a.B; p.sstride = a.sstride; p.log2_fout = 0;
-  c.kf = b0(o.w[11]); c.padl = b1(o.w[11]); c.g = b2(o.w[11]); c.nt = b3(o.w[11]);
-  c.cc = b0(o.w[12]); c.cc4_shift = b1(o.w[12]); c.n4p_shift = b2(o.w[12]); c.nch_shift = b3(o.w[12]);
-  c.pitch = h0(o.w[13]); c.rows = h1(o.w[13]);
-  c.vrows = h0(o.w[14]); c.nph = b2(o.w[14]); c.rounds = b3(o.w[14]);
-  c.phase_floats = h0(o.w[15]); c.slot_floats = h1(o.w[15]);
-  c.RG = b0(o.w[16]); c.KS = b1(o.w[16]); c.gpk = b2(o.w[16]); c.gpc = b3(o.w[16]);
-  c.PT = b0(o.w[17]); c.tiles = b1(o.w[17]); c.nt_shift = b2(o.w[17]); c.tw = b3(o.w[17]);
-  c.tasks = b0(o.w[18]); c.tasks_shift = b1(o.w[18]); c.opitch = h1(o.w[18]);
-  c.R = b0(o.w[19]); c.lpg = b1(o.w[19]); c.hand_next = b2(o.w[19]); c.fwd_sel = b3(o.w[19]);
-  c.fwd_coff4 = b0(o.w[20]); c.fwd_rmul = b1(o.w[20]); c.fwd_radd = b2(o.w[20]); c.cin = b3(o.w[20]);
-  c.pf_phase0_ready = 0; c.pre_next_phase0 = 0;
-}
+// conv op fields
+#define CV(name, expr) __device__ __forceinline__ int cv_##name(const OpWords& o) { return (expr); }
+CV(src_ld_b, h0(o.w[9]))   CV(ld0_b, h1(o.w[9]))   CV(ld1_b, h0(o.w[10]))
+CV(row_mul, (o.w[10] >> 16) & 3)   CV(row_add, (o.w[10] >> 18) & 1)   CV(stride2, (o.w[10] >> 19) & 1)   CV(tt2, (o.w[10] >> 20) & 1)
+CV(epi_ln, (o.w[10] >> 21) & 1)    CV(merged, (o.w[10] >> 22) & 1)    CV(staged_by_prev, (o.w[10] >> 23) & 1)
+CV(hand_next, (o.w[10] >> 24) & 1) CV(fwd_sel, (o.w[10] >> 25) & 1)   CV(fwd_rmul2, (o.w[10] >> 26) & 1)   CV(fwd_radd, (o.w[10] >> 27) & 1)
+CV(R2, (o.w[10] >> 28) & 1)        CV(has_dst1, (o.w[10] >> 29) & 1)  CV(gcode, o.w[10] >> 30)
+CV(F_in, h0(o.w[11]))      CV(F_out, h1(o.w[11]))
+CV(kf, b0(o.w[12]))        CV(padl, b1(o.w[12]))       CV(lpg, b2(o.w[12]))        CV(nt, b3(o.w[12]))
+CV(cc4_shift, b0(o.w[13])) CV(n4p_shift, b1(o.w[13]))  CV(nch_shift, b2(o.w[13]))  CV(nt_shift, b3(o.w[13]))
+CV(pitch_b, h0(o.w[14]))   CV(rows, h1(o.w[14]))
+CV(vrows, h0(o.w[15]))     CV(nph, b2(o.w[15]))        CV(rounds, b3(o.w[15]))
+CV(phase_b, o.w[16])       CV(slot_b, o.w[17])
+CV(RG, b0(o.w[18]))        CV(KS, b1(o.w[18]))         CV(gpk, b2(o.w[18]))        CV(gpc, b3(o.w[18]))
+CV(tasks, b0(o.w[19]))     CV(tasks_shift, b1(o.w[19])) CV(tw, b2(o.w[19]))        CV(fwd_coff4, b3(o.w[19]))
+CV(opitch_b, h0(o.w[20]))  CV(units, h1(o.w[20]))
+#undef CV
+__device__ __forceinline__ int cv_cc_b(const OpWords& o) { return 16 << cv_cc4_shift(o); }      // bytes of one channel chunk
 
 __device__ __forceinline__ void decode_lstm(const OpWords& o, const StepArgs& a, LstmParams& p) {
   p.x = aptr(a.arena, o.w[0]); p.x_ld = h0(o.w[1]); p.x_cols = h1(o.w[1]); p.x_rows = 0;
@@ -146,386 +138,392 @@ __device__ __forceinline__ void decode_ctfa(const OpWords& o, const StepArgs& a,
   p.F = static_cast<int>(o.w[12]); p.B = a.B; p.sstride = a.sstride;
 }
 
-// LDS float offset of (image row lr, float4 column c4) inside one phase
-__device__ __forceinline__ int img_addr(const ConvPlan& c, int lr, int c4) {
-  return c.stride == 1 ? lr * c.pitch + 4 * c4 : (lr >> 1) * c.pitch + (lr & 1) * c.cc + 4 * c4;
+// global / LDS accesses by byte offset
+__device__ __forceinline__ f32x4 ldb(gcb_t base, unsigned boff) { return *(gc4_t)(base + static_cast<unsigned long long>(boff)); }
+__device__ __forceinline__ void stb(gcb_t base, unsigned boff, f32x4 v) {
+  *(g4_t)((gb_t)(unsigned long long)base + static_cast<unsigned long long>(boff)) = v;
+}
+__device__ __forceinline__ f32x4& lds4(float* base, int boff) { return *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + boff); }
+__device__ __forceinline__ float& lds1(float* base, int boff) { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff); }
+
+// LDS byte offset of (image row lr, float4 column c4) inside one phase
+__device__ __forceinline__ int img_addr_b(const OpWords& o, int lr, int c4) {
+  const int pitch = cv_pitch_b(o);
+  return cv_stride2(o) ? (lr >> 1) * pitch + (lr & 1) * cv_cc_b(o) + 16 * c4 : lr * pitch + 16 * c4;
 }
 
 // ---------------------------------------------------------------------------------------------
 //  Staging of a layer's LDS image through registers.  Item q (float4) -> (phase, row, column):
 //  phase = (time tap t, channel chunk ch); only rows that exist in the stream travel through
 //  registers, halo rows are zero-filled (ZeroPadding2D of proposed.py:210/:242, SAME pad of :255).
-//  float4 columns [fwd_lo4, fwd_hi4) of the CURRENT-frame tap are excluded: the producing
+//  Item q = tid + 512*i (+ first phase) has disjoint bit fields (float4 column | row | channel chunk |
+//  time tap), all sizes powers of two, and tid < 512 <= the step of i: the global offset and the LDS
+//  address of an item are (per-lane part, computed once) + (per-pass part, wave-uniform -> SALU).
+//  float4 columns [lo4, hi4) of the CURRENT-frame tap can be excluded from the store: the producing
 //  layer's epilogue forwards them.
 // ---------------------------------------------------------------------------------------------
-// Item q = tid + 512*i (+ first phase) has disjoint bit fields (float4 column | row | channel chunk |
-// time tap), all sizes powers of two, and tid < 512 <= the step of i: the global offset and the LDS
-// address of an item are (per-lane part, computed once) + (per-pass part, wave-uniform -> SALU).
 struct FwdWin { int lo4, hi4, rmul, radd; bool on; };   // float4 columns [lo4,hi4) of rows (row % rmul == radd) are forwarded
+struct ImgSrc { unsigned src0, dtap, ld; int n4p_shift, cc4_shift, nch_shift; };   // what image_load needs of a layer
+__device__ __forceinline__ ImgSrc img_src(const OpWords& o) {
+  return ImgSrc{o.w[0], o.w[1], static_cast<unsigned>(cv_src_ld_b(o)), cv_n4p_shift(o), cv_cc4_shift(o), cv_nch_shift(o)};
+}
 struct ItemBits { int ph, row, c4, t, ch; };
-__device__ __forceinline__ ItemBits item_bits(const ConvPlan& c, int q) {
+__device__ __forceinline__ ItemBits item_bits(int n4p_shift, int cc4_shift, int nch_shift, int q) {
   ItemBits a;
-  a.ph = q >> c.n4p_shift;
-  const int r = q & ((1 << c.n4p_shift) - 1);
-  a.row = r >> c.cc4_shift;
-  a.c4 = r & ((1 << c.cc4_shift) - 1);
-  a.t = a.ph >> c.nch_shift;
-  a.ch = a.ph & ((1 << c.nch_shift) - 1);
+  a.ph = q >> n4p_shift;
+  const int r = q & ((1 << n4p_shift) - 1);
+  a.row = r >> cc4_shift;
+  a.c4 = r & ((1 << cc4_shift) - 1);
+  a.t = a.ph >> nch_shift;
+  a.ch = a.ph & ((1 << nch_shift) - 1);
   return a;
 }
 
-// what image_load needs of a layer; built with field-wise (scalar) selects where one load site serves two layers
-struct ImgSrc { const float* src0; const float* src1; long long sstride; int ld, n4p_shift, cc4_shift, nch_shift; };
-__device__ __forceinline__ ImgSrc img_src(const ConvParams& p, const ConvPlan& c) {
-  return ImgSrc{p.src0, p.src1, p.sstride, p.src_ld, c.n4p_shift, c.cc4_shift, c.nch_shift};
-}
-__device__ __forceinline__ ItemBits item_bits(const ImgSrc& c, int q) {
-  ItemBits a;
-  a.ph = q >> c.n4p_shift;
-  const int r = q & ((1 << c.n4p_shift) - 1);
-  a.row = r >> c.cc4_shift;
-  a.c4 = r & ((1 << c.cc4_shift) - 1);
-  a.t = a.ph >> c.nch_shift;
-  a.ch = a.ph & ((1 << c.nch_shift) - 1);
-  return a;
-}
-
-// phases [ph0, ph0+nphases) of a layer image -> registers
-__device__ __forceinline__ void image_load(const ImgSrc& c, int stream, int ph0, int nphases, int tid, f32x4 (&pf)[MK_MAXPF]) {
+// phases [ph0, ph0+nphases) of a layer image -> registers.  Pass 0 is unconditional (every image has
+// one); passes 1..7 exist only in images of more than 512 float4 and their (scalar) address parts are
+// computed behind the guards.
+__device__ __forceinline__ void image_load(const ImgSrc& c, gcb_t sb, int ph0, int nphases, int tid, f32x4 (&pf)[MK_MAXPF]) {
   // (opaque copy: pins the per-lane address arithmetic to this call site -- hoisted out of the
-  //  caller's loops and branches it would run, for all MK_MAXPF items, in layers that never stage)
+  //  caller's loops and branches it would run in layers that never stage)
   asm volatile("" : "+v"(tid));
-  // both time taps live in the same stream slice: one uniform base, the tap picks a 32-bit offset
-  const float* lo = (c.src1 && c.src1 < c.src0) ? c.src1 : c.src0;
-  const float* s0 = lo + static_cast<size_t>(stream) * c.sstride;
-  const unsigned tap0 = static_cast<unsigned>(c.src0 - lo);
-  const unsigned dtap = (c.src1 ? static_cast<unsigned>(c.src1 - lo) : tap0) - tap0;     // (mod 2^32)
-  const unsigned ld = static_cast<unsigned>(c.ld);
   const int n = nphases << c.n4p_shift;
   const int wave_q0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
   // lanes past the end (only when n < 512) re-load the last item: nothing selects on a pending load
-  const ItemBits l = item_bits(c, tid < n ? tid : n - 1);
-  const unsigned g_lo = tap0 + static_cast<unsigned>(l.t) * dtap + static_cast<unsigned>(l.row) * ld +
-                        4u * static_cast<unsigned>((l.ch << c.cc4_shift) + l.c4);
+  const ItemBits l = item_bits(c.n4p_shift, c.cc4_shift, c.nch_shift, tid < n ? tid : n - 1);
+  const unsigned g_lo = c.src0 + static_cast<unsigned>(l.t) * c.dtap + static_cast<unsigned>(l.row) * c.ld +
+                        16u * static_cast<unsigned>((l.ch << c.cc4_shift) + l.c4);
 #pragma unroll
   for (int i = 0; i < MK_MAXPF; ++i) {
-    if (wave_q0 + i * MK_THREADS < n) {       // wave-uniform guard (scalar branch)
-      const ItemBits h = item_bits(c, i * MK_THREADS + (ph0 << c.n4p_shift));           // wave-uniform
-      unsigned g_hi = static_cast<unsigned>(h.t) * dtap + static_cast<unsigned>(h.row) * ld +
-                      4u * static_cast<unsigned>(h.ch << c.cc4_shift);
-      asm volatile("" : "+s"(g_hi));          // stays one SGPR: no re-association with the lane part
-      pf[i] = ld4(s0, g_lo + g_hi);
+    if (i == 0 || (n > MK_THREADS && wave_q0 + i * MK_THREADS < n)) {       // wave-uniform guard (scalar branch)
+      int qh = i * MK_THREADS + (ph0 << c.n4p_shift);
+      if (i > 0) asm volatile("" : "+s"(qh));     // not speculated above the guard
+      const ItemBits h = item_bits(c.n4p_shift, c.cc4_shift, c.nch_shift, qh);          // wave-uniform
+      unsigned g_hi = static_cast<unsigned>(h.t) * c.dtap + static_cast<unsigned>(h.row) * c.ld +
+                      16u * static_cast<unsigned>(h.ch << c.cc4_shift);
+      asm volatile("" : "+s"(g_hi));              // stays one SGPR: no re-association with the lane part
+      pf[i] = ldb(sb, g_lo + g_hi);
     }
   }
 }
 
-// registers -> LDS image (phase ph lands at lds_in + (ph - ph_base) * phase_floats) + zero halo rows
-__device__ __forceinline__ void image_store(const ConvPlan& c, float* lds_in, int ph0, int nphases, int ph_base, const FwdWin& fw,
+// registers -> LDS image of layer o (phase ph lands at lds_in + (ph - ph_base) * phase bytes) + zero halo rows
+__device__ __forceinline__ void image_store(const OpWords& o, float* lds_in, int ph0, int nphases, int ph_base, const FwdWin& fw,
                                             int tid, const f32x4 (&pf)[MK_MAXPF]) {
   asm volatile("" : "+v"(tid));
-  const int n = nphases << c.n4p_shift;
+  const int n4p_shift = cv_n4p_shift(o), cc4_shift = cv_cc4_shift(o), nch_shift = cv_nch_shift(o);
+  const int n = nphases << n4p_shift;
   const int wave_q0 = __builtin_amdgcn_readfirstlane(tid) & ~63;
-  const ItemBits l = item_bits(c, tid < n ? tid : n - 1);
-  const int l_lo = l.ph * c.phase_floats + img_addr(c, c.padl + l.row, l.c4);
-  const int chan4_lo = (l.ch << c.cc4_shift) + l.c4;
+  const int phase_b = cv_phase_b(o), padl = cv_padl(o);
+  const ItemBits l = item_bits(n4p_shift, cc4_shift, nch_shift, tid < n ? tid : n - 1);
+  const int l_lo = l.ph * phase_b + img_addr_b(o, padl + l.row, l.c4);
+  const int chan4_lo = (l.ch << cc4_shift) + l.c4;
   const bool fwd_lane = fw.on && (l.row & (fw.rmul - 1)) == fw.radd;
+  const int t_cur = cv_tt2(o);
 #pragma unroll
   for (int i = 0; i < MK_MAXPF; ++i) {
-    if (wave_q0 + i * MK_THREADS < n) {
-      const ItemBits h = item_bits(c, i * MK_THREADS + (ph0 << c.n4p_shift));           // wave-uniform
+    if (i == 0 || (n > MK_THREADS && wave_q0 + i * MK_THREADS < n)) {
+      int qh = i * MK_THREADS + (ph0 << n4p_shift);
+      if (i > 0) asm volatile("" : "+s"(qh));
+      const ItemBits h = item_bits(n4p_shift, cc4_shift, nch_shift, qh);               // wave-uniform
       // (h.row is 0 or a multiple of 512 / cc4 >= 32: even, so it moves whole stride-2 row pairs)
-      int l_hi = (h.ph - ph_base) * c.phase_floats + (c.stride == 1 ? h.row : (h.row >> 1)) * c.pitch;
+      int l_hi = (h.ph - ph_base) * phase_b + (cv_stride2(o) ? (h.row >> 1) : h.row) * cv_pitch_b(o);
       asm volatile("" : "+s"(l_hi));
       // forwarded by the producing layer's epilogue: current-frame tap, float4 columns [lo4,hi4), matching rows
       const int t = l.t | h.t;
-      const unsigned col = static_cast<unsigned>(chan4_lo + (h.ch << c.cc4_shift) - fw.lo4);
-      const bool skip = fwd_lane && t == c.tt - 1 && col < static_cast<unsigned>(fw.hi4 - fw.lo4);
-      if ((i > 0 || tid < n) && !skip) *reinterpret_cast<f32x4*>(lds_in + l_lo + l_hi) = pf[i];
+      const unsigned col = static_cast<unsigned>(chan4_lo + (h.ch << cc4_shift) - fw.lo4);
+      const bool skip = fwd_lane && t == t_cur && col < static_cast<unsigned>(fw.hi4 - fw.lo4);
+      if ((i > 0 || tid < n) && !skip) lds4(lds_in, l_lo + l_hi) = pf[i];
     }
   }
   // halo rows (<= 3 per phase, 4 slots): thread -> (phase, slot, float4 column), no division
-  const int hrows = c.rows - c.vrows;
-  const int c4 = tid & ((1 << c.cc4_shift) - 1);
-  const int slot = tid >> c.cc4_shift;
+  const int vrows = cv_vrows(o);
+  const int hrows = cv_rows(o) - vrows;
+  const int c4 = tid & ((1 << cc4_shift) - 1);
+  const int slot = tid >> cc4_shift;
   const int hr = slot & 3, phl = slot >> 2;
   if (hr < hrows && phl < nphases) {
-    const int lr = hr < c.padl ? hr : c.vrows + hr;         // top halo rows first, then the bottom ones
+    const int lr = hr < padl ? hr : vrows + hr;         // top halo rows first, then the bottom ones
     // (a zero the compiler cannot hoist out of the layer loop -- it would spill it, and a scratch
     //  reload costs a vmcnt(0) wait right here)
     float zf = 0.f;
     asm volatile("" : "+v"(zf));
     const f32x4 z = {zf, zf, zf, zf};
-    *reinterpret_cast<f32x4*>(lds_in + (ph0 - ph_base + phl) * c.phase_floats + img_addr(c, lr, c4)) = z;
+    lds4(lds_in, (ph0 - ph_base + phl) * phase_b + img_addr_b(o, lr, c4)) = z;
   }
 }
 
 // Direct writes into the NEXT layer's LDS image (current-frame tap): a float4 column / a single channel of row `row`
-__device__ __forceinline__ void img_put4(const ConvPlan& n, float* lds_in, int row, int chan4, f32x4 v) {
-  const int ph = ((n.tt - 1) << n.nch_shift) + (chan4 >> n.cc4_shift);
-  *reinterpret_cast<f32x4*>(lds_in + ph * n.phase_floats + img_addr(n, n.padl + row, chan4 & ((1 << n.cc4_shift) - 1))) = v;
+__device__ __forceinline__ void img_put4(const OpWords& n, float* lds_in, int row, int chan4, f32x4 v) {
+  const int cc4_shift = cv_cc4_shift(n);
+  const int ph = (cv_tt2(n) << cv_nch_shift(n)) + (chan4 >> cc4_shift);
+  lds4(lds_in, ph * cv_phase_b(n) + img_addr_b(n, cv_padl(n) + row, chan4 & ((1 << cc4_shift) - 1))) = v;
 }
-__device__ __forceinline__ void img_put1(const ConvPlan& n, float* lds_in, int row, int chan, float v) {
+__device__ __forceinline__ void img_put1(const OpWords& n, float* lds_in, int row, int chan, float v) {
   const int chan4 = chan >> 2;
-  const int ph = ((n.tt - 1) << n.nch_shift) + (chan4 >> n.cc4_shift);
-  lds_in[ph * n.phase_floats + img_addr(n, n.padl + row, chan4 & ((1 << n.cc4_shift) - 1)) + (chan & 3)] = v;
+  const int cc4_shift = cv_cc4_shift(n);
+  const int ph = (cv_tt2(n) << cv_nch_shift(n)) + (chan4 >> cc4_shift);
+  lds1(lds_in, ph * cv_phase_b(n) + img_addr_b(n, cv_padl(n) + row, chan4 & ((1 << cc4_shift) - 1)) + 4 * (chan & 3)) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
-//  MFMA part of one round of one task.  4-group chunks: the next chunk's 4 weight fragments
-//  (1 KiB per wave load, L2) are in flight while the current chunk's 16 MFMAs issue.
+//  What travels in registers from op to op: the next conv layer's first weight chunk (this wave's
+//  task) and its epilogue parameters (this lane's float4 of bias / gamma / beta).  Fetched while
+//  the current op runs its epilogue, complete at the op boundary.
 // ---------------------------------------------------------------------------------------------
-struct WeightCursor {   // wave-uniform
-  gc4_t base;           // packed weights + (k-slice, channel tile) offset of this task, round 0
-  int wstep;            // float4 between consecutive groups (NT * 64)
-  int round_step;       // float4 between consecutive rounds of this task (RG * wstep)
-};
+struct Carry { f32x4 w[4]; f32x4 e[3]; };
 
-__device__ __forceinline__ void load_chunk(f32x4 (&w)[4], gc4_t ptr, int wstep, int lane) {
-  // ptr is wave-uniform; the per-lane part is a 32-bit byte offset
+__device__ __forceinline__ void prefetch_conv(const OpWords& n, gcb_t wb, int wave, int tid, Carry& cy) {
+  const int nt = cv_nt(n);
+  const bool act = wave < cv_tasks(n) * cv_KS(n);
+  const int ks = act ? (wave >> cv_tasks_shift(n)) : 0;
+  const int ntile = act ? (wave & (nt - 1)) : 0;
+  const unsigned w0 = n.w[4] + static_cast<unsigned>(ks * cv_gpk(n) * nt + ntile) * 1024u;      // wave-uniform
+  const unsigned wstep_b = static_cast<unsigned>(nt) << 10;
+  const unsigned lane16 = static_cast<unsigned>(tid & 63) * 16u;
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
-    w[u] = *(gc4_t)((gcb_t)ptr + static_cast<unsigned long long>(static_cast<unsigned>(u * wstep + lane) * 16u));
-}
-
-// first weight chunk of the next conv layer for this wave's task (single static load site per op kind)
-__device__ __forceinline__ void load_next_weights(const ConvParams& np, const ConvPlan& ncp, int wave, int lane, f32x4 (&wnext)[4]) {
-  const bool nact = wave < ncp.tasks * ncp.KS;
-  const int nks = nact ? (wave >> ncp.tasks_shift) : 0;
-  const int nnt = nact ? (wave & (ncp.nt - 1)) : 0;
-  load_chunk(wnext, (gc4_t)(unsigned long long)np.wpk + (static_cast<size_t>(nks * ncp.gpk) * ncp.nt + nnt) * 64, ncp.nt * 64, lane);
+  for (int u = 0; u < 4; ++u) cy.w[u] = ldb(wb, w0 + u * wstep_b + lane16);
+  const int lpg = cv_lpg(n);
+  const unsigned li16 = static_cast<unsigned>(tid & (lpg - 1)) * 16u;
+  const unsigned gi = cv_R2(n) ? static_cast<unsigned>((tid >> (3 + cv_gcode(n))) & 1) : 0u;     // lpg = 8 << gcode
+  cy.e[0] = ldb(wb, n.w[5] + gi * static_cast<unsigned>(lpg * 16) + li16);
+  cy.e[1] = ldb(wb, n.w[6] + li16);      // (layers without LayerNorm: gamma = beta = bias offset)
+  cy.e[2] = ldb(wb, n.w[7] + li16);
 }
 
 // cursor over the resident image for one task: (local phase, frequency tap, channel group), wave-uniform
 struct KCursor { int phl, kf, gg; };
 
-__device__ __forceinline__ KCursor kcursor_init(const ConvPlan& c, int ks) {
+__device__ __forceinline__ KCursor kcursor_init(const OpWords& o, int ks) {
   // (no integer divisions: gpc is 4 or 8, kf is 1, 2 or 3, seg < 64)
-  const int g_first = ks * c.gpk;
-  const int gshift = c.gpc == 8 ? 3 : 2;
+  const int gpc = cv_gpc(o), kf = cv_kf(o);
+  const int g_first = ks * cv_gpk(o);
+  const int gshift = gpc == 8 ? 3 : 2;
   const int seg = g_first >> gshift;
   KCursor k;
-  k.gg = g_first & (c.gpc - 1);
-  k.phl = c.kf == 3 ? ((seg * 43) >> 7) : (c.kf == 2 ? (seg >> 1) : seg);
-  k.kf = seg - k.phl * c.kf;
+  k.gg = g_first & (gpc - 1);
+  k.phl = kf == 3 ? ((seg * 43) >> 7) : (kf == 2 ? (seg >> 1) : seg);
+  k.kf = seg - k.phl * kf;
   return k;
 }
 
-// The 16 (x TW) MFMAs of one 4-group chunk (TW = 1 or 2 position tiles sharing the weight fragments).
-template <int TW>
-__device__ __forceinline__ void chunk_mfma(f32x16 (&acc)[2], const f32x4 (&wa)[4], const float* lds_lane0, const float* lds_lane1, int boff) {
-  // B fragments: one ds_read_b128 per tile per group, fetched one group ahead of its MFMAs
-  f32x4 b0 = *reinterpret_cast<const f32x4*>(lds_lane0 + boff), b1 = b0;
-  if (TW == 2) b1 = *reinterpret_cast<const f32x4*>(lds_lane1 + boff);
+// The 16 MFMAs of one 4-group chunk for the first position tile and, in 16-tile layers, 16 more for the
+// second tile (same weight fragments).  The first tile's accumulator has ONE update site and the second
+// one a conditional in-place one: a two-sided branch (tile count 1 / 2) made the register allocator copy
+// both accumulators in and out of temporaries around every chunk -- each copy waiting for the MFMA chain.
+__device__ __forceinline__ void chunk_mfma(f32x16& acc0, f32x16& acc1, bool two, const f32x4 (&wa)[4], float* lds_in, int lb0, int lb1) {
+  f32x4 b[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const f32x4 c0 = b0, c1 = b1;
-    if (u < 3) {
-      b0 = *reinterpret_cast<const f32x4*>(lds_lane0 + boff + 8 * (u + 1));
-      if (TW == 2) b1 = *reinterpret_cast<const f32x4*>(lds_lane1 + boff + 8 * (u + 1));
-    }
+  for (int u = 0; u < 4; ++u) b[u] = lds4(lds_in, lb0 + 32 * u);     // B fragments: one ds_read_b128 per group
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], c0[j], acc[0], 0, 0, 0);
-      if (TW == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], c1[j], acc[1], 0, 0, 0);
-    }
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], b[u][j], acc0, 0, 0, 0);
+  if (two) {
+    f32x4 d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = lds4(lds_in, lb1 + 32 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], d[u][j], acc1, 0, 0, 0);
   }
+}
+
+// DPP lane exchange (no LDS crossbar round trip): quad xor 1, quad xor 2, mirror inside 8 / 16 lanes
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int LPG>
+__device__ __forceinline__ float group_sum(float s) {      // sum over LPG consecutive lanes (aligned), result in all of them
+  s += dpp_mov<0xB1>(s);                  // quad_perm [1,0,3,2]
+  s += dpp_mov<0x4E>(s);                  // quad_perm [2,3,0,1]
+  if (LPG >= 8) s += dpp_mov<0x141>(s);   // row_half_mirror: the other quad of the 8
+  if (LPG >= 16) s += dpp_mov<0x140>(s);  // row_mirror: the other 8 of the 16
+  if (LPG >= 32) s += __shfl_xor(s, 16);
+  return s;
 }
 
 // ---------------------------------------------------------------------------------------------
 //  Row-wise epilogue: LPG lanes per output row (row = LPG*4 channels), optional LN + PReLU; writes
-//  HBM destinations and, when `nx` is given, forwards the rows into the next layer's LDS image.
+//  HBM destinations and, when `do_fwd`, forwards the rows into the next layer's LDS image.
 // ---------------------------------------------------------------------------------------------
 template <int LPG, bool LN>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const ConvPlan& c, int stream, const float* lds_out, int tid,
-                                              f32x4 bias, f32x4 gm, f32x4 bt, bool do_fwd, const ConvPlan& nx, float* lds_next,
-                                              int fwd_coff4) {
+__device__ __forceinline__ void conv_epilogue(const OpWords& o, gcb_t sb, float* lds_out, int tid, f32x4 bias, f32x4 gm, f32x4 bt,
+                                              bool do_fwd, const OpWords& nx, float* lds_next) {
   constexpr int GC = LPG * 4;
+  const int units = cv_units(o);
+  int u = tid / LPG;
+  if (u >= units) return;
   const int li = tid & (LPG - 1);
-  const int units = p.F_out * c.R;
-  float* d0 = p.dst0 + static_cast<size_t>(stream) * p.sstride;
-  float* d1 = p.dst1 ? p.dst1 + static_cast<size_t>(stream) * p.sstride : nullptr;
+  const int R2 = cv_R2(o), KS = cv_KS(o), slot_b = cv_slot_b(o), opitch_b = cv_opitch_b(o);
+  const unsigned d0 = o.w[2] + 16u * li, d1 = o.w[3] + 16u * li;
+  const int ld0 = cv_ld0_b(o), ld1 = cv_ld1_b(o), row_mul = cv_row_mul(o), row_add = cv_row_add(o);
+  const bool has1 = cv_has_dst1(o);
+  const float alpha = __uint_as_float(o.w[8]);
   // forwarded block inside the next image: float4 column (coff4 + li) of the current-frame phase
-  int f_ph = 0, f_c4 = 0;
+  int f_base = 0, f_c4 = 0;
   if (do_fwd) {
-    const int chan4 = fwd_coff4 + li;
-    f_ph = ((nx.tt - 1) << nx.nch_shift) + (chan4 >> nx.cc4_shift);
-    f_c4 = chan4 & ((1 << nx.cc4_shift) - 1);
+    const int chan4 = cv_fwd_coff4(o) + li;
+    const int cs = cv_cc4_shift(nx);
+    f_base = ((cv_tt2(nx) << cv_nch_shift(nx)) + (chan4 >> cs)) * cv_phase_b(nx);
+    f_c4 = chan4 & ((1 << cs) - 1);
   }
-  for (int u = tid / LPG; u < units; u += MK_THREADS / LPG) {
-    const int pos = (c.R == 2) ? (u >> 1) : u, gi = (c.R == 2) ? (u & 1) : 0;
-    const float* o = lds_out + pos * c.opitch + gi * GC + 4 * li;
+  for (; u < units; u += MK_THREADS / LPG) {
+    const int pos = R2 ? (u >> 1) : u, gi = R2 ? (u & 1) : 0;
+    const int ob = pos * opitch_b + gi * (GC * 4) + 16 * li;
     f32x4 v = bias;
-    for (int ks = 0; ks < c.KS; ++ks) v += *reinterpret_cast<const f32x4*>(o + ks * c.slot_floats);
+    for (int ks = 0; ks < KS; ++ks) v += lds4(lds_out, ob + ks * slot_b);
     if (LN) {
-      float s = v[0] + v[1] + v[2] + v[3];
-#pragma unroll
-      for (int m = 1; m < LPG; m <<= 1) s += __shfl_xor(s, m);
-      const float mean = s * (1.0f / GC);
+      const float mean = group_sum<LPG>(v[0] + v[1] + v[2] + v[3]) * (1.0f / GC);
       v -= mean;
-      float q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-#pragma unroll
-      for (int m = 1; m < LPG; m <<= 1) q += __shfl_xor(q, m);
+      const float q = group_sum<LPG>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
       const float rstd = 1.0f / sqrtf(q * (1.0f / GC) + MK_LN_EPS);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float y = v[i] * rstd * gm[i] + bt[i];
-        v[i] = y >= 0.f ? y : p.alpha * y;
+        v[i] = y >= 0.f ? y : alpha * y;
       }
     }
-    const int row = pos * p.row_mul + p.row_add + gi;
-    st4(d0, static_cast<unsigned>(row * p.ld0 + 4 * li), v);
-    if (d1) st4(d1, static_cast<unsigned>(row * p.ld1 + 4 * li), v);
-    if (do_fwd) *reinterpret_cast<f32x4*>(lds_next + f_ph * nx.phase_floats + img_addr(nx, nx.padl + row, f_c4)) = v;
+    const int row = pos * row_mul + row_add + gi;
+    stb(sb, d0 + static_cast<unsigned>(row * ld0), v);
+    if (has1) stb(sb, d1 + static_cast<unsigned>(row * ld1), v);
+    if (do_fwd) lds4(lds_next, f_base + img_addr_b(nx, cv_padl(nx) + row, f_c4)) = v;
   }
 }
 
 // One conv-like layer for one stream.
-//   wnext  in : this task's first weight chunk (fetched while the previous layer ran) when `have_w`
-//          out: the next layer's first chunk (single static load site -> no copies of pending loads)
-__device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& c, bool nconv, const ConvParams& np, const ConvPlan& ncp,
-                                           int stream, float* lds_in, float* lds_out, int tid, f32x4 (&wnext)[4], bool& have_w,
-                                           unsigned long long* sub, unsigned long long* dbg) {
+//   cy  in : this wave's first weight chunk + this lane's epilogue parameters (fetched by the previous op)
+//       out: the same for the next conv layer (a layer with no conv successor re-reads its own)
+__device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, bool nconv, gcb_t sb, gcb_t wb, float* lds_in,
+                                           float* lds_out, int tid, Carry& cy, unsigned long long* sub, unsigned long long* dbg) {
   MK_T(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SGPR
   const int pl = lane & 31, h = lane >> 5;
-  const bool active = wave < c.tasks * c.KS;
-  const int ks = wave >> c.tasks_shift, tl = wave & (c.tasks - 1);
-  const int pt = (tl >> c.nt_shift) * c.tw, nt = tl & (c.nt - 1);     // first position tile, channel tile
+  const int tasks = cv_tasks(o), nt = cv_nt(o), tw = cv_tw(o), F_out = cv_F_out(o);
+  const bool active = wave < tasks * cv_KS(o);
+  const int ks = wave >> cv_tasks_shift(o), tl = wave & (tasks - 1);
+  const int pt = (tl >> cv_nt_shift(o)) * tw, ntile = tl & (nt - 1);     // first position tile, channel tile
   int pc0 = pt * 32 + pl, pc1 = pc0 + 32;
-  if (pc0 > p.F_out - 1) pc0 = p.F_out - 1;        // padding lanes recompute the last position
-  if (pc1 > p.F_out - 1) pc1 = p.F_out - 1;
-  const float* lds_lane0 = lds_in + pc0 * c.pitch + 4 * h;
-  const float* lds_lane1 = lds_in + pc1 * c.pitch + 4 * h;
+  if (pc0 > F_out - 1) pc0 = F_out - 1;        // padding lanes recompute the last position
+  if (pc1 > F_out - 1) pc1 = F_out - 1;
+  const int pitch_b = cv_pitch_b(o);
+  const int lane_b0 = pc0 * pitch_b + 16 * h, lane_b1 = pc1 * pitch_b + 16 * h;
   const FwdWin nofw = {0, 0, 1, 0, false};
 
-  WeightCursor wc;
-  wc.wstep = c.nt * 64;
-  wc.round_step = c.RG * wc.wstep;
-  wc.base = (gc4_t)(unsigned long long)p.wpk + (static_cast<size_t>(active ? ks * c.gpk : 0) * c.nt + (active ? nt : 0)) * 64;
+  // weight stream of this task: byte offsets from the weight arena (wave-uniform) + lane part
+  const unsigned wstep_b = static_cast<unsigned>(nt) << 10;                 // one 8-channel group: nt * 64 float4
+  const unsigned round_step_b = static_cast<unsigned>(cv_RG(o)) * wstep_b;
+  const unsigned wbase_b = o.w[4] + static_cast<unsigned>((active ? ks * cv_gpk(o) : 0) * nt + (active ? ntile : 0)) * 1024u;
+  const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
 
-  // ---- first weight chunk: fetched by the previous layer, or (first layer of a run) right now
+  // ---- first weight chunk and epilogue parameters: fetched by the previous op
   f32x4 wa[4];
-  if (have_w) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) wa[u] = wnext[u];
-  } else {
-    load_chunk(wa, wc.base, wc.wstep, lane);
-  }
+  for (int u = 0; u < 4; ++u) wa[u] = cy.w[u];
+  const f32x4 bias = cy.e[0], gm = cy.e[1], bt = cy.e[2];
   MK_STAMP(0);
 
   // ---- LDS image of round 0 (skipped when the previous layer handed it over complete)
-  const int nstage = c.merged ? c.nph : 1;
-  if (!c.staged_by_prev) {
+  const int nstage = cv_merged(o) ? cv_nph(o) : 1;
+  if (!cv_staged_by_prev(o)) {
     f32x4 pf[MK_MAXPF];
-    image_load(img_src(p, c), stream, 0, nstage, tid, pf);
-    image_store(c, lds_in, 0, nstage, 0, nofw, tid, pf);
+    image_load(img_src(o), sb, 0, nstage, tid, pf);
+    image_store(o, lds_in, 0, nstage, 0, nofw, tid, pf);
     lds_barrier();
   }
   MK_STAMP(1);
   MK_T(2);
 
   // ---- what this layer owes the next one
-  const bool hand = nconv && c.hand_next;
-  FwdWin fw = nofw;
-  if (hand && c.fwd_sel) { fw.lo4 = c.fwd_coff4; fw.hi4 = c.fwd_coff4 + c.lpg; fw.rmul = c.fwd_rmul; fw.radd = c.fwd_radd; fw.on = true; }
-  const int n_hand = hand ? (ncp.merged ? ncp.nph : 1) : 0;
-
-  // Global loads are issued oldest-needed-first (vmcnt retires in order): epilogue parameters, then
-  // the next layer's first weight chunk, then -- after this layer's own last weight prefetch -- the
-  // rows of the next layer's LDS image that this layer does not produce (previous-frame tap,
-  // skip-connection channels; HBM, long latency).  None of the barriers in between drains vmcnt.
-  const int lpg = c.lpg;
-  const int li = tid & (lpg - 1);
-  const int gi_mine = (c.R == 2) ? ((tid / lpg) & 1) : 0;
-  const f32x4 bias = *G4(p.bias + gi_mine * (4 * lpg) + 4 * li);
-  // (always loaded -- a value select on a pending load would wait for it right here; layers without
-  //  LayerNorm re-read the bias)
-  const f32x4 gm = *G4((c.epi_ln ? p.gamma : p.bias) + 4 * li);
-  const f32x4 bt = *G4((c.epi_ln ? p.beta : p.bias) + 4 * li);
+  const bool hand = nconv && cv_hand_next(o);
+  const bool do_fwd = hand && cv_fwd_sel(o);
+  const int n_hand = hand ? (cv_merged(n) ? cv_nph(n) : 1) : 0;
   MK_STAMP(6);
   MK_T(3);
+
   f32x16 acc[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
   // One register set and ONE static load site serve both image prefetches -- the next phase of THIS
-  // layer (rounds before the last: issued with the round's first chunk) and, in the last round, the
-  // next layer's image rows (issued right after the layer's last weight prefetch: the youngest loads,
-  // vmcnt retires in order).  Two load sites would meet in phi copies of pending loads, and the copy
-  // costs a full vmcnt(0) wait.
+  // layer (rounds before the last) and, in the last round, the next layer's image rows this layer does
+  // not produce (previous-frame tap, skip-connection channels; HBM, long latency).  Both are issued in
+  // the round's last chunk, right after its weight prefetch: the youngest loads (vmcnt retires in
+  // order).  Two load sites would meet in phi copies of pending loads, and such a copy costs a full
+  // vmcnt(0) wait.  None of the barriers in between drains vmcnt.
   f32x4 pfx[MK_MAXPF];
-  const int nchunks = active ? (c.gpk >> 2) : 1;     // idle waves run one empty chunk per round: they stage too
+  const int nchunks = active ? (cv_gpk(o) >> 2) : 1;     // idle waves run one empty chunk per round: they stage too
+  const int rounds = cv_rounds(o), kf_n = cv_kf(o), gpc = cv_gpc(o), phase_b = cv_phase_b(o);
+  const int cc_b = cv_cc_b(o), stride2 = cv_stride2(o);
 #pragma unroll 1
-  for (int rd = 0; rd < c.rounds; ++rd) {
-    const bool last = rd + 1 == c.rounds;
-    const int hook_ch = last ? nchunks - 1 : 0;
-    KCursor k = kcursor_init(c, ks);
-    gc4_t wp = wc.base + static_cast<size_t>(rd) * wc.round_step;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const bool last = rd + 1 == rounds;
+    KCursor k = kcursor_init(o, ks);
+    unsigned wcur = wbase_b + static_cast<unsigned>(rd) * round_step_b;
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
       // prefetch the next chunk: next in this slice, else the first chunk of the next round's slice
       // (wave-uniform condition -> scalar branch; nothing is fetched after the layer's last chunk)
       const bool more = active && ((ch + 1 < nchunks) || !last);
-      f32x4 wb[4];
+      f32x4 wn[4];
       if (more) {
-        gc4_t nxt = (ch + 1 < nchunks) ? wp + 4 * wc.wstep : wc.base + static_cast<size_t>(rd + 1) * wc.round_step;
-        load_chunk(wb, nxt, wc.wstep, lane);
+        const unsigned nxt = (ch + 1 < nchunks) ? wcur + 4 * wstep_b : wbase_b + static_cast<unsigned>(rd + 1) * round_step_b;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wn[u] = ldb(wb, nxt + u * wstep_b + lane16);
       }
-      if (ch == hook_ch && (!last || hand)) {
+      if (ch == nchunks - 1 && (!last || hand)) {
         ImgSrc is;
-        is.src0 = last ? np.src0 : p.src0; is.src1 = last ? np.src1 : p.src1; is.sstride = p.sstride;
-        is.ld = last ? np.src_ld : p.src_ld;
-        is.n4p_shift = last ? ncp.n4p_shift : c.n4p_shift; is.cc4_shift = last ? ncp.cc4_shift : c.cc4_shift;
-        is.nch_shift = last ? ncp.nch_shift : c.nch_shift;
-        image_load(is, stream, last ? 0 : rd + 1, last ? n_hand : 1, tid, pfx);
+        is.src0 = last ? n.w[0] : o.w[0]; is.dtap = last ? n.w[1] : o.w[1];
+        is.ld = static_cast<unsigned>(last ? cv_src_ld_b(n) : cv_src_ld_b(o));
+        const unsigned sh = last ? n.w[13] : o.w[13];
+        is.cc4_shift = b0(sh); is.n4p_shift = b1(sh); is.nch_shift = b2(sh);
+        image_load(is, sb, last ? 0 : rd + 1, last ? n_hand : 1, tid, pfx);
         MK_STAMP(7);
         MK_T(4);
       }
       if (active) {
-        const int koff = (c.stride == 1) ? k.kf * c.pitch : ((k.kf >> 1) * c.pitch + (k.kf & 1) * c.cc);
-        const int boff = k.phl * c.phase_floats + koff + 8 * k.gg;
-        if (c.tw == 2) chunk_mfma<2>(acc, wa, lds_lane0, lds_lane1, boff);
-        else chunk_mfma<1>(acc, wa, lds_lane0, lds_lane1, boff);
+        const int koff = stride2 ? ((k.kf >> 1) * pitch_b + (k.kf & 1) * cc_b) : k.kf * pitch_b;
+        const int boff = k.phl * phase_b + koff + 32 * k.gg;
+        chunk_mfma(acc[0], acc[1], tw == 2, wa, lds_in, lane_b0 + boff, lane_b1 + boff);
       }
       if (more) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) wa[u] = wb[u];
+        for (int u = 0; u < 4; ++u) wa[u] = wn[u];
       }
-      wp += 4 * wc.wstep;
+      wcur += 4 * wstep_b;
       k.gg += 4;
-      if (k.gg == c.gpc) { k.gg = 0; if (++k.kf == c.kf) { k.kf = 0; ++k.phl; } }
+      if (k.gg == gpc) { k.gg = 0; if (++k.kf == kf_n) { k.kf = 0; ++k.phl; } }
     }
     if (!last) {
       lds_barrier();             // every wave is done reading this phase's LDS rows
-      image_store(c, lds_in, rd + 1, 1, rd + 1, nofw, tid, pfx);
+      image_store(o, lds_in, rd + 1, 1, rd + 1, nofw, tid, pfx);
       lds_barrier();
     }
   }
   MK_T(5);
-  {   // next layer's first weight chunk (single load site; a layer with no conv successor re-reads its own)
-    // (field-wise selects: a reference/pointer select between the two structs would force both to memory)
-    const float* nw = nconv ? np.wpk : p.wpk;
-    const int n_tasks = nconv ? ncp.tasks : c.tasks, n_ks = nconv ? ncp.KS : c.KS, n_shift = nconv ? ncp.tasks_shift : c.tasks_shift;
-    const int n_nt = nconv ? ncp.nt : c.nt, n_gpk = nconv ? ncp.gpk : c.gpk;
-    const bool nact = wave < n_tasks * n_ks;
-    const int nks = nact ? (wave >> n_shift) : 0;
-    const int nnt = nact ? (wave & (n_nt - 1)) : 0;
-    load_chunk(wnext, (gc4_t)(unsigned long long)nw + (static_cast<size_t>(nks * n_gpk) * n_nt + nnt) * 64, n_nt * 64, lane);
-    have_w = nconv;
+  // next conv layer's first weight chunk + epilogue parameters (single load site)
+  {
+    OpWords s;     // (field-wise selects of the words prefetch_conv reads: a layer with no conv successor re-reads its own)
+    s.w[4] = nconv ? n.w[4] : o.w[4]; s.w[5] = nconv ? n.w[5] : o.w[5]; s.w[6] = nconv ? n.w[6] : o.w[6]; s.w[7] = nconv ? n.w[7] : o.w[7];
+    s.w[10] = nconv ? n.w[10] : o.w[10]; s.w[12] = nconv ? n.w[12] : o.w[12]; s.w[18] = nconv ? n.w[18] : o.w[18];
+    s.w[19] = nconv ? n.w[19] : o.w[19];
+    prefetch_conv(s, wb, wave, tid, cy);
   }
   MK_STAMP(2);
   MK_T(6);
 
   // ---- partial tiles -> LDS exchange buffer [ks][pos][32*NT (+4)]
   if (active) {
+    const int opitch_b = cv_opitch_b(o);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      if (t < c.tw) {
-        float* o = lds_out + ks * c.slot_floats + ((pt + t) * 32 + pl) * c.opitch + nt * 32 + 4 * h;
+      if (t < tw) {
+        const int ob = ks * cv_slot_b(o) + ((pt + t) * 32 + pl) * opitch_b + ntile * 128 + 16 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-          *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+          lds4(lds_out, ob + 32 * q) = v;
         }
       }
     }
@@ -535,17 +533,23 @@ __device__ __forceinline__ void conv_layer(const ConvParams& p, const ConvPlan& 
   MK_STAMP(3);
   MK_T(8);
 
-  const bool do_fwd = hand && c.fwd_sel;
-  if (c.epi_ln) {
-    if (c.g == 1) conv_epilogue<8, true>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
-    else conv_epilogue<16, true>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
+  const int gcode = cv_gcode(o);
+  if (cv_epi_ln(o)) {
+    if (gcode == 0) conv_epilogue<8, true>(o, sb, lds_out, tid, bias, gm, bt, do_fwd, n, lds_in);
+    else conv_epilogue<16, true>(o, sb, lds_out, tid, bias, gm, bt, do_fwd, n, lds_in);
   } else {
-    if (c.g == 2) conv_epilogue<16, false>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
-    else conv_epilogue<32, false>(p, c, stream, lds_out, tid, bias, gm, bt, do_fwd, ncp, lds_in, c.fwd_coff4);
+    if (gcode == 1) conv_epilogue<16, false>(o, sb, lds_out, tid, bias, gm, bt, do_fwd, n, lds_in);
+    else conv_epilogue<32, false>(o, sb, lds_out, tid, bias, gm, bt, do_fwd, n, lds_in);
   }
   MK_T(9);
   // ---- hand-off: the prefetched part of the next layer's image (the forwarded rows were written above)
-  if (hand) image_store(ncp, lds_in, 0, n_hand, 0, fw, tid, pfx);
+  if (hand) {
+    FwdWin fw = nofw;
+    if (do_fwd) {
+      fw.lo4 = cv_fwd_coff4(o); fw.hi4 = fw.lo4 + cv_lpg(o); fw.rmul = 1 + cv_fwd_rmul2(o); fw.radd = cv_fwd_radd(o); fw.on = true;
+    }
+    image_store(n, lds_in, 0, n_hand, 0, fw, tid, pfx);
+  }
   MK_STAMP(4);
   MK_T(10);
   __syncthreads();               // HBM stores visible to the workgroup; next image complete; exchange buffer free
@@ -566,8 +570,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // the op (input, weights of all three products, states, and the next conv layer's image rows) is issued
 // before the first barrier, so one memory latency is exposed.  When `hand`, the op also completes the
 // next conv layer's LDS image: its own output is written straight into it.
-__device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, float* lds, float* lds_in, int tid, bool hand, int fwd_coff,
-                                           const ConvParams& np, const ConvPlan& ncp) {
+__device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, gcb_t sbb, float* lds, float* lds_in, int tid, bool hand,
+                                           int fwd_coff, const OpWords& nx) {
   float* part = lds;               // [16][84]
   float* z = lds + 16 * 84;        // [96]
   float* hn = z + 96;              // [32]
@@ -609,7 +613,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
   }
   // ---- next conv layer's image rows this op does not produce
   f32x4 pfx[MK_MAXPF];
-  if (hand) image_load(img_src(np, ncp), stream, 0, ncp.nph, tid, pfx);
+  if (hand) image_load(img_src(nx), sbb, 0, cv_nph(nx), tid, pfx);
 
   if (mv) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -645,11 +649,11 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
     for (int u = 0; u < 21; ++u) a = fmaf(wd[u], hn[u], a);
     const int f = tid / p.dst_cols, c = tid - f * p.dst_cols;
     st1(p.dst + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(f * p.dst_ld + c), a);
-    if (hand) img_put1(ncp, lds_in, f, fwd_coff + c, a);
+    if (hand) img_put1(nx, lds_in, f, fwd_coff + c, a);
   }
   if (hand) {
     const FwdWin fw = {fwd_coff >> 2, (fwd_coff + p.dst_cols) >> 2, 1, 0, true};
-    image_store(ncp, lds_in, 0, ncp.nph, 0, fw, tid, pfx);
+    image_store(nx, lds_in, 0, cv_nph(nx), 0, fw, tid, pfx);
   }
   __syncthreads();
 }
@@ -657,10 +661,10 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, floa
 // CTFA gate + residual for one stream (ctfa_rt, models/proposed.py:162-196).
 // Wave u computes hidden unit u of the 64->16 layers (one product per lane + wave reduction);
 // the MLP weights are fetched before the mean-over-F reduction so their latency is hidden.
-__device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, float* lds, float* lds_in, int tid, bool hand, int fwd_coff,
-                                           const ConvParams& np, const ConvPlan& ncp) {
+__device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, gcb_t sbb, float* lds, float* lds_in, int tid, bool hand,
+                                           int fwd_coff, const OpWords& nx) {
   f32x4 pfx[MK_MAXPF];
-  if (hand) image_load(img_src(np, ncp), stream, 0, ncp.nph, tid, pfx);
+  if (hand) image_load(img_src(nx), sbb, 0, cv_nph(nx), tid, pfx);
   float* part = lds;               // [32][64]
   float* m = lds + 4096;           // [64]
   float* hid = m + 64;             // [16]
@@ -731,17 +735,17 @@ __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, floa
     const f32x4 ev = *G4(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
     const f32x4 yv = xv * g4 + ev;
     *G4W(yb + static_cast<size_t>(f) * p.y_ld + 4 * c4) = yv;
-    if (hand) img_put4(ncp, lds_in, f, (fwd_coff >> 2) + c4, yv);
+    if (hand) img_put4(nx, lds_in, f, (fwd_coff >> 2) + c4, yv);
   }
   if (hand) {
     const FwdWin fw = {fwd_coff >> 2, (fwd_coff >> 2) + 16, 1, 0, true};
-    image_store(ncp, lds_in, 0, ncp.nph, 0, fw, tid, pfx);
+    image_store(nx, lds_in, 0, cv_nph(nx), 0, fw, tid, pfx);
   }
   __syncthreads();
 }
 
 __device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs& a, int stream, float* lds_in, int tid, bool hand,
-                                               const ConvPlan& ncp) {
+                                               const OpWords& nx) {
   InLayerParams p;
   p.x = a.io_in; p.y = aptr(a.arena, o.w[0]);
   p.w = wptr(a.wbase, o.w[1]); p.b = wptr(a.wbase, o.w[2]); p.gamma = wptr(a.wbase, o.w[3]); p.beta = wptr(a.wbase, o.w[4]);
@@ -769,7 +773,7 @@ __device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs&
       o4[i] = t >= 0.f ? t : p.alpha * t;
     }
     *G4W(p.y + static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(pos) * 64 + 4 * c4) = o4;
-    if (hand) img_put4(ncp, lds_in, pos, c4, o4);     // the whole image of msfe6_en_in is this op's output
+    if (hand) img_put4(nx, lds_in, pos, c4, o4);     // the whole image of msfe6_en_in is this op's output
   }
   __syncthreads();
 }
@@ -794,16 +798,10 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
   float* lds_out = lds + MK_LDS_IN;
-  unsigned* lds_plan = reinterpret_cast<unsigned*>(lds + MK_LDS_IN + MK_LDS_OUT);
   const int n_ops = a.n_ops;
   unsigned long long* prof = a.prof;
-  // the whole compact plan -> LDS, once
-  {
-    const u32x4* src = reinterpret_cast<const u32x4*>(a.plan);
-    for (int q = threadIdx.x; q < n_ops * (MK_OP_WORDS / 4); q += MK_THREADS)
-      reinterpret_cast<u32x4*>(lds_plan)[q] = src[q];
-    __syncthreads();
-  }
+  const cplan_t plan = (cplan_t)(unsigned long long)a.plan;
+  const gcb_t wb = (gcb_t)(unsigned long long)a.wbase;
   // `fresh_tid()` re-materialises the thread id behind an opaque asm at every layer: without it the
   // compiler hoists dozens of tid-derived per-thread constants out of the layer loop, keeps them live
   // across the whole kernel and spills them -- and a scratch reload is a vmcnt wait, which in this
@@ -811,21 +809,16 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
   auto fresh_tid = []() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
   for (int stream = blockIdx.x; stream < a.B; stream += gridDim.x) {
     if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[n_ops * 9 + 1] = clock64();
-    // the first weight chunk of the next conv layer travels in registers from op to op
-    f32x4 wnext[4];
-    bool have_w = false;
-    OpWords cur = load_op(lds_plan, 0);
+    const gcb_t sb = (gcb_t)(unsigned long long)(a.arena + static_cast<size_t>(stream) * a.sstride);   // this stream's arena slice
+    Carry cy;
+    OpWords cur = load_op(plan, 0);
 #pragma unroll 1
     for (int i = 0; i < n_ops; ++i) {
       const int tid = fresh_tid();
-      const int lane = tid & 63;
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
       if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
-      const OpWords nxt = load_op(lds_plan, i + 1 < n_ops ? i + 1 : i);
+      const OpWords nxt = load_op(plan, i + 1 < n_ops ? i + 1 : i);
       const bool nconv = (i + 1 < n_ops) && static_cast<int>(nxt.w[23]) == DEV_OP_CONV;
-      ConvParams np;
-      ConvPlan ncp;
-      decode_conv(nxt, a, np, ncp);
       const int op = static_cast<int>(cur.w[23]);
       const bool nc_hand = nconv && b0(cur.w[22]) != 0;      // non-conv op -> conv hand-off
       const int nc_coff = b1(cur.w[22]);
@@ -833,32 +826,24 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
         unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
         unsigned long long* dbg = (sub && i == a.dbg_op) ? prof + n_ops * 9 + 3 : nullptr;
         if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 15] = clock64();
-        ConvParams p;
-        ConvPlan c;
-        decode_conv(cur, a, p, c);
-        if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 14] = clock64();
-        conv_layer(p, c, nconv, np, ncp, stream, lds_in, lds_out, tid, wnext, have_w, sub, dbg);
+        conv_layer(cur, nxt, nconv, sb, wb, lds_in, lds_out, tid, cy, sub, dbg);
       } else {
         if (op == DEV_OP_LSTM) {
           LstmParams p;
           decode_lstm(cur, a, p);
-          lstm_layer(p, stream, lds_out, lds_in, tid, nc_hand, nc_coff, np, ncp);
+          lstm_layer(p, stream, sb, lds_out, lds_in, tid, nc_hand, nc_coff, nxt);
         } else if (op == DEV_OP_CTFA) {
           CtfaParams p;
           decode_ctfa(cur, a, p);
-          ctfa_layer(p, stream, lds_out, lds_in, tid, nc_hand, nc_coff, np, ncp);
+          ctfa_layer(p, stream, sb, lds_out, lds_in, tid, nc_hand, nc_coff, nxt);
         } else if (op == DEV_OP_INLAYER) {
-          input_layer_op(cur, a, stream, lds_in, tid, nc_hand, ncp);
+          input_layer_op(cur, a, stream, lds_in, tid, nc_hand, nxt);
         } else if (op == DEV_OP_DDB) {
           ddb_block(a.ddb[cur.w[0]], stream, lds_out, tid, MK_THREADS);
         } else {
           out_conv_op(cur, a, stream, tid);
         }
-        have_w = false;
-        if (nconv) {
-          load_next_weights(np, ncp, wave, lane, wnext);
-          have_w = true;
-        }
+        if (nconv) prefetch_conv(nxt, wb, wave, tid, cy);
       }
       cur = nxt;
     }

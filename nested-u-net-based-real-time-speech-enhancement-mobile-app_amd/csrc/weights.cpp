@@ -165,27 +165,35 @@ CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) 
   o.w[22] = pack4(d.nc_hand, d.nc_fwd_coff, 0, 0);     // non-conv ops: hand-off to the following conv layer
   switch (d.op) {
     case DEV_OP_CONV: {
+      // conv offsets are BYTES from the stream slice / the weight arena (decoders: cv_* in megakernel.hip)
       const ConvParams& p = d.conv;
       const ConvPlan& c = d.cp;
-      o.w[0] = off_of(p.src0, arena); o.w[1] = off_of(p.src1, arena);
-      o.w[2] = off_of(p.dst0, arena); o.w[3] = off_of(p.dst1, arena);
-      o.w[4] = off_of(p.wpk, wbase); o.w[5] = off_of(p.bias, wbase);
-      o.w[6] = off_of(p.gamma, wbase); o.w[7] = off_of(p.beta, wbase);
+      auto ab = [&](const float* q) { return static_cast<uint32_t>((q - arena) * 4); };
+      auto wbo = [&](const float* q) { return static_cast<uint32_t>((q - wbase) * 4); };
+      o.w[0] = ab(p.src0);
+      o.w[1] = p.src1 ? ab(p.src1) - ab(p.src0) : 0u;                   // second time tap relative to the first (mod 2^32)
+      o.w[2] = ab(p.dst0); o.w[3] = p.dst1 ? ab(p.dst1) : 0u;
+      o.w[4] = wbo(p.wpk); o.w[5] = wbo(p.bias);
+      o.w[6] = c.epi_ln ? wbo(p.gamma) : o.w[5];                        // no LayerNorm: the loads still happen, on the bias
+      o.w[7] = c.epi_ln ? wbo(p.beta) : o.w[5];
       o.w[8] = fbits(p.alpha);
-      const int flags = (p.row_mul & 3) | ((p.row_add & 1) << 2) | ((c.stride - 1) << 3) | ((c.tt - 1) << 4) | (c.epi_ln << 5) |
-                        (c.merged << 6) | (c.staged_by_prev << 7);
-      o.w[9] = pack4(p.src_ld, p.ld0, p.ld1, flags);
-      o.w[10] = pack2(p.F_in, p.F_out);
-      o.w[11] = pack4(c.kf, c.padl, c.g, c.nt);
-      o.w[12] = pack4(c.cc, c.cc4_shift, c.n4p_shift, c.nch_shift);
-      o.w[13] = pack2(c.pitch, c.rows);
-      o.w[14] = pack2(c.vrows, c.nph | (c.rounds << 8));
-      o.w[15] = pack2(c.phase_floats, c.slot_floats);
-      o.w[16] = pack4(c.RG, c.KS, c.gpk, c.gpc);
-      o.w[17] = pack4(c.PT, c.tiles, c.nt_shift, c.tw);
-      o.w[18] = pack2(c.tasks | (c.tasks_shift << 8), c.opitch);
-      o.w[19] = pack4(c.R, c.lpg, c.hand_next, c.fwd_sel);
-      o.w[20] = pack4(c.fwd_coff4, c.fwd_rmul, c.fwd_radd, c.cin);
+      const int gcode = c.g == 1 ? 0 : (c.g == 2 ? 1 : 2);
+      const uint32_t flags = (p.row_mul & 3) | ((p.row_add & 1) << 2) | ((c.stride - 1) << 3) | ((c.tt - 1) << 4) | (c.epi_ln << 5) |
+                             (c.merged << 6) | (c.staged_by_prev << 7) | ((c.hand_next ? 1 : 0) << 8) | ((c.fwd_sel ? 1 : 0) << 9) |
+                             ((c.fwd_rmul == 2 ? 1 : 0) << 10) | ((c.fwd_radd & 1) << 11) | ((c.R == 2 ? 1 : 0) << 12) |
+                             ((p.dst1 ? 1 : 0) << 13) | (static_cast<uint32_t>(gcode) << 14);
+      o.w[9] = pack2(p.src_ld * 4, p.ld0 * 4);
+      o.w[10] = pack2(p.ld1 * 4, static_cast<int>(flags));
+      o.w[11] = pack2(p.F_in, p.F_out);
+      o.w[12] = pack4(c.kf, c.padl, c.lpg, c.nt);
+      o.w[13] = pack4(c.cc4_shift, c.n4p_shift, c.nch_shift, c.nt_shift);
+      o.w[14] = pack2(c.pitch * 4, c.rows);
+      o.w[15] = pack2(c.vrows, c.nph | (c.rounds << 8));
+      o.w[16] = static_cast<uint32_t>(c.phase_floats) * 4u;
+      o.w[17] = static_cast<uint32_t>(c.slot_floats) * 4u;
+      o.w[18] = pack4(c.RG, c.KS, c.gpk, c.gpc);
+      o.w[19] = pack4(c.tasks, c.tasks_shift, c.tw, c.fwd_coff4);
+      o.w[20] = pack2(c.opitch * 4, p.F_out * c.R);
       break;
     }
     case DEV_OP_LSTM: {
