@@ -66,15 +66,18 @@ constexpr int MK_THREADS = 64 * MK_WAVES;
 constexpr int MK_MAXPF = MK_STAGE_ITEMS / MK_THREADS;   // float4 prefetch registers per thread (8)
 constexpr int MK_LDS_IN = MK_LDS_IN_FLOATS;
 constexpr int MK_LDS_OUT = 16 * 32 * 36;      // floats: 16 tasks x 32 positions x (32+4)
-constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT) * sizeof(float);
+constexpr int MK_LDS_DBG = 256;               // floats: 8 waves x 16 cycle stamps (profiling only)
+constexpr size_t MK_LDS_BYTES = (MK_LDS_IN + MK_LDS_OUT + MK_LDS_DBG) * sizeof(float);
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does NOT drain vmcnt,
 // so global loads issued earlier (next layer's image rows, weight fragments) stay in flight across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#define MK_STAMP(k) do { if (sub && tid == 0) sub[k] = wall_clock64(); } while (0)
+#define MK_STAMP(k) do { if (PROF && sub && tid == 0) sub[k] = wall_clock64(); } while (0)
 // fine-grained cycle stamps of ONE chosen op (debug builds of the profile path only)
-#define MK_T(k) do { if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + k] = clock64(); } while (0)
+// (stamps go to LDS and are copied out after the op: a global store here would sit in vmcnt and stretch
+//  every vmcnt(0) wait that follows)
+#define MK_T(k) do { if (PROF && dbg && (tid & 63) == 0) dbg_lds[(tid >> 6) * 16 + k] = clock64(); } while (0)
 
 // ---------------------------------------------------------------------------------------------
 //  Compact plan (layout: encode_op() in weights.cpp).  Ops are read with scalar loads straight into
@@ -192,17 +195,20 @@ __device__ __forceinline__ void image_load(const ImgSrc& c, gcb_t sb, int ph0, i
   const ItemBits l = item_bits(c.n4p_shift, c.cc4_shift, c.nch_shift, tid < n ? tid : n - 1);
   const unsigned g_lo = c.src0 + static_cast<unsigned>(l.t) * c.dtap + static_cast<unsigned>(l.row) * c.ld +
                         16u * static_cast<unsigned>((l.ch << c.cc4_shift) + l.c4);
+  auto pass = [&](int i) {
+    int qh = i * MK_THREADS + (ph0 << c.n4p_shift);
+    if (i > 0) asm volatile("" : "+s"(qh));       // not speculated above the guards
+    const ItemBits h = item_bits(c.n4p_shift, c.cc4_shift, c.nch_shift, qh);            // wave-uniform
+    unsigned g_hi = static_cast<unsigned>(h.t) * c.dtap + static_cast<unsigned>(h.row) * c.ld +
+                    16u * static_cast<unsigned>(h.ch << c.cc4_shift);
+    asm volatile("" : "+s"(g_hi));                // stays one SGPR: no re-association with the lane part
+    pf[i] = ldb(sb, g_lo + g_hi);
+  };
+  pass(0);
+  if (n > MK_THREADS) {                           // one scalar branch skips all of this for the small images
 #pragma unroll
-  for (int i = 0; i < MK_MAXPF; ++i) {
-    if (i == 0 || (n > MK_THREADS && wave_q0 + i * MK_THREADS < n)) {       // wave-uniform guard (scalar branch)
-      int qh = i * MK_THREADS + (ph0 << c.n4p_shift);
-      if (i > 0) asm volatile("" : "+s"(qh));     // not speculated above the guard
-      const ItemBits h = item_bits(c.n4p_shift, c.cc4_shift, c.nch_shift, qh);          // wave-uniform
-      unsigned g_hi = static_cast<unsigned>(h.t) * c.dtap + static_cast<unsigned>(h.row) * c.ld +
-                      16u * static_cast<unsigned>(h.ch << c.cc4_shift);
-      asm volatile("" : "+s"(g_hi));              // stays one SGPR: no re-association with the lane part
-      pf[i] = ldb(sb, g_lo + g_hi);
-    }
+    for (int i = 1; i < MK_MAXPF; ++i)
+      if (wave_q0 + i * MK_THREADS < n) pass(i);  // wave-uniform guard
   }
 }
 
@@ -219,21 +225,24 @@ __device__ __forceinline__ void image_store(const OpWords& o, float* lds_in, int
   const int chan4_lo = (l.ch << cc4_shift) + l.c4;
   const bool fwd_lane = fw.on && (l.row & (fw.rmul - 1)) == fw.radd;
   const int t_cur = cv_tt2(o);
+  auto pass = [&](int i) {
+    int qh = i * MK_THREADS + (ph0 << n4p_shift);
+    if (i > 0) asm volatile("" : "+s"(qh));
+    const ItemBits h = item_bits(n4p_shift, cc4_shift, nch_shift, qh);                 // wave-uniform
+    // (h.row is 0 or a multiple of 512 / cc4 >= 32: even, so it moves whole stride-2 row pairs)
+    int l_hi = (h.ph - ph_base) * phase_b + (cv_stride2(o) ? (h.row >> 1) : h.row) * cv_pitch_b(o);
+    asm volatile("" : "+s"(l_hi));
+    // forwarded by the producing layer's epilogue: current-frame tap, float4 columns [lo4,hi4), matching rows
+    const int t = l.t | h.t;
+    const unsigned col = static_cast<unsigned>(chan4_lo + (h.ch << cc4_shift) - fw.lo4);
+    const bool skip = fwd_lane && t == t_cur && col < static_cast<unsigned>(fw.hi4 - fw.lo4);
+    if ((i > 0 || tid < n) && !skip) lds4(lds_in, l_lo + l_hi) = pf[i];
+  };
+  pass(0);
+  if (n > MK_THREADS) {
 #pragma unroll
-  for (int i = 0; i < MK_MAXPF; ++i) {
-    if (i == 0 || (n > MK_THREADS && wave_q0 + i * MK_THREADS < n)) {
-      int qh = i * MK_THREADS + (ph0 << n4p_shift);
-      if (i > 0) asm volatile("" : "+s"(qh));
-      const ItemBits h = item_bits(n4p_shift, cc4_shift, nch_shift, qh);               // wave-uniform
-      // (h.row is 0 or a multiple of 512 / cc4 >= 32: even, so it moves whole stride-2 row pairs)
-      int l_hi = (h.ph - ph_base) * phase_b + (cv_stride2(o) ? (h.row >> 1) : h.row) * cv_pitch_b(o);
-      asm volatile("" : "+s"(l_hi));
-      // forwarded by the producing layer's epilogue: current-frame tap, float4 columns [lo4,hi4), matching rows
-      const int t = l.t | h.t;
-      const unsigned col = static_cast<unsigned>(chan4_lo + (h.ch << cc4_shift) - fw.lo4);
-      const bool skip = fwd_lane && t == t_cur && col < static_cast<unsigned>(fw.hi4 - fw.lo4);
-      if ((i > 0 || tid < n) && !skip) lds4(lds_in, l_lo + l_hi) = pf[i];
-    }
+    for (int i = 1; i < MK_MAXPF; ++i)
+      if (wave_q0 + i * MK_THREADS < n) pass(i);
   }
   // halo rows (<= 3 per phase, 4 slots): thread -> (phase, slot, float4 column), no division
   const int vrows = cv_vrows(o);
@@ -395,8 +404,10 @@ __device__ __forceinline__ void conv_epilogue(const OpWords& o, gcb_t sb, float*
 // One conv-like layer for one stream.
 //   cy  in : this wave's first weight chunk + this lane's epilogue parameters (fetched by the previous op)
 //       out: the same for the next conv layer (a layer with no conv successor re-reads its own)
+template <bool PROF>
 __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, bool nconv, gcb_t sb, gcb_t wb, float* lds_in,
                                            float* lds_out, int tid, Carry& cy, unsigned long long* sub, unsigned long long* dbg) {
+  unsigned long long* dbg_lds = reinterpret_cast<unsigned long long*>(lds_out + MK_LDS_OUT);
   MK_T(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SGPR
@@ -445,7 +456,11 @@ __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, b
 
   f32x16 acc[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+  if (tw == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[1][r] = 0.f;
+  }
   // One register set and ONE static load site serve both image prefetches -- the next phase of THIS
   // layer (rounds before the last) and, in the last round, the next layer's image rows this layer does
   // not produce (previous-frame tap, skip-connection channels; HBM, long latency).  Both are issued in
@@ -555,6 +570,10 @@ __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, b
   __syncthreads();               // HBM stores visible to the workgroup; next image complete; exchange buffer free
   MK_STAMP(5);
   MK_T(11);
+  if (PROF && dbg) {
+    __syncthreads();
+    if (tid < 128 && (tid & 15) < 12) dbg[tid] = dbg_lds[tid];
+  }
 }
 
 __device__ __forceinline__ float mk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -794,12 +813,15 @@ __device__ __forceinline__ void out_conv_op(const OpWords& o, const StepArgs& a,
   __syncthreads();
 }
 
+// PROF = true: the profiling build of the same kernel (wall-clock stamps at op / phase boundaries of
+// workgroup 0); the production build carries none of the stamp code.
+template <bool PROF>
 __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
   float* lds_out = lds + MK_LDS_IN;
   const int n_ops = a.n_ops;
-  unsigned long long* prof = a.prof;
+  unsigned long long* prof = PROF ? a.prof : nullptr;
   const cplan_t plan = (cplan_t)(unsigned long long)a.plan;
   const gcb_t wb = (gcb_t)(unsigned long long)a.wbase;
   // `fresh_tid()` re-materialises the thread id behind an opaque asm at every layer: without it the
@@ -826,7 +848,8 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
         unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
         unsigned long long* dbg = (sub && i == a.dbg_op) ? prof + n_ops * 9 + 3 : nullptr;
         if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 15] = clock64();
-        conv_layer(cur, nxt, nconv, sb, wb, lds_in, lds_out, tid, cy, sub, dbg);
+        if (dbg) __syncthreads();      // (the stamp's store must not sit in vmcnt during the op)
+        conv_layer<PROF>(cur, nxt, nconv, sb, wb, lds_in, lds_out, tid, cy, sub, dbg);
       } else {
         if (op == DEV_OP_LSTM) {
           LstmParams p;
@@ -854,12 +877,16 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
 hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nutls_stream_step_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nutls_stream_step_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MK_LDS_BYTES));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(nutls_stream_step_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MK_LDS_BYTES));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(nutls_stream_step_kernel, dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
+  if (a.prof) hipLaunchKernelGGL(nutls_stream_step_kernel<true>, dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(nutls_stream_step_kernel<false>, dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
