@@ -89,7 +89,7 @@ struct StageStates {
 
 struct ConvLayerW { float *wpk, *bias, *gamma, *beta; float alpha; };
 struct LstmW { float *wxT, *whT, *bias, *wdT, *bd; int din, dout; };
-struct CtfaW { float *w1T, *b1, *w2T, *b2; };
+struct CtfaW { float *w1T, *b1, *w2T, *b2, *w2; };   // w2: [64][16] as stored (persistent kernel), w2T: [16][64]
 
 struct Engine {
   int B = 0, device = 0;
@@ -379,6 +379,7 @@ static int prep_weights(Engine* e, const WeightMap& wm) {
         if ((rc = upload(e, transpose2d(*w1, 16, 64), &cw.w1T))) return rc;
         if ((rc = upload(e, b1->data, &cw.b1))) return rc;
         if ((rc = upload(e, transpose2d(*w2, 64, 16), &cw.w2T))) return rc;
+        if ((rc = upload(e, w2->data, &cw.w2))) return rc;
         if ((rc = upload(e, b2->data, &cw.b2))) return rc;
         e->ctfaw[P + br] = cw;
       }
@@ -632,6 +633,7 @@ static void build_stage(Engine* e, std::vector<Launch>* plan, int side, int s, i
   c.x = dD; c.x_ld = dD_ld; c.e0 = cur(ss.conv[0]); c.e0_ld = c1; c.y = y_dst; c.y_ld = y_ld;
   c.ta_w1T = ta.w1T; c.ta_b1 = ta.b1; c.ta_w2T = ta.w2T; c.ta_b2 = ta.b2;
   c.fa_w1T = fa.w1T; c.fa_b1 = fa.b1; c.fa_w2T = fa.w2T; c.fa_b2 = fa.b2;
+  c.ta_w2 = ta.w2; c.fa_w2 = fa.w2;
   c.B = e->B; c.F = st.f0; c.sstride = static_cast<long long>(e->sstride);
   plan->push_back(L);
 }

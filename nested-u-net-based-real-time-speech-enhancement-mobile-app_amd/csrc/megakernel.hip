@@ -139,6 +139,7 @@ __device__ __forceinline__ void decode_ctfa(const OpWords& o, const StepArgs& a,
   p.ta_w1T = wptr(a.wbase, o.w[4]); p.ta_b1 = wptr(a.wbase, o.w[5]); p.ta_w2T = wptr(a.wbase, o.w[6]); p.ta_b2 = wptr(a.wbase, o.w[7]);
   p.fa_w1T = wptr(a.wbase, o.w[8]); p.fa_b1 = wptr(a.wbase, o.w[9]); p.fa_w2T = wptr(a.wbase, o.w[10]); p.fa_b2 = wptr(a.wbase, o.w[11]);
   p.F = static_cast<int>(o.w[12]); p.B = a.B; p.sstride = a.sstride;
+  p.ta_w2 = wptr(a.wbase, o.w[13]); p.fa_w2 = wptr(a.wbase, o.w[14]);
 }
 
 // global / LDS accesses by byte offset
@@ -677,90 +678,138 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, gcb_
   __syncthreads();
 }
 
+// Fast transcendental forms (v_exp_f32 / v_rcp_f32, ~1 ulp): the IEEE expf / division sequences are
+// 10-30 dependent instructions each, on the critical path of the 21..64 threads that evaluate gates.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// 64 -> 16 (ReLU) -> 64 perceptron of the CTFA gates, evaluated by ONE wave without barriers: lane c
+// holds input channel c.  The 16 hidden sums over the 64 lanes go through a [64][20] LDS scratch (lane
+// (q, u) adds 16 of the 64 products of unit u, then the four quarters meet in two lane exchanges); the
+// hidden vector is broadcast from lanes 0..15 with v_readlane.  Returns the pre-activation of channel c.
+__device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1)[4], float b1_u, const f32x4 (&w2)[4], float b2, float* scr, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(scr + lane * 20 + 4 * q) = w1[q] * in;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // same wave wrote it: no barrier needed
+  const int u = lane & 15, qtr = lane >> 4;
+  float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    h0 += scr[(qtr * 16 + i) * 20 + u];
+    h1 += scr[(qtr * 16 + i + 1) * 20 + u];
+  }
+  float hsum = h0 + h1;
+  hsum += __shfl_xor(hsum, 16);
+  hsum += __shfl_xor(hsum, 32);
+  const float hid = fmaxf(hsum + b1_u, 0.f);               // lanes 0..15 (and their copies): hidden unit u
+  float a0 = b2, a1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    a0 = fmaf(w2[k >> 2][k & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hid), k)), a0);
+    a1 = fmaf(w2[(k + 1) >> 2][(k + 1) & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hid), k + 1)), a1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // scratch reads done before the next call overwrites it
+  return a0 + a1;
+}
+
 // CTFA gate + residual for one stream (ctfa_rt, models/proposed.py:162-196).
-// Wave u computes hidden unit u of the 64->16 layers (one product per lane + wave reduction);
-// the MLP weights are fetched before the mean-over-F reduction so their latency is hidden.
+// One memory round trip and three barriers: every thread fetches its rows of x and of the residual (and
+// keeps them in registers), the column sums of x meet in LDS, wave 0 alone evaluates both gate
+// perceptrons (no barriers inside), then everybody applies the gate to the rows it still holds.
+template <bool PROF>
 __device__ __forceinline__ void ctfa_layer(const CtfaParams& p, int stream, gcb_t sbb, float* lds, float* lds_in, int tid, bool hand,
-                                           int fwd_coff, const OpWords& nx) {
-  f32x4 pfx[MK_MAXPF];
-  if (hand) image_load(img_src(nx), sbb, 0, cv_nph(nx), tid, pfx);
-  float* part = lds;               // [32][64]
-  float* m = lds + 4096;           // [64]
-  float* hid = m + 64;             // [16]
-  float* ta = hid + 16;            // [64]
-  float* gate = ta + 64;           // [64]
+                                           int fwd_coff, const OpWords& nx, unsigned long long* dbg) {
+  unsigned long long* dbg_lds = reinterpret_cast<unsigned long long*>(lds + MK_LDS_OUT);
+  MK_T(0);
+  float* part = lds;               // [8][64]   column sums per wave
+  float* gate = lds + 512;         // [64]
+  float* scr = gate + 64;          // [64][20]  perceptron scratch (wave 0)
   const int c4 = tid & 15, rg = tid >> 4;            // 32 row groups x 16 float4 columns
-  const int lane = tid & 63, wave = tid >> 6;        // wave w owns hidden units w and w + 8
-  const float w1_ta0 = GF(p.ta_w1T)[lane * 16 + wave], w1_ta1 = GF(p.ta_w1T)[lane * 16 + wave + 8];
-  const float w1_fa0 = GF(p.fa_w1T)[lane * 16 + wave], w1_fa1 = GF(p.fa_w1T)[lane * 16 + wave + 8];
-  const float b1_ta0 = GF(p.ta_b1)[wave], b1_ta1 = GF(p.ta_b1)[wave + 8];
-  const float b1_fa0 = GF(p.fa_b1)[wave], b1_fa1 = GF(p.fa_b1)[wave + 8];
-  float w2_ta[16], w2_fa[16];
-  float b2_ta = 0.f, b2_fa = 0.f;
-  if (tid < 64) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      w2_ta[u] = GF(p.ta_w2T)[u * 64 + tid];
-      w2_fa[u] = GF(p.fa_w2T)[u * 64 + tid];
-    }
-    b2_ta = GF(p.ta_b2)[tid];
-    b2_fa = GF(p.fa_b2)[tid];
-  }
+  const int lane = tid & 63;
+  const bool w0 = tid < 64;
   const float* xb = p.x + static_cast<size_t>(stream) * p.sstride;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int f = rg; f < p.F; f += 32) s += *G4(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
-  *reinterpret_cast<f32x4*>(part + rg * 64 + 4 * c4) = s;
-  lds_barrier();
-  if (tid < 64) {
-    float a = 0.f;
-#pragma unroll 16
-    for (int r = 0; r < 32; ++r) a += part[r * 64 + tid];
-    m[tid] = a / static_cast<float>(p.F);
-  }
-  lds_barrier();
-  {
-    const float t0 = wave_sum(w1_ta0 * m[lane]), t1 = wave_sum(w1_ta1 * m[lane]);
-    if (lane == 0) { hid[wave] = fmaxf(t0 + b1_ta0, 0.f); hid[wave + 8] = fmaxf(t1 + b1_ta1, 0.f); }
-  }
-  lds_barrier();
-  float ta_c = 0.f;
-  if (tid < 64) {
-    float a = b2_ta;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) a = fmaf(w2_ta[u], hid[u], a);
-    ta_c = mk_sigmoid(a);
-    ta[tid] = ta_c;
-  }
-  lds_barrier();
-  {
-    const float tv = ta[lane] * (1.0f / 32.0f);
-    const float t0 = wave_sum(w1_fa0 * tv), t1 = wave_sum(w1_fa1 * tv);
-    lds_barrier();             // everyone has read hid (TA pass) before it is overwritten
-    if (lane == 0) { hid[wave] = fmaxf(t0 + b1_fa0, 0.f); hid[wave + 8] = fmaxf(t1 + b1_fa1, 0.f); }
-  }
-  lds_barrier();
-  if (tid < 64) {
-    float a = b2_fa;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) a = fmaf(w2_fa[u], hid[u], a);
-    gate[tid] = mk_sigmoid(a) * ta_c;
-  }
-  lds_barrier();
-  const f32x4 g4 = *reinterpret_cast<const f32x4*>(gate + 4 * c4);
   const float* eb = p.e0 + static_cast<size_t>(stream) * p.sstride;
   float* yb = p.y + static_cast<size_t>(stream) * p.sstride;
-  for (int f = rg; f < p.F; f += 32) {
-    const f32x4 xv = *G4(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
-    const f32x4 ev = *G4(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
-    const f32x4 yv = xv * g4 + ev;
-    *G4W(yb + static_cast<size_t>(f) * p.y_ld + 4 * c4) = yv;
-    if (hand) img_put4(nx, lds_in, f, (fwd_coff >> 2) + c4, yv);
+  // ---- every global load of the op, oldest-needed first
+  f32x4 xv[8], ev[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = rg + 32 * i;
+    if (f < p.F) xv[i] = ld4(xb, static_cast<unsigned>(f * p.x_ld + 4 * c4));
   }
+  f32x4 w1t[4], w1f[4], w2t[4], w2f[4];
+  float b1t = 0.f, b1f = 0.f, b2t = 0.f, b2f = 0.f;
+  if (w0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      w1t[q] = ld4(p.ta_w1T, static_cast<unsigned>(lane * 16 + 4 * q));
+      w2t[q] = ld4(p.ta_w2, static_cast<unsigned>(lane * 16 + 4 * q));
+      w1f[q] = ld4(p.fa_w1T, static_cast<unsigned>(lane * 16 + 4 * q));
+      w2f[q] = ld4(p.fa_w2, static_cast<unsigned>(lane * 16 + 4 * q));
+    }
+    b1t = ld1(p.ta_b1, static_cast<unsigned>(lane & 15)); b1f = ld1(p.fa_b1, static_cast<unsigned>(lane & 15));
+    b2t = ld1(p.ta_b2, static_cast<unsigned>(lane)); b2f = ld1(p.fa_b2, static_cast<unsigned>(lane));
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = rg + 32 * i;
+    if (f < p.F) ev[i] = ld4(eb, static_cast<unsigned>(f * p.e0_ld + 4 * c4));
+  }
+  f32x4 pfx[MK_MAXPF];
+  if (hand) image_load(img_src(nx), sbb, 0, cv_nph(nx), tid, pfx);
+  MK_T(1);
+
+  // ---- column sums of x
+  f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (rg + 32 * i < p.F) s4 += xv[i];
+  // the wave's four row groups meet in registers (lanes 16 / 32 apart hold the same float4 column)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s4[j] += __shfl_xor(s4[j], 16);
+    s4[j] += __shfl_xor(s4[j], 32);
+  }
+  MK_T(2);
+  if (lane < 16) *reinterpret_cast<f32x4*>(part + (tid >> 6) * 64 + 4 * c4) = s4;
+  lds_barrier();
+  MK_T(3);
+  if (w0) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < MK_WAVES; ++r) m += part[r * 64 + lane];
+    m = m * __builtin_amdgcn_rcpf(static_cast<float>(p.F));      // F is a power of two: exact
+    MK_T(4);
+    const float ta_c = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t, scr, lane));
+    MK_T(5);
+    const float fa_c = fast_sigmoid(gate_mlp(ta_c * (1.0f / 32.0f), w1f, b1f, w2f, b2f, scr, lane));
+    gate[lane] = fa_c * ta_c;
+    MK_T(6);
+  }
+  lds_barrier();
+  MK_T(7);
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(gate + 4 * c4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = rg + 32 * i;
+    if (f < p.F) {
+      const f32x4 yv = xv[i] * g4 + ev[i];
+      st4(yb, static_cast<unsigned>(f * p.y_ld + 4 * c4), yv);
+      if (hand) img_put4(nx, lds_in, f, (fwd_coff >> 2) + c4, yv);
+    }
+  }
+  MK_T(8);
   if (hand) {
     const FwdWin fw = {fwd_coff >> 2, (fwd_coff >> 2) + 16, 1, 0, true};
     image_store(nx, lds_in, 0, cv_nph(nx), 0, fw, tid, pfx);
   }
+  MK_T(9);
   __syncthreads();
+  MK_T(10);
+  if (PROF && dbg) {
+    __syncthreads();
+    if (tid < 128 && (tid & 15) < 12) dbg[tid] = dbg_lds[tid];
+  }
 }
 
 __device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs& a, int stream, float* lds_in, int tid, bool hand,
@@ -844,11 +893,11 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
       const int op = static_cast<int>(cur.w[23]);
       const bool nc_hand = nconv && b0(cur.w[22]) != 0;      // non-conv op -> conv hand-off
       const int nc_coff = b1(cur.w[22]);
+      unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
+      unsigned long long* dbg = (sub && i == a.dbg_op) ? prof + n_ops * 9 + 3 : nullptr;
+      if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 15] = clock64();
+      if (dbg) __syncthreads();      // (the stamp's store must not sit in vmcnt during the op)
       if (op == DEV_OP_CONV) {
-        unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
-        unsigned long long* dbg = (sub && i == a.dbg_op) ? prof + n_ops * 9 + 3 : nullptr;
-        if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 15] = clock64();
-        if (dbg) __syncthreads();      // (the stamp's store must not sit in vmcnt during the op)
         conv_layer<PROF>(cur, nxt, nconv, sb, wb, lds_in, lds_out, tid, cy, sub, dbg);
       } else {
         if (op == DEV_OP_LSTM) {
@@ -858,7 +907,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
         } else if (op == DEV_OP_CTFA) {
           CtfaParams p;
           decode_ctfa(cur, a, p);
-          ctfa_layer(p, stream, sb, lds_out, lds_in, tid, nc_hand, nc_coff, nxt);
+          ctfa_layer<PROF>(p, stream, sb, lds_out, lds_in, tid, nc_hand, nc_coff, nxt, dbg);
         } else if (op == DEV_OP_INLAYER) {
           input_layer_op(cur, a, stream, lds_in, tid, nc_hand, nxt);
         } else if (op == DEV_OP_DDB) {

@@ -111,6 +111,7 @@ struct CtfaParams {
   float* y; int y_ld;            // out  [B,F,64]
   const float* ta_w1T; const float* ta_b1; const float* ta_w2T; const float* ta_b2;  // [64][16],[16],[16][64],[64]
   const float* fa_w1T; const float* fa_b1; const float* fa_w2T; const float* fa_b2;
+  const float* ta_w2; const float* fa_w2;   // [64][16] (output channel major): the persistent kernel reads a lane's 16 weights as 4 float4
   int B, F;
   long long sstride;
 };

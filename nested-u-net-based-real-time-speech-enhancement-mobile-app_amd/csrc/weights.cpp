@@ -214,6 +214,7 @@ CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) 
       o.w[4] = off_of(p.ta_w1T, wbase); o.w[5] = off_of(p.ta_b1, wbase); o.w[6] = off_of(p.ta_w2T, wbase); o.w[7] = off_of(p.ta_b2, wbase);
       o.w[8] = off_of(p.fa_w1T, wbase); o.w[9] = off_of(p.fa_b1, wbase); o.w[10] = off_of(p.fa_w2T, wbase); o.w[11] = off_of(p.fa_b2, wbase);
       o.w[12] = static_cast<uint32_t>(p.F);
+      o.w[13] = off_of(p.ta_w2, wbase); o.w[14] = off_of(p.fa_w2, wbase);
       break;
     }
     case DEV_OP_INLAYER: {
