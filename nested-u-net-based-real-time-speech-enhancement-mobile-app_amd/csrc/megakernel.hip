@@ -388,7 +388,7 @@ __device__ __forceinline__ void conv_epilogue(const OpWords& o, gcb_t sb, float*
       const float mean = group_sum<LPG>(v[0] + v[1] + v[2] + v[3]) * (1.0f / GC);
       v -= mean;
       const float q = group_sum<LPG>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-      const float rstd = 1.0f / sqrtf(q * (1.0f / GC) + MK_LN_EPS);
+      const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / GC) + MK_LN_EPS);     // v_rsq_f32, 1 ulp
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float y = v[i] * rstd * gm[i] + bt[i];
@@ -577,7 +577,11 @@ __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, b
   }
 }
 
-__device__ __forceinline__ float mk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Fast transcendental forms (v_exp_f32 / v_rcp_f32, ~1 ulp): the IEEE expf / division sequences are
+// 10-30 dependent instructions each, on the critical path of the 21..64 threads that evaluate gates.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -654,10 +658,10 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, gcb_
   }
   lds_barrier();
   if (tid < 21) {
-    const float gi = mk_sigmoid(z[tid]), gf = mk_sigmoid(z[21 + tid]);
-    const float gg = tanhf(z[42 + tid]), go = mk_sigmoid(z[63 + tid]);
+    const float gi = fast_sigmoid(z[tid]), gf = fast_sigmoid(z[21 + tid]);
+    const float gg = fast_tanh(z[42 + tid]), go = fast_sigmoid(z[63 + tid]);
     const float c_new = gf * c_old + gi * gg;
-    const float h_new = go * tanhf(c_new);
+    const float h_new = go * fast_tanh(c_new);
     st1(p.c_out + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(tid), c_new);
     st1(p.h_out + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(tid), h_new);
     hn[tid] = h_new;
@@ -677,11 +681,6 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, gcb_
   }
   __syncthreads();
 }
-
-// Fast transcendental forms (v_exp_f32 / v_rcp_f32, ~1 ulp): the IEEE expf / division sequences are
-// 10-30 dependent instructions each, on the critical path of the 21..64 threads that evaluate gates.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // 64 -> 16 (ReLU) -> 64 perceptron of the CTFA gates, evaluated by ONE wave without barriers: lane c
 // holds input channel c.  The 16 hidden sums over the 64 lanes go through a [64][20] LDS scratch (lane
@@ -833,7 +832,7 @@ __device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs&
     float q = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + MK_LN_EPS);
+    const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / 64.0f) + MK_LN_EPS);
     f32x4 o4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
