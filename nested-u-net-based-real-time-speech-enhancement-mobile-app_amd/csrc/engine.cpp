@@ -87,7 +87,7 @@ struct StageStates {
   int h, c;
 };
 
-struct ConvLayerW { float *wpk, *bias, *gamma, *beta; float alpha; };
+struct ConvLayerW { float *wpk, *wpk16, *bias, *gamma, *beta; float alpha; };
 struct LstmW { float *wxT, *whT, *bias, *wdT, *bd; int din, dout; };
 struct CtfaW { float *w1T, *b1, *w2T, *b2, *w2; };   // w2: [64][16] as stored (persistent kernel), w2T: [16][64]
 
@@ -243,6 +243,7 @@ static int prep_conv(Engine* e, const WeightMap& wm, const std::string& layer, c
   ConvLayerW cw{};
   int rc = upload(e, pack_conv_weights(*w, perm, taps, sh.tt, sh.cin, sh.nt), &cw.wpk);
   if (rc) return rc;
+  if ((rc = upload(e, pack_conv_weights16(*w, perm, taps, sh.tt, sh.cin, sh.nt), &cw.wpk16))) return rc;
   std::vector<float> bp(perm.size());
   for (size_t i = 0; i < perm.size(); ++i) bp[i] = b->data[perm[i]];
   if ((rc = upload(e, bp, &cw.bias))) return rc;
@@ -519,7 +520,7 @@ static void push_conv(Engine* e, std::vector<Launch>* plan, const std::string& w
   L.name = wkey;
   L.encoder_strided = enc_strided;
   ConvParams& p = L.conv;
-  p.src0 = src0; p.src1 = src1; p.wpk = w.wpk; p.bias = w.bias; p.gamma = w.gamma; p.beta = w.beta;
+  p.src0 = src0; p.src1 = src1; p.wpk = w.wpk; p.wpk16 = w.wpk16; p.bias = w.bias; p.gamma = w.gamma; p.beta = w.beta;
   p.dst0 = dst0; p.dst1 = dst1; p.src_ld = src_ld; p.ld0 = ld0; p.ld1 = ld1;
   p.B = e->B; p.F_in = f_in; p.F_out = f_out; p.log2_fout = ilog2(f_out);
   p.row_mul = row_mul; p.row_add = row_add; p.alpha = w.alpha; p.sstride = static_cast<long long>(e->sstride);
@@ -793,7 +794,10 @@ static int upload_device_plans(Engine* e) {
       std::memset(&d, 0, sizeof(d));
       d.ck = L.ck;
       switch (L.kind) {
-        case Launch::CONV: d.op = DEV_OP_CONV; d.conv = L.conv; d.cp = make_conv_plan(L.ck, L.conv); d.cp.fwd_rmul = 1; break;
+        case Launch::CONV:
+          d.op = DEV_OP_CONV; d.conv = L.conv; d.cp = make_conv_plan(L.ck, L.conv); d.cp.fwd_rmul = 1;
+          if (!getenv("NUTLS_NO_S16")) apply_s16_plan(&d.cp, L.conv);
+          break;
         case Launch::LSTM: d.op = DEV_OP_LSTM; d.lstm = L.lstm; break;
         case Launch::CTFA: d.op = DEV_OP_CTFA; d.ctfa = L.ctfa; break;
         case Launch::INLAYER: d.op = DEV_OP_INLAYER; d.inl = L.inl; break;
@@ -806,8 +810,8 @@ static int upload_device_plans(Engine* e) {
       for (size_t i = 0; i < dv.size(); ++i)
         if (dv[i].op == DEV_OP_CONV) {
           const ConvPlan& c = dv[i].cp;
-          fprintf(stderr, "%-24s F %3d->%3d merged %d rounds %d RG %2d KS %2d gpk %2d tiles %2d | staged_by_prev %d pf0 %d hand %d fwd %d@%d r%%%d==%d pre0 %d\n",
-                  e->plan[par][i].name.c_str(), dv[i].conv.F_in, dv[i].conv.F_out, c.merged, c.rounds, c.RG, c.KS, c.gpk, c.tiles,
+          fprintf(stderr, "%-24s F %3d->%3d s16 %d merged %d rounds %d RG %2d KS %2d gpk %2d tiles %2d | staged_by_prev %d pf0 %d hand %d fwd %d@%d r%%%d==%d pre0 %d\n",
+                  e->plan[par][i].name.c_str(), dv[i].conv.F_in, dv[i].conv.F_out, c.s16, c.merged, c.rounds, c.RG, c.KS, c.gpk, c.tiles,
                   c.staged_by_prev, c.pf_phase0_ready, c.hand_next, c.fwd_sel, c.fwd_coff4, c.fwd_rmul, c.fwd_radd, c.pre_next_phase0);
         } else {
           fprintf(stderr, "%-24s (op %d) nc_hand %d fwd_coff %d\n", e->plan[par][i].name.c_str(), dv[i].op, dv[i].nc_hand, dv[i].nc_fwd_coff);

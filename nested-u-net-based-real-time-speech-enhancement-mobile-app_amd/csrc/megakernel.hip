@@ -96,6 +96,12 @@ __device__ __forceinline__ OpWords load_op(cplan_t plan, int i) {
   for (int k = 0; k < MK_OP_WORDS; ++k) o.w[k] = plan[i * MK_OP_WORDS + k];
   return o;
 }
+// Same words again, through a fresh scalar load the compiler cannot merge with the first one: lets the
+// first copy die before a register-hungry region instead of being spilled to VGPR lanes across it.
+__device__ __forceinline__ OpWords reload_op(cplan_t plan, int i) {
+  asm volatile("" : "+s"(i));
+  return load_op(plan, i);
+}
 __device__ __forceinline__ int b0(unsigned w) { return w & 255; }
 __device__ __forceinline__ int b1(unsigned w) { return (w >> 8) & 255; }
 __device__ __forceinline__ int b2(unsigned w) { return (w >> 16) & 255; }
@@ -121,6 +127,7 @@ CV(phase_b, o.w[16])       CV(slot_b, o.w[17])
 CV(RG, b0(o.w[18]))        CV(KS, b1(o.w[18]))         CV(gpk, b2(o.w[18]))        CV(gpc, b3(o.w[18]))
 CV(tasks, b0(o.w[19]))     CV(tasks_shift, b1(o.w[19])) CV(tw, b2(o.w[19]))        CV(fwd_coff4, b3(o.w[19]))
 CV(opitch_b, h0(o.w[20]))  CV(units, h1(o.w[20]))
+CV(s16, o.w[21] & 1)       // F_out <= 16: 16x16x4 MFMA tiles, fragments are 16-channel K groups, nt counts 16-channel tiles
 #undef CV
 __device__ __forceinline__ int cv_cc_b(const OpWords& o) { return 16 << cv_cc4_shift(o); }      // bytes of one channel chunk
 
@@ -307,7 +314,7 @@ __device__ __forceinline__ KCursor kcursor_init(const OpWords& o, int ks) {
   // (no integer divisions: gpc is 4 or 8, kf is 1, 2 or 3, seg < 64)
   const int gpc = cv_gpc(o), kf = cv_kf(o);
   const int g_first = ks * cv_gpk(o);
-  const int gshift = gpc == 8 ? 3 : 2;
+  const int gshift = gpc == 8 ? 3 : (gpc == 4 ? 2 : 1);
   const int seg = g_first >> gshift;
   KCursor k;
   k.gg = g_first & (gpc - 1);
@@ -316,27 +323,37 @@ __device__ __forceinline__ KCursor kcursor_init(const OpWords& o, int ks) {
   return k;
 }
 
-// The 16 MFMAs of one 4-group chunk for the first position tile and, in 16-tile layers, 16 more for the
-// second tile (same weight fragments).  The first tile's accumulator has ONE update site and the second
-// one a conditional in-place one: a two-sided branch (tile count 1 / 2) made the register allocator copy
-// both accumulators in and out of temporaries around every chunk -- each copy waiting for the MFMA chain.
-__device__ __forceinline__ void chunk_mfma(f32x16& acc0, f32x16& acc1, bool two, const f32x4 (&wa)[4], float* lds_in, int lb0, int lb1) {
+// MFMAs of one 4-fragment chunk = two fragment pairs (a pair never straddles a frequency-tap segment;
+// lbA / lbB: B-operand offsets of the pairs).
+//   32-position tiles (v_mfma_f32_32x32x2_f32): a fragment is 8 channels, 4 MFMAs per fragment and tile; the
+//     first tile's accumulator has ONE update site, the second tile's (16-tile layers) a conditional in-place
+//     one -- any second site (a two-sided branch, a conditional tail) makes the register allocator copy the
+//     accumulators in and out of temporaries around every chunk, each copy waiting for the MFMA chain.
+//   16-position tiles (v_mfma_f32_16x16x4_f32, layers with F_out <= 16): a fragment is 16 channels.
+__device__ __forceinline__ void chunk_mfma32(f32x16& acc0, f32x16& acc1, bool two, const f32x4 (&w)[4], float* lds_in, int lbA0, int lbB0,
+                                             int lbA1, int lbB1) {
   f32x4 b[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) b[u] = lds4(lds_in, lb0 + 32 * u);     // B fragments: one ds_read_b128 per group
+  b[0] = lds4(lds_in, lbA0); b[1] = lds4(lds_in, lbA0 + 32); b[2] = lds4(lds_in, lbB0); b[3] = lds4(lds_in, lbB0 + 32);
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], b[u][j], acc0, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], b[u][j], acc0, 0, 0, 0);
   if (two) {
     f32x4 d[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) d[u] = lds4(lds_in, lb1 + 32 * u);
+    d[0] = lds4(lds_in, lbA1); d[1] = lds4(lds_in, lbA1 + 32); d[2] = lds4(lds_in, lbB1); d[3] = lds4(lds_in, lbB1 + 32);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], d[u][j], acc1, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], d[u][j], acc1, 0, 0, 0);
   }
+}
+__device__ __forceinline__ void chunk_mfma16(f32x4& acc, const f32x4 (&w)[4], float* lds_in, int lbA, int lbB) {
+  f32x4 b[4];
+  b[0] = lds4(lds_in, lbA); b[1] = lds4(lds_in, lbA + 64); b[2] = lds4(lds_in, lbB); b[3] = lds4(lds_in, lbB + 64);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][j], b[u][j], acc, 0, 0, 0);
 }
 
 // DPP lane exchange (no LDS crossbar round trip): quad xor 1, quad xor 2, mirror inside 8 / 16 lanes
@@ -406,13 +423,16 @@ __device__ __forceinline__ void conv_epilogue(const OpWords& o, gcb_t sb, float*
 //   cy  in : this wave's first weight chunk + this lane's epilogue parameters (fetched by the previous op)
 //       out: the same for the next conv layer (a layer with no conv successor re-reads its own)
 template <bool PROF>
-__device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, bool nconv, gcb_t sb, gcb_t wb, float* lds_in,
+__device__ __forceinline__ void conv_layer(const OpWords& o_in, const OpWords& n_in, cplan_t plan, int op_i, int nxt_i, bool nconv, gcb_t sb, gcb_t wb,
+                                           float* lds_in,
                                            float* lds_out, int tid, Carry& cy, unsigned long long* sub, unsigned long long* dbg) {
   unsigned long long* dbg_lds = reinterpret_cast<unsigned long long*>(lds_out + MK_LDS_OUT);
   MK_T(0);
+  OpWords o = o_in, n = n_in;      // (re-read after the MFMA loop, see below)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SGPR
-  const int pl = lane & 31, h = lane >> 5;
+  const bool s16 = cv_s16(o);
+  const int pl = s16 ? (lane & 15) : (lane & 31), h = s16 ? (lane >> 4) : (lane >> 5);     // tile column, K sub-block of the lane
   const int tasks = cv_tasks(o), nt = cv_nt(o), tw = cv_tw(o), F_out = cv_F_out(o);
   const bool active = wave < tasks * cv_KS(o);
   const int ks = wave >> cv_tasks_shift(o), tl = wave & (tasks - 1);
@@ -462,6 +482,7 @@ __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, b
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[1][r] = 0.f;
   }
+  f32x4 acc16 = {0.f, 0.f, 0.f, 0.f};
   // One register set and ONE static load site serve both image prefetches -- the next phase of THIS
   // layer (rounds before the last) and, in the last round, the next layer's image rows this layer does
   // not produce (previous-frame tap, skip-connection channels; HBM, long latency).  Both are issued in
@@ -469,26 +490,50 @@ __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, b
   // order).  Two load sites would meet in phi copies of pending loads, and such a copy costs a full
   // vmcnt(0) wait.  None of the barriers in between drains vmcnt.
   f32x4 pfx[MK_MAXPF];
-  const int nchunks = active ? (cv_gpk(o) >> 2) : 1;     // idle waves run one empty chunk per round: they stage too
+  const int gpk = active ? cv_gpk(o) : 4;                // idle waves run one empty chunk per round: they stage too
   const int rounds = cv_rounds(o), kf_n = cv_kf(o), gpc = cv_gpc(o), phase_b = cv_phase_b(o);
   const int cc_b = cv_cc_b(o), stride2 = cv_stride2(o);
+  const int frag_b = s16 ? 64 : 32;                      // bytes of image channels one K fragment covers
 #pragma unroll 1
   for (int rd = 0; rd < rounds; ++rd) {
     const bool last = rd + 1 == rounds;
     KCursor k = kcursor_init(o, ks);
+    if (!active) k.gg = 0;
     unsigned wcur = wbase_b + static_cast<unsigned>(rd) * round_step_b;
+    auto boff_of = [&](const KCursor& q) {
+      const int koff = stride2 ? ((q.kf >> 1) * pitch_b + (q.kf & 1) * cc_b) : q.kf * pitch_b;
+      return q.phl * phase_b + koff + frag_b * q.gg;
+    };
+    auto advance = [&](KCursor& q, int ng) {
+      q.gg += ng;
+      if (q.gg == gpc) { q.gg = 0; if (++q.kf == kf_n) { q.kf = 0; ++q.phl; } }
+    };
+    // chunks of 4 fragments = two pairs; only 2-fragment segments (16-position tiles of a 32-channel
+    // image) put the second pair into the next segment
+    int rem = gpk;
 #pragma unroll 1
-    for (int ch = 0; ch < nchunks; ++ch) {
+    while (rem > 0) {
+      constexpr int nfr = 4;
+      rem -= nfr;
+      const int boffA = boff_of(k);
+      int boffB = boffA + 2 * frag_b;
+      if (gpc == 2) {
+        advance(k, 2);
+        boffB = boff_of(k);
+        advance(k, 2);
+      } else {
+        advance(k, 4);
+      }
       // prefetch the next chunk: next in this slice, else the first chunk of the next round's slice
       // (wave-uniform condition -> scalar branch; nothing is fetched after the layer's last chunk)
-      const bool more = active && ((ch + 1 < nchunks) || !last);
+      const bool more = active && (rem > 0 || !last);
       f32x4 wn[4];
       if (more) {
-        const unsigned nxt = (ch + 1 < nchunks) ? wcur + 4 * wstep_b : wbase_b + static_cast<unsigned>(rd + 1) * round_step_b;
+        const unsigned nxt = rem > 0 ? wcur + nfr * wstep_b : wbase_b + static_cast<unsigned>(rd + 1) * round_step_b;
 #pragma unroll
         for (int u = 0; u < 4; ++u) wn[u] = ldb(wb, nxt + u * wstep_b + lane16);
       }
-      if (ch == nchunks - 1 && (!last || hand)) {
+      if (rem == 0 && (!last || hand)) {
         ImgSrc is;
         is.src0 = last ? n.w[0] : o.w[0]; is.dtap = last ? n.w[1] : o.w[1];
         is.ld = static_cast<unsigned>(last ? cv_src_ld_b(n) : cv_src_ld_b(o));
@@ -499,17 +544,14 @@ __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, b
         MK_T(4);
       }
       if (active) {
-        const int koff = stride2 ? ((k.kf >> 1) * pitch_b + (k.kf & 1) * cc_b) : k.kf * pitch_b;
-        const int boff = k.phl * phase_b + koff + 32 * k.gg;
-        chunk_mfma(acc[0], acc[1], tw == 2, wa, lds_in, lane_b0 + boff, lane_b1 + boff);
+        if (s16) chunk_mfma16(acc16, wa, lds_in, lane_b0 + boffA, lane_b0 + boffB);
+        else chunk_mfma32(acc[0], acc[1], tw == 2, wa, lds_in, lane_b0 + boffA, lane_b0 + boffB, lane_b1 + boffA, lane_b1 + boffB);
       }
       if (more) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) wa[u] = wn[u];
       }
-      wcur += 4 * wstep_b;
-      k.gg += 4;
-      if (k.gg == gpc) { k.gg = 0; if (++k.kf == kf_n) { k.kf = 0; ++k.phl; } }
+      wcur += nfr * wstep_b;
     }
     if (!last) {
       lds_barrier();             // every wave is done reading this phase's LDS rows
@@ -518,6 +560,10 @@ __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, b
     }
   }
   MK_T(5);
+  // Both descriptors again, by fresh scalar loads: the ~40 words the code below needs are then not live
+  // (= not spilled to VGPR lanes and read back one v_readlane at a time) across the MFMA loop above.
+  o = reload_op(plan, op_i);
+  n = reload_op(plan, nxt_i);
   // next conv layer's first weight chunk + epilogue parameters (single load site)
   {
     OpWords s;     // (field-wise selects of the words prefetch_conv reads: a layer with no conv successor re-reads its own)
@@ -530,7 +576,10 @@ __device__ __forceinline__ void conv_layer(const OpWords& o, const OpWords& n, b
   MK_T(6);
 
   // ---- partial tiles -> LDS exchange buffer [ks][pos][32*NT (+4)]
-  if (active) {
+  if (active && s16) {
+    // 16x16 tile: lane holds channels 16*ntile + 4*h .. +3 of position pl
+    lds4(lds_out, ks * cv_slot_b(o) + pl * cv_opitch_b(o) + ntile * 64 + 16 * h) = acc16;
+  } else if (active) {
     const int opitch_b = cv_opitch_b(o);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -897,7 +946,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
       if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 15] = clock64();
       if (dbg) __syncthreads();      // (the stamp's store must not sit in vmcnt during the op)
       if (op == DEV_OP_CONV) {
-        conv_layer<PROF>(cur, nxt, nconv, sb, wb, lds_in, lds_out, tid, cy, sub, dbg);
+        conv_layer<PROF>(cur, nxt, plan, i, i + 1 < n_ops ? i + 1 : i, nconv, sb, wb, lds_in, lds_out, tid, cy, sub, dbg);
       } else {
         if (op == DEV_OP_LSTM) {
           LstmParams p;

@@ -34,6 +34,7 @@ struct ConvParams {
   const float* src0;   // time tap 0 (previous frame) -- or the only input when TT == 1
   const float* src1;   // time tap 1 (current frame)
   const float* wpk;    // weights in MFMA fragment order (pack_conv_weights)
+  const float* wpk16;  // the same weights in 16x16x4 fragment order (pack_conv_weights16; persistent kernel, F_out <= 16)
   const float* bias;   // [32*NT]  packed channel order
   const float* gamma;  // [32*G]   LayerNorm scale (EPI_LN only)
   const float* beta;   // [32*G]
@@ -157,6 +158,7 @@ struct ConvPlan {
   // hand-off between consecutive layers
   int staged_by_prev;    // the previous layer's epilogue already completed this layer's LDS image
   int pf_phase0_ready;   // the previous layer already issued this layer's phase-0 loads into the prefetch registers
+  int s16;               // F_out <= 16: 16x16x4 MFMA tiles (16 positions x 16 channels), nt = channel tiles of 16
   int hand_next;         // complete the next layer's LDS image in this layer's epilogue
   int fwd_sel;           // 1 / 2: rows written to dst0 / dst1 are also forwarded into the next layer's image
   int fwd_coff4;         // float4 offset of the forwarded block inside the next layer's input row
@@ -218,5 +220,12 @@ hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s);
 std::vector<float> pack_conv_weights(const HostTensor& w, const std::vector<int>& perm,
                                      const std::vector<std::pair<int, int>>& taps_per_t,
                                      int tt, int cin, int nt);
+// Same, for v_mfma_f32_16x16x4_f32 tiles: fragment (16-channel K group g, 16-row channel tile rt), lane l
+// holds W[16 rt + (l & 15)][16 g + 4 (l >> 4) + j], j = 0..3.  Order [t][chunk][kf][g16][rt][lane][4].
+std::vector<float> pack_conv_weights16(const HostTensor& w, const std::vector<int>& perm,
+                                       const std::vector<std::pair<int, int>>& taps_per_t,
+                                       int tt, int cin, int nt32);
+// Re-plans a layer with F_out <= 16 for 16x16x4 tiles (no-op otherwise).
+void apply_s16_plan(ConvPlan* c, const ConvParams& p);
 
 }  // namespace nutls

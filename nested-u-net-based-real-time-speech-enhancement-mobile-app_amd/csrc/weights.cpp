@@ -98,6 +98,33 @@ std::vector<float> pack_conv_weights(const HostTensor& w, const std::vector<int>
   return out;
 }
 
+std::vector<float> pack_conv_weights16(const HostTensor& w, const std::vector<int>& perm,
+                                       const std::vector<std::pair<int, int>>& taps_per_t,
+                                       int tt, int cin, int nt32) {
+  const int th = w.dims[1], kw = w.dims[2], wc = w.dims[3];
+  const int cc = cin < 64 ? cin : 64, nch = cin / cc, kf = static_cast<int>(taps_per_t.size());
+  const int nrt = 2 * nt32;
+  std::vector<float> out(static_cast<size_t>(tt) * nch * kf * (cc / 16) * nrt * 64 * 4);
+  size_t o = 0;
+  for (int t = 0; t < tt; ++t)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int k = 0; k < kf; ++k)
+        for (int g = 0; g < cc / 16; ++g)
+          for (int rt = 0; rt < nrt; ++rt)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 4; ++j) {
+                const int np = rt * 16 + (lane & 15);
+                const int c = ch * cc + g * 16 + 4 * (lane >> 4) + j;
+                const int src_t = (tt == 1) ? taps_per_t[k].first : t;
+                const int src_k = taps_per_t[k].second;
+                float v = 0.f;
+                if (src_k >= 0 && np < static_cast<int>(perm.size()) && perm[np] >= 0)
+                  v = w.data[((static_cast<size_t>(perm[np]) * th + src_t) * kw + src_k) * wc + c];
+                out[o++] = v;
+              }
+  return out;
+}
+
 static int ilog2_exact(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -148,6 +175,31 @@ ConvPlan make_conv_plan(ConvKind k, const ConvParams& p) {
   return c;
 }
 
+void apply_s16_plan(ConvPlan* cp, const ConvParams& p) {
+  ConvPlan& c = *cp;
+  if (p.F_out > 16 || !c.merged || c.rounds != 1 || !p.wpk16) return;
+  const int nt16 = 2 * c.nt;
+  if (nt16 > MK_NWAVES) return;
+  const int gpc16 = c.cc / 16;
+  const int RG = c.nph * c.kf * gpc16;
+  int best = 0;
+  for (int ks = 1; ks <= MK_NWAVES / nt16; ++ks)
+    if (RG % ks == 0 && (RG / ks) % 4 == 0) best = ks;      // whole 4-fragment chunks per slice (two pairs; a pair never straddles a tap segment)
+  if (!best) return;
+  c.s16 = 1;
+  c.nt = nt16;
+  c.nt_shift = ilog2_exact(nt16);
+  c.gpc = gpc16;
+  c.RG = RG;
+  c.PT = 1;
+  c.tiles = nt16;
+  c.tw = 1;
+  c.tasks = nt16;
+  c.tasks_shift = c.nt_shift;
+  c.KS = best;
+  c.gpk = RG / best;
+}
+
 static uint32_t off_of(const float* p, const float* base) {
   return p ? static_cast<uint32_t>(p - base) : MK_NULL_OFF;
 }
@@ -173,7 +225,7 @@ CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) 
       o.w[0] = ab(p.src0);
       o.w[1] = p.src1 ? ab(p.src1) - ab(p.src0) : 0u;                   // second time tap relative to the first (mod 2^32)
       o.w[2] = ab(p.dst0); o.w[3] = p.dst1 ? ab(p.dst1) : 0u;
-      o.w[4] = wbo(p.wpk); o.w[5] = wbo(p.bias);
+      o.w[4] = wbo(c.s16 ? p.wpk16 : p.wpk); o.w[5] = wbo(p.bias);
       o.w[6] = c.epi_ln ? wbo(p.gamma) : o.w[5];                        // no LayerNorm: the loads still happen, on the bias
       o.w[7] = c.epi_ln ? wbo(p.beta) : o.w[5];
       o.w[8] = fbits(p.alpha);
@@ -194,6 +246,7 @@ CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) 
       o.w[18] = pack4(c.RG, c.KS, c.gpk, c.gpc);
       o.w[19] = pack4(c.tasks, c.tasks_shift, c.tw, c.fwd_coff4);
       o.w[20] = pack2(c.opitch * 4, p.F_out * c.R);
+      o.w[21] = static_cast<uint32_t>(c.s16 & 1);
       break;
     }
     case DEV_OP_LSTM: {
