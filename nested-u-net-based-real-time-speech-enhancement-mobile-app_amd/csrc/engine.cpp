@@ -806,6 +806,15 @@ static int upload_device_plans(Engine* e) {
       }
     }
     plan_handoffs(e->plan[par], &dv);
+    for (size_t i = 0; i + 1 < dv.size(); ++i) {
+      if (dv[i].op != DEV_OP_CONV || !dv[i].cp.hand_next) continue;
+      ConvPlan& c = dv[i].cp;
+      const ConvPlan& nc = dv[i + 1].cp;
+      const ConvParams& np = dv[i + 1].conv;
+      c.hx_src0 = np.src0; c.hx_src1 = np.src1; c.hx_ld = np.src_ld;
+      c.hx_cc4_shift = nc.cc4_shift; c.hx_n4p_shift = nc.n4p_shift; c.hx_nch_shift = nc.nch_shift;
+      c.hx_nhand = nc.merged ? nc.nph : 1;
+    }
     if (par == 0 && getenv("NUTLS_DUMP_PLAN")) {
       for (size_t i = 0; i < dv.size(); ++i)
         if (dv[i].op == DEV_OP_CONV) {

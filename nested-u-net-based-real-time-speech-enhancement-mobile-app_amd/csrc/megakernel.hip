@@ -123,13 +123,17 @@ CV(kf, b0(o.w[12]))        CV(padl, b1(o.w[12]))       CV(lpg, b2(o.w[12]))     
 CV(cc4_shift, b0(o.w[13])) CV(n4p_shift, b1(o.w[13]))  CV(nch_shift, b2(o.w[13]))  CV(nt_shift, b3(o.w[13]))
 CV(pitch_b, h0(o.w[14]))   CV(rows, h1(o.w[14]))
 CV(vrows, h0(o.w[15]))     CV(nph, b2(o.w[15]))        CV(rounds, b3(o.w[15]))
-CV(phase_b, o.w[16])       CV(slot_b, o.w[17])
+CV(phase_b, o.w[16])
 CV(RG, b0(o.w[18]))        CV(KS, b1(o.w[18]))         CV(gpk, b2(o.w[18]))        CV(gpc, b3(o.w[18]))
 CV(tasks, b0(o.w[19]))     CV(tasks_shift, b1(o.w[19])) CV(tw, b2(o.w[19]))        CV(fwd_coff4, b3(o.w[19]))
 CV(opitch_b, h0(o.w[20]))  CV(units, h1(o.w[20]))
+CV(hx_nhand, (o.w[21] >> 1) & 7)   CV(hx_cc4_shift, (o.w[21] >> 4) & 15)   CV(hx_n4p_shift, (o.w[21] >> 8) & 15)
+CV(hx_nch_shift, (o.w[21] >> 12) & 15)   CV(hx_ld_b, o.w[21] >> 16)
 CV(s16, o.w[21] & 1)       // F_out <= 16: 16x16x4 MFMA tiles, fragments are 16-channel K groups, nt counts 16-channel tiles
 #undef CV
 __device__ __forceinline__ int cv_cc_b(const OpWords& o) { return 16 << cv_cc4_shift(o); }      // bytes of one channel chunk
+// bytes of one K-slice slot of the exchange buffer: PT * 32 positions (PT = 1 for 16-position tiles)
+__device__ __forceinline__ int cv_slot_b(const OpWords& o) { return ((cv_F_out(o) + 31) >> 5) * 32 * cv_opitch_b(o); }
 
 __device__ __forceinline__ void decode_lstm(const OpWords& o, const StepArgs& a, LstmParams& p) {
   p.x = aptr(a.arena, o.w[0]); p.x_ld = h0(o.w[1]); p.x_cols = h1(o.w[1]); p.x_rows = 0;
@@ -423,12 +427,12 @@ __device__ __forceinline__ void conv_epilogue(const OpWords& o, gcb_t sb, float*
 //   cy  in : this wave's first weight chunk + this lane's epilogue parameters (fetched by the previous op)
 //       out: the same for the next conv layer (a layer with no conv successor re-reads its own)
 template <bool PROF>
-__device__ __forceinline__ void conv_layer(const OpWords& o_in, const OpWords& n_in, cplan_t plan, int op_i, int nxt_i, bool nconv, gcb_t sb, gcb_t wb,
+__device__ __forceinline__ void conv_layer(const OpWords& o_in, OpWords& n, cplan_t plan, int op_i, int nxt_i, gcb_t sb, gcb_t wb,
                                            float* lds_in,
                                            float* lds_out, int tid, Carry& cy, unsigned long long* sub, unsigned long long* dbg) {
   unsigned long long* dbg_lds = reinterpret_cast<unsigned long long*>(lds_out + MK_LDS_OUT);
   MK_T(0);
-  OpWords o = o_in, n = n_in;      // (re-read after the MFMA loop, see below)
+  OpWords o = o_in;                // (re-read after the MFMA loop, see below; the next op's words arrive there too)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SGPR
   const bool s16 = cv_s16(o);
@@ -469,9 +473,9 @@ __device__ __forceinline__ void conv_layer(const OpWords& o_in, const OpWords& n
   MK_T(2);
 
   // ---- what this layer owes the next one
-  const bool hand = nconv && cv_hand_next(o);
+  const bool hand = cv_hand_next(o);       // (planned only in front of a conv layer)
   const bool do_fwd = hand && cv_fwd_sel(o);
-  const int n_hand = hand ? (cv_merged(n) ? cv_nph(n) : 1) : 0;
+  const int n_hand = cv_hx_nhand(o);
   MK_STAMP(6);
   MK_T(3);
 
@@ -535,10 +539,11 @@ __device__ __forceinline__ void conv_layer(const OpWords& o_in, const OpWords& n
       }
       if (rem == 0 && (!last || hand)) {
         ImgSrc is;
-        is.src0 = last ? n.w[0] : o.w[0]; is.dtap = last ? n.w[1] : o.w[1];
-        is.ld = static_cast<unsigned>(last ? cv_src_ld_b(n) : cv_src_ld_b(o));
-        const unsigned sh = last ? n.w[13] : o.w[13];
-        is.cc4_shift = b0(sh); is.n4p_shift = b1(sh); is.nch_shift = b2(sh);
+        is.src0 = last ? o.w[22] : o.w[0]; is.dtap = last ? o.w[17] : o.w[1];
+        is.ld = static_cast<unsigned>(last ? cv_hx_ld_b(o) : cv_src_ld_b(o));
+        is.cc4_shift = last ? cv_hx_cc4_shift(o) : cv_cc4_shift(o);
+        is.n4p_shift = last ? cv_hx_n4p_shift(o) : cv_n4p_shift(o);
+        is.nch_shift = last ? cv_hx_nch_shift(o) : cv_nch_shift(o);
         image_load(is, sb, last ? 0 : rd + 1, last ? n_hand : 1, tid, pfx);
         MK_STAMP(7);
         MK_T(4);
@@ -564,6 +569,7 @@ __device__ __forceinline__ void conv_layer(const OpWords& o_in, const OpWords& n
   // (= not spilled to VGPR lanes and read back one v_readlane at a time) across the MFMA loop above.
   o = reload_op(plan, op_i);
   n = reload_op(plan, nxt_i);
+  const bool nconv = nxt_i != op_i && static_cast<int>(n.w[23]) == DEV_OP_CONV;
   // next conv layer's first weight chunk + epilogue parameters (single load site)
   {
     OpWords s;     // (field-wise selects of the words prefetch_conv reads: a layer with no conv successor re-reads its own)
@@ -936,18 +942,20 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
       const int tid = fresh_tid();
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
       if (prof && blockIdx.x == 0 && tid == 0) prof[i] = wall_clock64();
-      const OpWords nxt = load_op(plan, i + 1 < n_ops ? i + 1 : i);
-      const bool nconv = (i + 1 < n_ops) && static_cast<int>(nxt.w[23]) == DEV_OP_CONV;
+      const int nxt_i = i + 1 < n_ops ? i + 1 : i;
       const int op = static_cast<int>(cur.w[23]);
-      const bool nc_hand = nconv && b0(cur.w[22]) != 0;      // non-conv op -> conv hand-off
-      const int nc_coff = b1(cur.w[22]);
       unsigned long long* sub = (prof && blockIdx.x == 0) ? prof + (n_ops + 1) + 8 * i : nullptr;
       unsigned long long* dbg = (sub && i == a.dbg_op) ? prof + n_ops * 9 + 3 : nullptr;
       if (dbg && (tid & 63) == 0) dbg[(tid >> 6) * 16 + 15] = clock64();
       if (dbg) __syncthreads();      // (the stamp's store must not sit in vmcnt during the op)
+      OpWords nxt;                   // the next op's words: a conv layer reads them late (after its MFMA loop)
       if (op == DEV_OP_CONV) {
-        conv_layer<PROF>(cur, nxt, plan, i, i + 1 < n_ops ? i + 1 : i, nconv, sb, wb, lds_in, lds_out, tid, cy, sub, dbg);
+        conv_layer<PROF>(cur, nxt, plan, i, nxt_i, sb, wb, lds_in, lds_out, tid, cy, sub, dbg);
       } else {
+        nxt = load_op(plan, nxt_i);
+        const bool nconv = (i + 1 < n_ops) && static_cast<int>(nxt.w[23]) == DEV_OP_CONV;
+        const bool nc_hand = nconv && b0(cur.w[22]) != 0;      // non-conv op -> conv hand-off
+        const int nc_coff = b1(cur.w[22]);
         if (op == DEV_OP_LSTM) {
           LstmParams p;
           decode_lstm(cur, a, p);

@@ -160,6 +160,9 @@ struct ConvPlan {
   int pf_phase0_ready;   // the previous layer already issued this layer's phase-0 loads into the prefetch registers
   int s16;               // F_out <= 16: 16x16x4 MFMA tiles (16 positions x 16 channels), nt = channel tiles of 16
   int hand_next;         // complete the next layer's LDS image in this layer's epilogue
+  // what the hand-off loads of the NEXT layer's image need (copied from its plan, so that this layer's
+  // descriptor alone drives them): source offsets (floats from the arena), row pitch, item bit fields, phases
+  const float* hx_src0; const float* hx_src1; int hx_ld, hx_cc4_shift, hx_n4p_shift, hx_nch_shift, hx_nhand;
   int fwd_sel;           // 1 / 2: rows written to dst0 / dst1 are also forwarded into the next layer's image
   int fwd_coff4;         // float4 offset of the forwarded block inside the next layer's input row
   int fwd_rmul, fwd_radd; // rows this layer writes: row % fwd_rmul == fwd_radd (1, 0 = every row)

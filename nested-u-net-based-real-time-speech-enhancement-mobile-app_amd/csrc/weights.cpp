@@ -214,7 +214,7 @@ static uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) {
   CompactOp o{};
   o.w[23] = static_cast<uint32_t>(d.op);
-  o.w[22] = pack4(d.nc_hand, d.nc_fwd_coff, 0, 0);     // non-conv ops: hand-off to the following conv layer
+  o.w[22] = pack4(d.nc_hand, d.nc_fwd_coff, 0, 0);     // non-conv ops: hand-off to the following conv layer (conv ops: see below)
   switch (d.op) {
     case DEV_OP_CONV: {
       // conv offsets are BYTES from the stream slice / the weight arena (decoders: cv_* in megakernel.hip)
@@ -242,11 +242,15 @@ CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase) 
       o.w[14] = pack2(c.pitch * 4, c.rows);
       o.w[15] = pack2(c.vrows, c.nph | (c.rounds << 8));
       o.w[16] = static_cast<uint32_t>(c.phase_floats) * 4u;
-      o.w[17] = static_cast<uint32_t>(c.slot_floats) * 4u;
+      // [17], [21], [22]: the hand-off loads of the next layer's image (0 without hand-off)
+      o.w[17] = (c.hand_next && c.hx_src1) ? ab(c.hx_src1) - ab(c.hx_src0) : 0u;
+      o.w[22] = c.hand_next ? ab(c.hx_src0) : 0u;
       o.w[18] = pack4(c.RG, c.KS, c.gpk, c.gpc);
       o.w[19] = pack4(c.tasks, c.tasks_shift, c.tw, c.fwd_coff4);
       o.w[20] = pack2(c.opitch * 4, p.F_out * c.R);
-      o.w[21] = static_cast<uint32_t>(c.s16 & 1);
+      o.w[21] = static_cast<uint32_t>(c.s16 & 1) | (static_cast<uint32_t>(c.hx_nhand & 7) << 1) | (static_cast<uint32_t>(c.hx_cc4_shift & 15) << 4) |
+                (static_cast<uint32_t>(c.hx_n4p_shift & 15) << 8) | (static_cast<uint32_t>(c.hx_nch_shift & 15) << 12) |
+                (static_cast<uint32_t>(c.hx_ld * 4) << 16);
       break;
     }
     case DEV_OP_LSTM: {
