@@ -84,6 +84,8 @@ def main():
                     help="baseline = dilated-dense bottleneck with synthetic weights, seed 4321 (BASELINE configs[2])")
     ap.add_argument("--host-io", action="store_true",
                     help="streaming serving (BASELINE configs[4]): one step per host call, host buffers in/out (H2D + D2H timed)")
+    ap.add_argument("--frontend", action="store_true",
+                    help="a step = STFT analysis + model step + inverse STFT/overlap-add of one 256-sample hop per stream, all on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default="", help="write the per-launch HIP-event timeline here")
     args = ap.parse_args()
@@ -123,7 +125,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pcm = pcm_out = None
+    if args.frontend:        # PCM hops resident in HBM: white noise at speech level
+        pcm = (0.05 * torch.randn(8, B, 256, generator=torch.Generator().manual_seed(1234 + rank))).cuda()
+        pcm_out = torch.empty(B, 256, device="cuda")
+
     def one_step(s):
+        if args.frontend:
+            return eng.enhance_hop(pcm[s % 8], "edge", pcm_out)
         if args.host_io:
             return eng.step(pool_host[s % 8])            # numpy in / numpy out: H2D + step + D2H, synchronous
         return eng.step(pool[s % 8], out)
@@ -140,7 +149,7 @@ def main():
     frames = B * args.steps
     total_frames, max_elapsed = reduce_throughput(frames, elapsed, dist if world > 1 else None,
                                                   torch.device("cuda", local_rank))
-    assert args.host_io or bool(torch.isfinite(out).all())
+    assert args.host_io or bool(torch.isfinite(pcm_out if args.frontend else out).all())
 
     if rank == 0:
         import re
@@ -224,7 +233,7 @@ def main():
             "config": {"workload": ("NUNet-TLS-LSTM (proposed) frame step, batch=%d streams per GPU, 256-bin frames (BASELINE configs[1])" % B)
                        if args.variant == "lstm" else
                        ("NUNet-TLS dilated-dense baseline frame step, synthetic weights seed 4321, batch=%d streams per GPU (BASELINE configs[2])" % B),
-                       "variant": args.variant, "host_io": bool(args.host_io),
+                       "variant": args.variant, "host_io": bool(args.host_io), "stft_istft_on_gpu": bool(args.frontend),
                        "streams_per_gpu": B, "total_streams": B * world, "parallelism": "stream-sharded x%d" % world,
                        "mode": args.mode, "layers_per_step": len(plan)},
             "rtf_per_stream": round(1e3 * max_elapsed / args.steps / 16.0, 5),

@@ -68,6 +68,26 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
 /* Same with HOST buffers: H2D copy, step, D2H copy, synchronises before returning. */
 int nutls_step_host(nutls_handle* h, const float* mag_in, float* mag_out);
 
+/* ---- STFT front end / inverse-STFT back end on the device -----------------
+ * Replaces the numpy part of the reference's real_time_speech_enhancer loop
+ * (dnn_model/interpreter_proposed.py:203-213 analysis, :352-365 synthesis): frame 512, hop 256,
+ * analysis window = periodic Hann with end taps 1e-7 (:20-22), inverse window (:24-26), overlap-add.
+ * The library keeps, per stream, the previous hop and the overlap tail (zeroed by nutls_reset).
+ *
+ * nutls_enhance_hop: pcm_in / pcm_out are DEVICE pointers to [B, 256] float32 (row = stream, one hop of
+ * 256 samples): analysis -> model step -> synthesis, asynchronous on `stream`.  Like the reference loop the
+ * output lags the input by one hop (the first returned hop is the leading half-window).
+ * dc_mode: how bin 0 is re-created behind the 256-bin model. */
+#define NUTLS_DC_EDGE 0   /* PC loop: np.pad(..., mode='edge'), interpreter_proposed.py:352-353 */
+#define NUTLS_DC_ZERO 1   /* phone: zero, mobile_app/.../RTSE_NUTLS_LSTM.java:677 */
+int nutls_enhance_hop(nutls_handle* h, const float* pcm_in, float* pcm_out, int dc_mode, void* stream);
+/* Same with HOST buffers (H2D, pipeline, D2H, synchronises). */
+int nutls_enhance_hop_host(nutls_handle* h, const float* pcm_in, float* pcm_out, int dc_mode);
+/* The two halves on their own (testing, custom models): analysis of one hop into the library's mag_in buffer
+ * (+ phase kept inside), synthesis of one hop from the library's mag_out buffer.  Device pointers. */
+int nutls_stft_hop(nutls_handle* h, const float* pcm_in, void* stream);
+int nutls_istft_hop(nutls_handle* h, float* pcm_out, int dc_mode, void* stream);
+
 /* Library-owned device staging buffers [B,256]; stepping on them avoids the D2D copies and lets
  * the captured hipGraph run with no per-call parameter update. */
 int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out);

@@ -5,6 +5,7 @@
 // optional hipGraph capture of that plan.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -116,6 +117,9 @@ struct Engine {
   int central_h = -1, central_c = -1;
   std::vector<Launch> plan[2];
   float *io_in = nullptr, *io_out = nullptr;
+  // STFT front / back end (allocated on first use): previous hop, overlap tail, phasors, windows, twiddles, staging
+  float *fe_tail = nullptr, *fe_ola = nullptr, *fe_ph = nullptr, *fe_win = nullptr, *fe_inv = nullptr, *fe_tw = nullptr;
+  float *fe_pcm_in = nullptr, *fe_pcm_out = nullptr;
   float *t_inlayer = nullptr, *t_y = nullptr, *t_d = nullptr, *t_up = nullptr;
   float* upcat[6] = {nullptr};
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
@@ -888,6 +892,48 @@ struct nutls_handle {
   Engine eng;
 };
 
+// ---- STFT front / back end state ---------------------------------------------------------------
+static int frontend_init(Engine* e) {
+  if (e->fe_tail) return NUTLS_OK;
+  const size_t hop = static_cast<size_t>(e->B) * NUTLS_FRAME_STEP;
+  auto dalloc = [&](float** p, size_t n) -> int {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, n * sizeof(float)));
+    HIP_TRY(hipMemset(q, 0, n * sizeof(float)));
+    e->allocs.push_back(q);
+    *p = static_cast<float*>(q);
+    return NUTLS_OK;
+  };
+  int rc;
+  float* tail = nullptr;
+  if ((rc = dalloc(&tail, hop)) || (rc = dalloc(&e->fe_ola, hop)) || (rc = dalloc(&e->fe_ph, static_cast<size_t>(e->B) * (NUTLS_FRAME_STEP + 1) * 2)) ||
+      (rc = dalloc(&e->fe_win, NUTLS_FRAME_LEN)) || (rc = dalloc(&e->fe_inv, NUTLS_FRAME_LEN)) || (rc = dalloc(&e->fe_tw, NUTLS_FRAME_LEN)) ||
+      (rc = dalloc(&e->fe_pcm_in, hop)) || (rc = dalloc(&e->fe_pcm_out, hop)))
+    return rc;
+  // windows in float32 like tf.signal.hann_window (interpreter_proposed.py:20-26); twiddles from double
+  std::vector<float> hann(NUTLS_FRAME_LEN), win(NUTLS_FRAME_LEN), inv(NUTLS_FRAME_LEN), tw(NUTLS_FRAME_LEN);
+  for (int k = 0; k < NUTLS_FRAME_LEN; ++k) {
+    const float arg = 6.28318530717958647692f * static_cast<float>(k) / static_cast<float>(NUTLS_FRAME_LEN);
+    hann[k] = 0.5f - 0.5f * std::cos(arg);
+  }
+  win = hann;
+  win[0] = 1e-7f; win[NUTLS_FRAME_LEN - 1] = 1e-7f;
+  for (int k = 0; k < NUTLS_FRAME_LEN; ++k) {
+    const int k2 = (k + NUTLS_FRAME_STEP) % NUTLS_FRAME_LEN;
+    inv[k] = hann[k] / (hann[k] * hann[k] + hann[k2] * hann[k2]);
+  }
+  for (int k = 0; k < NUTLS_FRAME_LEN / 2; ++k) {
+    const double a = -2.0 * 3.14159265358979323846 * k / NUTLS_FRAME_LEN;
+    tw[2 * k] = static_cast<float>(std::cos(a));
+    tw[2 * k + 1] = static_cast<float>(std::sin(a));
+  }
+  HIP_TRY(hipMemcpy(e->fe_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->fe_inv, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->fe_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+  e->fe_tail = tail;
+  return NUTLS_OK;
+}
+
 extern "C" {
 
 const char* nutls_last_error(void) { return g_last_error.c_str(); }
@@ -1020,6 +1066,49 @@ int nutls_step_host(nutls_handle* h, const float* mag_in, float* mag_out) {
   return NUTLS_OK;
 }
 
+int nutls_stft_hop(nutls_handle* h, const float* pcm_in, void* stream) {
+  if (!h || !pcm_in) return fail(NUTLS_ERR_ARG, "nutls_stft_hop: null pointer");
+  Engine* e = &h->eng;
+  int rc = frontend_init(e);
+  if (rc) return rc;
+  HIP_TRY(launch_stft_hop(pcm_in, e->fe_tail, e->fe_win, e->fe_tw, e->io_in, e->fe_ph, e->B, static_cast<hipStream_t>(stream)));
+  return NUTLS_OK;
+}
+
+int nutls_istft_hop(nutls_handle* h, float* pcm_out, int dc_mode, void* stream) {
+  if (!h || !pcm_out) return fail(NUTLS_ERR_ARG, "nutls_istft_hop: null pointer");
+  if (dc_mode != NUTLS_DC_EDGE && dc_mode != NUTLS_DC_ZERO) return fail(NUTLS_ERR_ARG, "dc_mode must be NUTLS_DC_EDGE or NUTLS_DC_ZERO");
+  Engine* e = &h->eng;
+  int rc = frontend_init(e);
+  if (rc) return rc;
+  HIP_TRY(launch_istft_hop(e->io_out, e->fe_ph, e->fe_inv, e->fe_tw, e->fe_ola, pcm_out, dc_mode == NUTLS_DC_EDGE ? 1 : 0, e->B,
+                           static_cast<hipStream_t>(stream)));
+  return NUTLS_OK;
+}
+
+int nutls_enhance_hop(nutls_handle* h, const float* pcm_in, float* pcm_out, int dc_mode, void* stream) {
+  if (!h || !pcm_in || !pcm_out) return fail(NUTLS_ERR_ARG, "nutls_enhance_hop: null pointer");
+  int rc = nutls_stft_hop(h, pcm_in, stream);
+  if (rc) return rc;
+  Engine* e = &h->eng;
+  if ((rc = nutls_step(h, e->io_in, e->io_out, stream))) return rc;
+  return nutls_istft_hop(h, pcm_out, dc_mode, stream);
+}
+
+int nutls_enhance_hop_host(nutls_handle* h, const float* pcm_in, float* pcm_out, int dc_mode) {
+  if (!h || !pcm_in || !pcm_out) return fail(NUTLS_ERR_ARG, "nutls_enhance_hop_host: null pointer");
+  Engine* e = &h->eng;
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = frontend_init(e);
+  if (rc) return rc;
+  const size_t bytes = static_cast<size_t>(e->B) * NUTLS_FRAME_STEP * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(e->fe_pcm_in, pcm_in, bytes, hipMemcpyHostToDevice, e->stream));
+  if ((rc = nutls_enhance_hop(h, e->fe_pcm_in, e->fe_pcm_out, dc_mode, e->stream))) return rc;
+  HIP_TRY(hipMemcpyAsync(pcm_out, e->fe_pcm_out, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return NUTLS_OK;
+}
+
 int nutls_state_count(nutls_handle* h) { return h ? static_cast<int>(h->eng.states.size()) : fail(NUTLS_ERR_ARG, "null handle"); }
 
 int nutls_state_info(nutls_handle* h, int index, const char** name, int* dim0, int* dim1) {
@@ -1099,6 +1188,16 @@ int nutls_reset(nutls_handle* h, int stream_idx) {
   // a stream's whole slice of the arena (state of both parities + scratch) is contiguous
   if (stream_idx < 0) HIP_TRY(hipMemset(e->arena, 0, e->sstride * sizeof(float) * e->B));
   else HIP_TRY(hipMemset(e->arena + e->sstride * stream_idx, 0, e->sstride * sizeof(float)));
+  if (e->fe_tail) {   // STFT front / back end: previous hop and overlap tail
+    const size_t hop = NUTLS_FRAME_STEP * sizeof(float);
+    if (stream_idx < 0) {
+      HIP_TRY(hipMemset(e->fe_tail, 0, hop * e->B));
+      HIP_TRY(hipMemset(e->fe_ola, 0, hop * e->B));
+    } else {
+      HIP_TRY(hipMemset(e->fe_tail + static_cast<size_t>(NUTLS_FRAME_STEP) * stream_idx, 0, hop));
+      HIP_TRY(hipMemset(e->fe_ola + static_cast<size_t>(NUTLS_FRAME_STEP) * stream_idx, 0, hop));
+    }
+  }
   HIP_TRY(hipDeviceSynchronize());
   return NUTLS_OK;
 }
@@ -1106,6 +1205,22 @@ int nutls_reset(nutls_handle* h, int stream_idx) {
 int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats) {
   if (!h || !name || !host_buf) return fail(NUTLS_ERR_ARG, "nutls_debug_get: null pointer");
   Engine* e = &h->eng;
+  {   // the I/O staging buffers and the STFT phasors are plain [B, n] arrays
+    const std::string nm(name);
+    const float* src = nullptr;
+    size_t per = 0;
+    if (nm == "mag_in") { src = e->io_in; per = NUTLS_BINS; }
+    else if (nm == "mag_out") { src = e->io_out; per = NUTLS_BINS; }
+    else if (nm == "phasor") { src = e->fe_ph; per = 2 * (NUTLS_FRAME_STEP + 1); }
+    if (per) {
+      if (!src) return fail(NUTLS_ERR_ARG, "debug tensor not allocated yet: " + nm);
+      if (n_floats != per * e->B) return fail(NUTLS_ERR_ARG, "size mismatch for debug tensor " + nm);
+      HIP_TRY(hipSetDevice(e->device));
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemcpy(host_buf, src, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+      return NUTLS_OK;
+    }
+  }
   auto it = e->debug.find(name);
   if (it == e->debug.end()) return fail(NUTLS_ERR_ARG, std::string("unknown debug tensor: ") + name);
   if (n_floats != it->second.second * e->B) return fail(NUTLS_ERR_ARG, std::string("size mismatch for debug tensor ") + name);

@@ -142,6 +142,12 @@ hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
 // (megakernel.hip), which runs the whole frame step of one stream inside one workgroup.
 enum DevOp : int { DEV_OP_CONV = 0, DEV_OP_LSTM, DEV_OP_CTFA, DEV_OP_INLAYER, DEV_OP_OUTCONV, DEV_OP_DDB };
 constexpr int NUTLS_DEV_BINS = 256;
+constexpr int NUTLS_FRAME_LEN = 512;    // interpreter_proposed.py:17
+constexpr int NUTLS_FRAME_STEP = 256;   // interpreter_proposed.py:18
+// STFT front end / inverse-STFT + overlap-add back end of the streaming loop (stft.hip)
+hipError_t launch_stft_hop(const float* pcm, float* tail, const float* win, const float* tw, float* mag, float* ph, int B, hipStream_t s);
+hipError_t launch_istft_hop(const float* est, const float* ph, const float* inv_win, const float* tw, float* ola, float* pcm_out,
+                            int dc_edge, int B, hipStream_t s);
 // Host-precomputed execution plan of one conv-like layer inside the persistent kernel (all the
 // integer bookkeeping the kernel would otherwise redo per layer: LDS geometry, task split, hand-off).
 struct ConvPlan {

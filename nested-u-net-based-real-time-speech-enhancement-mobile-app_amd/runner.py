@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "nutls_launches_per_step", "nutls_launch_info", "nutls_profile_step",
     "nutls_profile_persistent", "nutls_last_error",
     "nutls_version",
+    "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
 )
 
 
@@ -70,6 +71,10 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                                       c.POINTER(c.c_double), c.POINTER(c.c_double)]
     lib.nutls_profile_step.argtypes = [c.c_void_p, fp, c.c_int]
     lib.nutls_profile_persistent.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
+    lib.nutls_enhance_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
+    lib.nutls_enhance_hop_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
+    lib.nutls_stft_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.nutls_istft_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:
@@ -167,6 +172,48 @@ class NutlsEngine:
             out = torch.empty_like(mag)
         stream = torch.cuda.current_stream(mag.device).cuda_stream
         _check(self._lib, self._lib.nutls_step(self._h, mag.data_ptr(), out.data_ptr(), stream))
+        return out
+
+    # -- STFT front end / inverse-STFT back end on the device ----------------
+    _DC = {"edge": 0, "zero": 1}
+
+    def enhance_hop(self, pcm, dc_mode: str = "edge", out=None):
+        """One hop (256 samples) of every stream: analysis -> model step -> synthesis, all on the
+        GPU (``interpreter_proposed.py:203-213, 352-365``).  ``pcm``: ``[B,256]`` float32 numpy array
+        (synchronous) or CUDA tensor (asynchronous on the current torch stream).  The output lags the
+        input by one hop, exactly like the reference loop."""
+        if dc_mode not in self._DC:
+            raise ValueError("dc_mode must be 'edge' or 'zero'")
+        if isinstance(pcm, np.ndarray):
+            x = np.ascontiguousarray(pcm, dtype=np.float32)
+            if x.shape != (self.batch, 256):
+                raise ValueError("pcm must be [%d,256], got %s" % (self.batch, x.shape))
+            o = np.empty_like(x)
+            _check(self._lib, self._lib.nutls_enhance_hop_host(self._h, _fptr(x), _fptr(o), self._DC[dc_mode]))
+            return o
+        import torch
+        if not (torch.is_tensor(pcm) and pcm.is_cuda and pcm.dtype == torch.float32 and pcm.is_contiguous()):
+            raise ValueError("pcm must be a contiguous float32 CUDA tensor or a numpy array")
+        if tuple(pcm.shape) != (self.batch, 256):
+            raise ValueError("pcm must be [%d,256], got %s" % (self.batch, tuple(pcm.shape)))
+        if out is None:
+            out = torch.empty_like(pcm)
+        stream = torch.cuda.current_stream(pcm.device).cuda_stream
+        _check(self._lib, self._lib.nutls_enhance_hop(self._h, pcm.data_ptr(), out.data_ptr(), self._DC[dc_mode], stream))
+        return out
+
+    def stft_hop(self, pcm):
+        """Analysis half only: CUDA tensor ``[B,256]`` -> the library's ``mag_in`` buffer (phase kept inside)."""
+        import torch
+        stream = torch.cuda.current_stream(pcm.device).cuda_stream
+        _check(self._lib, self._lib.nutls_stft_hop(self._h, pcm.data_ptr(), stream))
+
+    def istft_hop(self, out, dc_mode: str = "edge"):
+        """Synthesis half only: the library's ``mag_out`` buffer (+ the phase of the last ``stft_hop``) ->
+        CUDA tensor ``out [B,256]``."""
+        import torch
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        _check(self._lib, self._lib.nutls_istft_hop(self._h, out.data_ptr(), self._DC[dc_mode], stream))
         return out
 
     def step_resident(self, stream: int = 0):

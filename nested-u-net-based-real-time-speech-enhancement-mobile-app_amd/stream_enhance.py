@@ -129,6 +129,25 @@ def real_time_speech_enhancer(noisy_speech: np.ndarray, runner: Callable[..., Di
     return out_file[FRAME_LEN - FRAME_STEP:], time_array
 
 
+def enhance_batch_on_device(noisy: np.ndarray, engine, dc_mode: str = "edge") -> np.ndarray:
+    """The same loop with the STFT / inverse STFT on the GPU too: ``noisy [B, N]`` (one utterance per stream,
+    equal lengths) -> enhanced ``[B, N]`` in the alignment of :func:`real_time_speech_enhancer` (whose first
+    256 output samples are dropped, interpreter_proposed.py:368).  Only PCM hops cross the host boundary:
+    ``engine.enhance_hop`` = ``nutls_enhance_hop_host`` of the C ABI."""
+    audio = np.asarray(noisy, np.float32)
+    if audio.ndim == 1:
+        audio = audio[None]
+    if audio.shape[0] != engine.batch:
+        raise ValueError("need one utterance per stream: %d != %d" % (audio.shape[0], engine.batch))
+    n = audio.shape[1]
+    num_blocks = (n - (FRAME_LEN - FRAME_STEP)) // FRAME_STEP
+    out = np.zeros((audio.shape[0], n + (FRAME_LEN - FRAME_STEP)), np.float64)
+    for idx in range(num_blocks):
+        hop = np.ascontiguousarray(audio[:, idx * FRAME_STEP:(idx + 1) * FRAME_STEP])
+        out[:, idx * FRAME_STEP:(idx + 1) * FRAME_STEP] = engine.enhance_hop(hop, dc_mode)
+    return out[:, FRAME_LEN - FRAME_STEP:]
+
+
 def snr_db(clean: np.ndarray, est: np.ndarray) -> float:
     n = min(len(clean), len(est))
     c, e = np.asarray(clean[:n], np.float64), np.asarray(est[:n], np.float64)
