@@ -132,3 +132,170 @@ __device__ __forceinline__ void ddb_block(const DdbParams& p, int stream, float*
 }
 
 }  // namespace nutls
+
+// -------------------------------------------------------------------------------------------------
+//  The same block for the persistent kernel (512 threads, ~70 KB of LDS scratch): everything that does
+//  not depend on this frame's arithmetic -- the history rings, the previous input / output rows and
+//  the small weights of the six grouped blocks -- is fetched into LDS by all threads up front, and the
+//  two dense (2,3) convs (`in`: C -> G, `out`: G -> C) are split over K across the whole workgroup
+//  (float4 weight loads, coalesced over the output channel) instead of running on F*G threads.
+// -------------------------------------------------------------------------------------------------
+namespace nutls {
+
+typedef float ddb_f4 __attribute__((ext_vector_type(4)));
+
+// K-split dense (2,3) conv:  out[f][co] = sum_{t,kw,ci} W[t][kw][ci][co] * X_t[f+kw-1][ci]
+//   X0 / X1: LDS rows [F][CI] of the previous / current frame; W: global [2][3][CI][CO]
+//   part: LDS [nks][F*CO/4] float4 partial sums.  All nthreads call; the result is left in part[0..] summed
+//   by the first F*CO/4 threads (returned in `acc` for those threads, valid when tid < F*CO/4).
+__device__ __forceinline__ ddb_f4 ddb_dense23(const float* X0, const float* X1, const float* W, int F, int CI, int CO, float* part,
+                                              int tid, int nthreads) {
+  const int nq = F * CO / 4;                    // float4 outputs
+  int nks = nthreads / nq;
+  const int entries = 6 * CI;                   // (t, kw, ci)
+  while (entries % nks) nks >>= 1;              // whole entries per slice (entries = 3 * 2^n, nks a power of two)
+  const int epk = entries / nks;
+  const int q = tid % nq, ks = tid / nq;
+  const int f = q / (CO / 4), cq = q - f * (CO / 4);
+  ddb_f4 a = {0.f, 0.f, 0.f, 0.f};
+  if (ks < nks) {
+    for (int e = ks * epk; e < (ks + 1) * epk; ++e) {
+      const int t = e / (3 * CI), r = e - t * 3 * CI;
+      const int kw = r / CI, ci = r - kw * CI;
+      const int fr = f + kw - 1;
+      if (fr < 0 || fr >= F) continue;
+      const ddb_f4 w = *reinterpret_cast<const ddb_f4 __attribute__((address_space(1)))*>(
+          (unsigned long long)(W + static_cast<size_t>(e) * CO + 4 * cq));
+      a += w * (t ? X1 : X0)[fr * CI + ci];
+    }
+    *reinterpret_cast<ddb_f4*>(part + (static_cast<size_t>(ks) * nq + q) * 4) = a;
+  }
+  __syncthreads();
+  ddb_f4 s = {0.f, 0.f, 0.f, 0.f};
+  if (tid < nq)
+    for (int k2 = 0; k2 < nks; ++k2) s += *reinterpret_cast<const ddb_f4*>(part + (static_cast<size_t>(k2) * nq + tid) * 4);
+  return s;
+}
+
+// lds: >= 17.5K floats.  All nthreads (a multiple of 64, >= 256) call.
+__device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, float* lds, int tid, int nthreads) {
+  const int F = p.F, C = p.C, G = C >> 1;
+  const int FG = F * G, FC = F * C;
+  float* xs = lds;                    // [F][C]   current input
+  float* pin = xs + FC;               // [F][C]   previous input
+  float* o = pin + FC;                // [7][F][G] o_0 .. o_6
+  float* yv = o + 7 * FG;             // [F][G]
+  float* pout = yv + FG;              // [F][G]   previous o_6
+  float* rings = pout + FG;           // block k at rings + F*G*k(k-1)/2 : [F][k*G] (frame t-d)
+  float* wgs = rings + 21 * FG;       // block k at wgs + 6*G*k(k-1)/2 : [2][3][k][G]
+  float* w1s = wgs + 126 * G;         // [6][G][G]
+  float* sm = w1s + 6 * G * G;        // [6][4][G] bg, b1, gamma, beta
+  float* part = sm + 24 * G;          // K-split partial sums (<= 2048 floats)
+  const size_t soff = static_cast<size_t>(stream) * p.sstride;
+  const int step = *p.step;
+  // ---- phase A: everything that is already known
+  for (int q = tid; q < FC; q += nthreads) {
+    const int f = q / C, c = q - f * C;
+    xs[q] = p.x[soff + f * p.x_ld + c];
+    pin[q] = p.st_in[soff + q];
+  }
+  for (int q = tid; q < FG; q += nthreads) pout[q] = p.st_out[soff + q];
+  {
+    int roff = 0, woff = 0;
+    for (int k = 1; k <= 6; ++k) {
+      const int d = 1 << (k - 1), kG = k * G;
+      const float* ring = p.st_blk[k - 1] + soff + static_cast<size_t>(step & (d - 1)) * F * kG;
+      for (int q = tid; q < F * kG; q += nthreads) rings[roff + q] = ring[q];
+      for (int q = tid; q < 6 * kG; q += nthreads) wgs[woff + q] = p.wg[k - 1][q];
+      for (int q = tid; q < G * G; q += nthreads) w1s[(k - 1) * G * G + q] = p.w1[k - 1][q];
+      if (tid < G) {
+        sm[((k - 1) * 4 + 0) * G + tid] = p.bg[k - 1][tid];
+        sm[((k - 1) * 4 + 1) * G + tid] = p.b1[k - 1][tid];
+        sm[((k - 1) * 4 + 2) * G + tid] = p.gamma[k - 1][tid];
+        sm[((k - 1) * 4 + 3) * G + tid] = p.beta[k - 1][tid];
+      }
+      roff += F * kG;
+      woff += 6 * kG;
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < FC; q += nthreads) p.st_in[soff + q] = xs[q];      // prev_in <- x
+  // ---- o_0 = PReLU(conv(2,3)([prev_in ; x]))
+  {
+    const ddb_f4 s = ddb_dense23(pin, xs, p.w_in, F, C, G, part, tid, nthreads);
+    if (tid < FG / 4) {
+      const int cq = tid % (G / 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[4 * tid + j] = ddb_prelu(s[j] + p.b_in[4 * cq + j], p.a_in);
+    }
+    __syncthreads();
+  }
+  // ---- blocks 1..6 (sequential: dense connectivity)
+  int roff = 0, woff = 0;
+  for (int k = 1; k <= 6; ++k) {
+    const int d = 1 << (k - 1), kG = k * G;
+    const float* ringl = rings + roff;
+    const float* wgl = wgs + woff;
+    const float* sml = sm + (k - 1) * 4 * G;
+    if (tid < FG) {
+      const int f = tid / G, g = tid - f * G;
+      float a = sml[g];
+      for (int kw = 0; kw < 3; ++kw) {
+        const int fr = f + (kw - 1) * d;
+        if (fr < 0 || fr >= F) continue;
+        for (int j = 0; j < k; ++j) {
+          const int ch = g * k + j;             // channel of in_k seen by filter g
+          const int m = ch / G;                 // in_k = [o_{k-1}, ..., o_0]: chunk m is o_{k-1-m}
+          const float cur = o[(k - 1 - m) * FG + fr * G + (ch - m * G)];
+          const float old = ringl[fr * kG + ch];
+          a = fmaf(wgl[(kw * k + j) * G + g], old, a);
+          a = fmaf(wgl[(3 * k + kw * k + j) * G + g], cur, a);
+        }
+      }
+      yv[tid] = a;
+    }
+    // ring slot <- in_k of this frame (every read of the old slot went through LDS)
+    {
+      float* ring = p.st_blk[k - 1] + soff + static_cast<size_t>(step & (d - 1)) * F * kG;
+      for (int q = tid; q < F * kG; q += nthreads) {
+        const int f = q / kG, ch = q - f * kG;
+        const int m = ch / G;
+        ring[q] = o[(k - 1 - m) * FG + f * G + (ch - m * G)];
+      }
+    }
+    __syncthreads();
+    if (tid < FG) {
+      const int f = tid / G, g = tid - f * G;
+      const float* w1l = w1s + (k - 1) * G * G;
+      float z = sml[G + g];
+      for (int gi = 0; gi < G; ++gi) z = fmaf(w1l[gi * G + g], yv[f * G + gi], z);     // [gin][gout]
+      // LayerNorm over the G channels of row f = G consecutive lanes
+      float s = z;
+      for (int msk = 1; msk < G; msk <<= 1) s += __shfl_xor(s, msk);
+      const float mean = s / static_cast<float>(G);
+      const float dv = z - mean;
+      float q2 = dv * dv;
+      for (int msk = 1; msk < G; msk <<= 1) q2 += __shfl_xor(q2, msk);
+      const float rstd = 1.0f / sqrtf(q2 / static_cast<float>(G) + 1e-8f);
+      o[k * FG + tid] = ddb_prelu(dv * rstd * sml[2 * G + g] + sml[3 * G + g], p.alpha[k - 1]);
+    }
+    __syncthreads();
+    roff += F * kG;
+    woff += 6 * kG;
+  }
+  // ---- out conv over [prev_out ; o_6], then prev_out <- o_6
+  {
+    const ddb_f4 s = ddb_dense23(pout, o + 6 * FG, p.w_out, F, G, C, part, tid, nthreads);
+    if (tid < FC / 4) {
+      const int f = tid / (C / 4), cq = tid - f * (C / 4);
+      ddb_f4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = ddb_prelu(s[j] + p.b_out[4 * cq + j], p.a_out);
+      *reinterpret_cast<ddb_f4*>(p.dst + soff + f * p.dst_ld + 4 * cq) = r;
+    }
+    for (int q = tid; q < FG; q += nthreads) p.st_out[soff + q] = o[6 * FG + q];
+  }
+  __syncthreads();
+}
+
+}  // namespace nutls

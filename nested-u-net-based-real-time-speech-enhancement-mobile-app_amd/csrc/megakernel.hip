@@ -967,7 +967,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
         } else if (op == DEV_OP_INLAYER) {
           input_layer_op(cur, a, stream, lds_in, tid, nc_hand, nxt);
         } else if (op == DEV_OP_DDB) {
-          ddb_block(a.ddb[cur.w[0]], stream, lds_out, tid, MK_THREADS);
+          ddb_block_wg(a.ddb[cur.w[0]], stream, lds_out, tid, MK_THREADS);
         } else {
           out_conv_op(cur, a, stream, tid);
         }
