@@ -201,21 +201,16 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
   }
   for (int q = tid; q < FG; q += nthreads) pout[q] = p.st_out[soff + q];
   {
-    int roff = 0, woff = 0;
-    for (int k = 1; k <= 6; ++k) {
-      const int d = 1 << (k - 1), kG = k * G;
-      const float* ring = p.st_blk[k - 1] + soff + static_cast<size_t>(step & (d - 1)) * F * kG;
-      for (int q = tid; q < F * kG; q += nthreads) rings[roff + q] = ring[q];
-      for (int q = tid; q < 6 * kG; q += nthreads) wgs[woff + q] = p.wg[k - 1][q];
-      for (int q = tid; q < G * G; q += nthreads) w1s[(k - 1) * G * G + q] = p.w1[k - 1][q];
-      if (tid < G) {
-        sm[((k - 1) * 4 + 0) * G + tid] = p.bg[k - 1][tid];
-        sm[((k - 1) * 4 + 1) * G + tid] = p.b1[k - 1][tid];
-        sm[((k - 1) * 4 + 2) * G + tid] = p.gamma[k - 1][tid];
-        sm[((k - 1) * 4 + 3) * G + tid] = p.beta[k - 1][tid];
-      }
-      roff += F * kG;
-      woff += 6 * kG;
+    // small weights: one packed blob in exactly this LDS order (wgs | w1s | sm), float4 copies, all independent
+    const int n4 = (126 * G + 6 * G * G + 24 * G) / 4;
+    const ddb_f4 __attribute__((address_space(1)))* src = (const ddb_f4 __attribute__((address_space(1)))*)(unsigned long long)p.wsmall;
+    for (int q = tid; q < n4; q += nthreads) reinterpret_cast<ddb_f4*>(wgs)[q] = src[q];
+    // history rings of the six blocks as one flat index space (block k starts at FG * k(k-1)/2)
+    for (int q = tid; q < 21 * FG; q += nthreads) {
+      int k = 1, base = 0;
+      while (q >= base + k * FG) { base += k * FG; ++k; }
+      const int d = 1 << (k - 1);
+      rings[q] = p.st_blk[k - 1][soff + static_cast<size_t>(step & (d - 1)) * F * k * G + (q - base)];
     }
   }
   __syncthreads();

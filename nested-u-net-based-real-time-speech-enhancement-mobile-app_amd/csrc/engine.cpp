@@ -101,7 +101,7 @@ struct Engine {
   DdbParams* d_ddb = nullptr;
   struct DdbStates { int in, blk[6], out; };
   DdbStates ddb_st[13];
-  struct DdbW { float *w_in, *b_in, *wg[6], *bg[6], *w1[6], *b1[6], *gamma[6], *beta[6], *w_out, *b_out; float a_in, a_out, alpha[6]; };
+  struct DdbW { float *w_in, *b_in, *wg[6], *bg[6], *w1[6], *b1[6], *gamma[6], *beta[6], *w_out, *b_out, *wsmall; float a_in, a_out, alpha[6]; };
   DdbW ddbw[13];
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
@@ -318,6 +318,7 @@ static int prep_ddb_weights(Engine* e, const WeightMap& wm) {
     };
     if ((rc = conv_prelu(tag + "_in", &W.w_in, &W.b_in, &W.a_in))) return rc;
     if ((rc = conv_prelu(tag + "_out", &W.w_out, &W.b_out, &W.a_out))) return rc;
+    std::vector<float> pk_wg, pk_w1, pk_sm;      // the LDS image of ddb_block_wg: wg all blocks | w1 all blocks | bg,b1,gamma,beta per block
     for (int k = 1; k <= 6; ++k) {
       const std::string n = tag + "_" + std::to_string(k);
       const HostTensor* wg = find(wm, n + ".wg", &err);
@@ -337,7 +338,14 @@ static int prep_ddb_weights(Engine* e, const WeightMap& wm) {
       if ((rc = upload(e, gm->data, &W.gamma[k - 1]))) return rc;
       if ((rc = upload(e, bt->data, &W.beta[k - 1]))) return rc;
       W.alpha[k - 1] = al->data[0];
+      const std::vector<float> wgt = ohwi_to_tkio(*wg), w1t = transpose2d(*w1, G, G);
+      pk_wg.insert(pk_wg.end(), wgt.begin(), wgt.end());
+      pk_w1.insert(pk_w1.end(), w1t.begin(), w1t.end());
+      for (const HostTensor* t : {bg, b1, gm, bt}) pk_sm.insert(pk_sm.end(), t->data.begin(), t->data.end());
     }
+    pk_wg.insert(pk_wg.end(), pk_w1.begin(), pk_w1.end());
+    pk_wg.insert(pk_wg.end(), pk_sm.begin(), pk_sm.end());
+    if ((rc = upload(e, pk_wg, &W.wsmall))) return rc;
   }
   return NUTLS_OK;
 }
@@ -547,6 +555,7 @@ static void push_ddb(Engine* e, std::vector<Launch>* plan, int par, int b, const
     p.gamma[k] = W.gamma[k]; p.beta[k] = W.beta[k]; p.alpha[k] = W.alpha[k];
   }
   p.w_out = W.w_out; p.b_out = W.b_out; p.a_out = W.a_out;
+  p.wsmall = W.wsmall;
   p.step = e->d_step; p.F = F; p.C = C; p.B = e->B; p.sstride = static_cast<long long>(e->sstride);
   Launch L{};
   L.kind = Launch::DDB;

@@ -99,6 +99,7 @@ struct DdbParams {
   const float* w1[6]; const float* b1[6];                  // [gin][gout]
   const float* gamma[6]; const float* beta[6]; float alpha[6];
   const float* w_out; const float* b_out; float a_out;     // [t][kw][g][c]
+  const float* wsmall;               // wg (all blocks), w1 (all blocks), {bg,b1,gamma,beta} (all blocks) packed in the LDS order of ddb_block_wg
   const int* step;                   // device-resident frame counter (ring position)
   int F, C, B;
   long long sstride;
