@@ -19,4 +19,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   python $R/tools/pmc_summary.py $(find /tmp/pm -name "*.db" | head -1) nutls_stream
 done
 } > $OUT/pmc.txt 2>&1
+( cd $R && { timeout 300 python bench.py --no-cpu-baseline --variant baseline; timeout 300 python bench.py --no-cpu-baseline --batch 1024 --host-io --steps 100; timeout 300 python bench.py --no-cpu-baseline --frontend; timeout 300 python bench.py --no-cpu-baseline --mode graph --steps 50; } > $OUT/bench_other_configs.json 2>/dev/null )
+cut -c1-330 $OUT/bench_other_configs.json
 cat $OUT/bench.json | tail -1 | cut -c1-400; cat $OUT/kernel_stats.txt | head -5; cat $OUT/pmc.txt
