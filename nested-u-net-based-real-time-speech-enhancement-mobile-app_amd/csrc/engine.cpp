@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <exception>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -991,7 +992,12 @@ int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, in
   if ((rc = arena_commit(e))) return rc;
   build_plan(e, 0);
   build_plan(e, 1);
-  if ((rc = upload_device_plans(e))) return rc;
+  try {
+    rc = upload_device_plans(e);
+  } catch (const std::exception& ex) {     // planning invariants (weights.cpp) are reported, never thrown through the C ABI
+    return fail(NUTLS_ERR_ARG, std::string("plan: ") + ex.what());
+  }
+  if (rc) return rc;
   e->n_cu = prop.multiProcessorCount;
   e->debug["input_layer"] = {e->t_inlayer, 256 * 64};
   e->debug["msfe6_de.y"] = {e->t_y, 256 * 64};
