@@ -956,6 +956,9 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
         const bool nconv = (i + 1 < n_ops) && static_cast<int>(nxt.w[23]) == DEV_OP_CONV;
         const bool nc_hand = nconv && b0(cur.w[22]) != 0;      // non-conv op -> conv hand-off
         const int nc_coff = b1(cur.w[22]);
+        // the next conv layer's first weights / epilogue parameters: requested before the op's own loads, so that
+        // they have arrived when the op ends (requested after it, the next layer would start with an L2 round trip)
+        if (nconv) prefetch_conv(nxt, wb, wave, tid, cy);
         if (op == DEV_OP_LSTM) {
           LstmParams p;
           decode_lstm(cur, a, p);
@@ -971,7 +974,6 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
         } else {
           out_conv_op(cur, a, stream, tid);
         }
-        if (nconv) prefetch_conv(nxt, wb, wave, tid, cy);
       }
       cur = nxt;
     }
