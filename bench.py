@@ -59,6 +59,34 @@ def cpu_baseline(sample_batch=32, budget_s=12.0):
             "kind": "port", "sample": "%d steps of %d streams (oracle/nutls_ref.py, torch-CPU fp32), %.1f s" % (n, sample_batch, dt)}
 
 
+def bench_offline(args, rank, world, local_rank):
+    """one utterance per GPU, blocks of T frames resident in HBM; value = frames/s of that utterance."""
+    import torch
+    import nunet_amd
+    T_ = args.offline
+    off = nunet_amd.NutlsOffline(max_frames=T_, device=local_rank)
+    pool = torch.from_numpy(synthetic_pool(T_, 4, 1234 + rank)).cuda()
+    out = torch.empty(T_, 256, device="cuda")
+    for s in range(max(2, args.warmup // 8)):
+        off.process_block_device(pool[s % 4], out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        off.process_block_device(pool[s % 4], out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    if rank == 0:
+        print(json.dumps({"metric": "STFT frames/sec (512-pt, 50% hop) through the NUNet-TLS frame step", "value": round(T_ * args.steps / dt, 1),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup // 8),
+                          "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic magnitudes 0.25*|N(0,1)|, trained weights",
+                          "config": {"workload": "offline / block mode: ONE utterance, %d consecutive frames per call (SURVEY 8f.2)" % T_,
+                                     "frames_per_block": T_, "mode": "per-layer kernels, frame index as stream index, LSTM scan"},
+                          "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6)}))
+    off.close()
+
+
 def parity_check(eng_cls, pool, n_streams=4, steps=6):
     """GPU vs oracle on identical inputs for the first streams of the workload (streams are
     independent, so a 4-stream engine reproduces streams 0..3 of the 256-stream run)."""
@@ -86,6 +114,8 @@ def main():
                     help="streaming serving (BASELINE configs[4]): one step per host call, host buffers in/out (H2D + D2H timed)")
     ap.add_argument("--frontend", action="store_true",
                     help="a step = STFT analysis + model step + inverse STFT/overlap-add of one 256-sample hop per stream, all on the GPU")
+    ap.add_argument("--offline", type=int, default=0, metavar="T",
+                    help="offline / block mode: ONE utterance, a step = one block of T consecutive frames (frames/s of that utterance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default="", help="write the per-launch HIP-event timeline here")
     args = ap.parse_args()
@@ -108,6 +138,8 @@ def main():
     import nunet_amd
     from nunet_amd.sharding import reduce_throughput
 
+    if args.offline:
+        return bench_offline(args, rank, world, local_rank)
     B = args.batch
     weights = None
     if args.variant == "baseline":

@@ -88,6 +88,18 @@ int nutls_enhance_hop_host(nutls_handle* h, const float* pcm_in, float* pcm_out,
 int nutls_stft_hop(nutls_handle* h, const float* pcm_in, void* stream);
 int nutls_istft_hop(nutls_handle* h, float* pcm_out, int dc_mode, void* stream);
 
+/* ---- Offline / block mode ------------------------------------------------
+ * One utterance, up to `max_frames` consecutive frames per call: the frame index takes the place of the stream
+ * index (a conv layer's previous-frame tap is the same tensor one frame earlier), every conv-like layer runs once
+ * per block over all frames, only the 13 LSTM recurrences are scanned sequentially.  Same function as feeding the
+ * frames one by one to a batch-1 streaming handle (the offline formulation of models/proposed.py:284-625 with the
+ * streaming CTFA of converter_proposed.py:258-262); the state carries over from block to block inside the handle
+ * and is zeroed by nutls_reset(h, -1).  mag_in / mag_out: DEVICE pointers to [n_frames, 256] float32. */
+int nutls_create_offline(const void* weights, size_t n_bytes, int max_frames, int device, nutls_handle** out);
+int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames, void* stream);
+/* Same with HOST buffers (synchronises). */
+int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames);
+
 /* Library-owned device staging buffers [B,256]; stepping on them avoids the D2D copies and lets
  * the captured hipGraph run with no per-call parameter update. */
 int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out);

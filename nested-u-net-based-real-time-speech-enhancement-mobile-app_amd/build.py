@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnutls_hip.so")
-SOURCES = ["kernels.hip", "megakernel.hip", "stft.hip", "weights.cpp", "engine.cpp"]
+SOURCES = ["kernels.hip", "megakernel.hip", "stft.hip", "offline.hip", "weights.cpp", "engine.cpp"]
 HEADERS = ["nutls_internal.hpp", os.path.join("..", "..", "include", "nutls.h")]
 
 

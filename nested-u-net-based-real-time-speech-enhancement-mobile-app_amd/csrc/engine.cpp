@@ -123,6 +123,9 @@ struct Engine {
   float *fe_pcm_in = nullptr, *fe_pcm_out = nullptr;
   float *t_inlayer = nullptr, *t_y = nullptr, *t_d = nullptr, *t_up = nullptr;
   float* upcat[6] = {nullptr};
+  int offline = 0;       // > 0: offline / block handle for up to this many frames per call (arena slot 0 = carried state)
+  std::vector<Launch> plan_off;   // plan[0] with 'previous frame' = one arena slot earlier
+  float* zx = nullptr;   // [offline][84] LSTM input products of a block
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
   int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel
   CompactOp* dplan[2] = {nullptr, nullptr};
@@ -949,7 +952,9 @@ extern "C" {
 const char* nutls_last_error(void) { return g_last_error.c_str(); }
 const char* nutls_version(void) { return "nutls-hip 0.1 (gfx950, fp32 MFMA)"; }
 
-int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, int device, nutls_handle** out) {
+static int build_offline_plan(Engine* e);
+
+static int create_common(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out) {
   if (!weights || !out || batch < 1) return fail(NUTLS_ERR_ARG, "nutls_create: null pointer or batch < 1");
   if (variant != NUTLS_VARIANT_LSTM && variant != NUTLS_VARIANT_BASELINE) return fail(NUTLS_ERR_ARG, "nutls_create: unknown variant");
   int ndev = 0;
@@ -1004,8 +1009,99 @@ int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, in
   e->debug["msfe6_de.up"] = {e->t_up, 256 * 128};
   e->debug["msfe6_de.d"] = {e->t_d, 256 * 64};
   for (int s = 0; s < 6; ++s) e->debug[std::string(kDecoder[s].prefix) + ".upcat"] = {e->upcat[s], static_cast<size_t>(kDecoder[s].f0 / 2) * 128};
+  if (offline_frames > 0) {
+    e->offline = offline_frames;
+    e->mode = 0;
+    if ((rc = build_offline_plan(e))) return rc;
+  }
   HIP_TRY(hipDeviceSynchronize());
   *out = h.release();
+  return NUTLS_OK;
+}
+
+int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, int device, nutls_handle** out) {
+  return create_common(weights, n_bytes, variant, batch, device, 0, out);
+}
+
+int nutls_create_offline(const void* weights, size_t n_bytes, int max_frames, int device, nutls_handle** out) {
+  if (max_frames < 1 || max_frames > 4096) return fail(NUTLS_ERR_ARG, "nutls_create_offline: max_frames must be 1..4096");
+  // arena slot 0 holds the state carried in from the previous block, slots 1..max_frames the frames of the block
+  return create_common(weights, n_bytes, NUTLS_VARIANT_LSTM, max_frames + 1, device, max_frames, out);
+}
+
+// ---- offline / block mode -------------------------------------------------------------------------
+// plan[0] reads the previous-frame tap of every state tensor from its second ping-pong buffer and writes the
+// current frame into the first.  The block plan keeps ONE buffer per tensor: the current frame of block frame
+// t is arena slot t+1, its previous frame slot t -- i.e. "cur" pointers move one slot up, "prev" pointers become
+// the first buffer at slot 0; the kernels then index slots with the frame number.
+static int build_offline_plan(Engine* e) {
+  const size_t S = e->sstride;
+  auto rw = [&](const float* q) -> float* {
+    if (!q) return nullptr;
+    float* p = const_cast<float*>(q);
+    if (p < e->arena || p >= e->arena + S) return p;               // weights, I/O staging
+    for (const StateTensor& st : e->states)
+      if (st.buf[1] != st.buf[0] && p >= st.buf[1] && p < st.buf[1] + st.per_stream()) return st.buf[0] + (p - st.buf[1]);
+    return p + S;
+  };
+  e->plan_off = e->plan[0];
+  for (Launch& L : e->plan_off) {
+    switch (L.kind) {
+      case Launch::CONV:
+        L.conv.src0 = rw(L.conv.src0); L.conv.src1 = rw(L.conv.src1); L.conv.dst0 = rw(L.conv.dst0); L.conv.dst1 = rw(L.conv.dst1);
+        break;
+      case Launch::LSTM:
+        L.lstm.x = rw(L.lstm.x); L.lstm.dst = rw(L.lstm.dst);
+        L.lstm.h_in = rw(L.lstm.h_in); L.lstm.c_in = rw(L.lstm.c_in); L.lstm.h_out = rw(L.lstm.h_out); L.lstm.c_out = rw(L.lstm.c_out);
+        break;
+      case Launch::CTFA: L.ctfa.x = rw(L.ctfa.x); L.ctfa.e0 = rw(L.ctfa.e0); L.ctfa.y = rw(L.ctfa.y); break;
+      case Launch::INLAYER: L.inl.y = rw(L.inl.y); break;
+      case Launch::OUTCONV: L.outc.x = rw(L.outc.x); break;
+      case Launch::DDB: return fail(NUTLS_ERR_ARG, "offline mode: LSTM variant only");
+    }
+  }
+  return dev_alloc(e, static_cast<size_t>(e->offline) * 84, &e->zx, true);
+}
+
+int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames, void* stream) {
+  if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_process_block: null pointer");
+  Engine* e = &h->eng;
+  if (!e->offline) return fail(NUTLS_ERR_ARG, "nutls_process_block: not an offline handle (nutls_create_offline)");
+  if (n_frames < 1 || n_frames > e->offline) return fail(NUTLS_ERR_ARG, "nutls_process_block: n_frames out of range");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t bytes = static_cast<size_t>(n_frames) * NUTLS_BINS * sizeof(float);
+  if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
+  for (const Launch& L0 : e->plan_off) {
+    Launch L = L0;
+    hipError_t err = hipSuccess;
+    switch (L.kind) {
+      case Launch::CONV: L.conv.B = n_frames; err = launch_conv(L.ck, L.conv, s); break;
+      case Launch::LSTM: L.lstm.B = n_frames; err = launch_lstm_block(L.lstm, e->zx, n_frames, s); break;
+      case Launch::CTFA: L.ctfa.B = n_frames; err = launch_ctfa(L.ctfa, s); break;
+      case Launch::INLAYER: L.inl.n_pos = n_frames * NUTLS_BINS; err = launch_input_layer(L.inl, s); break;
+      case Launch::OUTCONV: L.outc.n_pos = n_frames * NUTLS_BINS; err = launch_out_conv(L.outc, s); break;
+      default: err = hipErrorInvalidValue;
+    }
+    if (err != hipSuccess) return fail(NUTLS_ERR_HIP, "block launch " + L.name + ": " + hipGetErrorString(err));
+  }
+  if (mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
+  // the last frame's slot becomes the carried state of the next block
+  HIP_TRY(hipMemcpyAsync(e->arena, e->arena + static_cast<size_t>(n_frames) * e->sstride, e->sstride * sizeof(float), hipMemcpyDeviceToDevice, s));
+  e->steps += n_frames;
+  return NUTLS_OK;
+}
+
+int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames) {
+  if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_process_block_host: null pointer");
+  Engine* e = &h->eng;
+  if (!e->offline || n_frames < 1 || n_frames > e->offline) return fail(NUTLS_ERR_ARG, "nutls_process_block_host: not an offline handle or n_frames out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t bytes = static_cast<size_t>(n_frames) * NUTLS_BINS * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyHostToDevice, e->stream));
+  int rc = nutls_process_block(h, e->io_in, e->io_out, n_frames, e->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return NUTLS_OK;
 }
 
@@ -1049,6 +1145,7 @@ int nutls_set_mode(nutls_handle* h, int mode) {
 int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* stream) {
   if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_step: null pointer");
   Engine* e = &h->eng;
+  if (e->offline) return fail(NUTLS_ERR_ARG, "nutls_step: offline handle, use nutls_process_block");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = static_cast<size_t>(e->B) * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
@@ -1198,6 +1295,7 @@ int nutls_reset(nutls_handle* h, int stream_idx) {
   if (!h) return fail(NUTLS_ERR_ARG, "null handle");
   Engine* e = &h->eng;
   if (stream_idx >= e->B) return fail(NUTLS_ERR_ARG, "nutls_reset: stream index out of range");
+  if (e->offline) stream_idx = 0;    // one utterance: the carried state lives in arena slot 0
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
   // a stream's whole slice of the arena (state of both parities + scratch) is contiguous

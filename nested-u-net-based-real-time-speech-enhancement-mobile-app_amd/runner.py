@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "nutls_profile_persistent", "nutls_last_error",
     "nutls_version",
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
+    "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
 )
 
 
@@ -75,6 +76,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_enhance_hop_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
     lib.nutls_stft_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
     lib.nutls_istft_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
+    lib.nutls_create_offline.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
+    lib.nutls_process_block.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
+    lib.nutls_process_block_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:
@@ -344,3 +348,58 @@ class NutlsRunner:
             res[k_out] = a.reshape(self._io_shape(shp))
         self._last = res
         return res
+
+
+class NutlsOffline:
+    """Offline / block mode: one utterance, up to ``max_frames`` consecutive frames per
+    call -- every conv-like layer runs once per block over all frames (the frame index takes the place of
+    the stream index), only the LSTM recurrences are scanned.  Same function as a batch-1 streaming engine
+    fed frame by frame; the state carries over between calls until :meth:`reset`."""
+
+    def __init__(self, weights=None, max_frames: int = 256, device: int = 0):
+        self._lib = load_library()
+        blob = read_blob(weights if weights is not None else DEFAULT_WEIGHTS)
+        self._h = ctypes.c_void_p()
+        self.max_frames = int(max_frames)
+        _check(self._lib, self._lib.nutls_create_offline(blob, len(blob), self.max_frames, int(device), ctypes.byref(self._h)))
+
+    def process(self, mags) -> np.ndarray:
+        """``mags [N,256]`` float32 (any N) -> enhanced magnitudes ``[N,256]``; blocks of ``max_frames``."""
+        m = np.ascontiguousarray(mags, dtype=np.float32)
+        if m.ndim != 2 or m.shape[1] != T.N_BINS:
+            raise ValueError("mags must be [N,%d], got %s" % (T.N_BINS, m.shape))
+        out = np.empty_like(m)
+        for a in range(0, m.shape[0], self.max_frames):
+            blk = np.ascontiguousarray(m[a:a + self.max_frames])
+            o = np.empty_like(blk)
+            _check(self._lib, self._lib.nutls_process_block_host(self._h, _fptr(blk), _fptr(o), blk.shape[0]))
+            out[a:a + blk.shape[0]] = o
+        return out
+
+    def process_block_device(self, mag, out=None):
+        """One block on device tensors: ``mag [n,256]`` float32 CUDA tensor, n <= max_frames; asynchronous on the
+        current torch stream."""
+        import torch
+        if not (torch.is_tensor(mag) and mag.is_cuda and mag.dtype == torch.float32 and mag.is_contiguous()):
+            raise ValueError("mag must be a contiguous float32 CUDA tensor")
+        if mag.dim() != 2 or mag.shape[1] != T.N_BINS or mag.shape[0] > self.max_frames:
+            raise ValueError("mag must be [n<=%d,%d], got %s" % (self.max_frames, T.N_BINS, tuple(mag.shape)))
+        if out is None:
+            out = torch.empty_like(mag)
+        stream = torch.cuda.current_stream(mag.device).cuda_stream
+        _check(self._lib, self._lib.nutls_process_block(self._h, mag.data_ptr(), out.data_ptr(), int(mag.shape[0]), stream))
+        return out
+
+    def reset(self):
+        _check(self._lib, self._lib.nutls_reset(self._h, -1))
+
+    def close(self):
+        if self._h:
+            self._lib.nutls_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,62 @@
+"""``-m gpu``: offline / block mode through the C ABI: T frames of one utterance per call must
+equal the frame-by-frame streaming result (same function, models/proposed.py offline semantics with the streaming
+CTFA) -- against the golden clip (oracle A outputs), the streaming HIP engine, and across block boundaries."""
+import os
+
+import numpy as np
+import pytest
+
+from nunet_amd import NutlsEngine, NutlsOffline
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def clip():
+    return np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+
+
+@pytest.mark.parametrize("max_frames", [256, 64, 7])
+def test_block_mode_equals_golden_and_streaming(clip, max_frames):
+    """249 frames in blocks of 256 (one call), 64 (carry across 4 calls) and 7 (ragged last block)."""
+    off = NutlsOffline(max_frames=max_frames)
+    got = off.process(clip["mags_in"])
+    off.close()
+    assert rms(got, clip["mags_out"]) < 2e-5
+    eng = NutlsEngine(batch=1)
+    stream = np.stack([eng.step(clip["mags_in"][i:i + 1])[0] for i in range(40)])
+    eng.close()
+    assert rms(got[:40], stream) < 1e-6
+
+
+def test_state_carries_between_calls_and_reset_restarts(clip):
+    off = NutlsOffline(max_frames=32)
+    a = off.process(clip["mags_in"][:32])
+    b = off.process(clip["mags_in"][32:64])            # continues the utterance
+    assert rms(np.concatenate([a, b]), clip["mags_out"][:64]) < 2e-5
+    off.reset()
+    again = off.process(clip["mags_in"][:32])
+    np.testing.assert_array_equal(a, again)
+    with pytest.raises(ValueError):
+        off.process(np.zeros((4, 255), np.float32))
+    off.close()
+
+
+def test_streaming_entry_points_reject_offline_handles_and_vice_versa(clip):
+    import ctypes
+    from nunet_amd.runner import _fptr
+    off = NutlsOffline(max_frames=8)
+    x = np.zeros((9, 256), np.float32)
+    assert off._lib.nutls_step_host(off._h, _fptr(x), _fptr(x.copy())) != 0
+    assert off._lib.nutls_process_block_host(off._h, _fptr(x), _fptr(x.copy()), 9) != 0      # > max_frames
+    off.close()
+    eng = NutlsEngine(batch=2)
+    y = np.zeros((2, 256), np.float32)
+    assert eng._lib.nutls_process_block_host(eng._h, _fptr(y), _fptr(y.copy()), 2) != 0
+    eng.close()
