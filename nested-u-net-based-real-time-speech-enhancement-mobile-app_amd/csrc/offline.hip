@@ -16,7 +16,9 @@ namespace nutls {
 
 namespace {
 constexpr int U = 21, G4 = 84;
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 forms (as in the persistent kernel): the scan is a serial chain, IEEE expf / division are 10-30 instructions each
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 }  // namespace
 
 // grid = frames; 128 threads.  zx [frames][84]
@@ -60,9 +62,9 @@ __global__ __launch_bounds__(128) void lstm_scan_kernel(const LstmParams p, cons
     }
     __syncthreads();
     if (tid < U) {
-      const float gi = sigm(z[tid]), gf = sigm(z[U + tid]), gg = tanhf(z[2 * U + tid]), go = sigm(z[3 * U + tid]);
+      const float gi = sigm(z[tid]), gf = sigm(z[U + tid]), gg = tanh_fast(z[2 * U + tid]), go = sigm(z[3 * U + tid]);
       c_state = gf * c_state + gi * gg;
-      const float h_new = go * tanhf(c_state);
+      const float h_new = go * tanh_fast(c_state);
       p.c_out[static_cast<size_t>(t) * p.sstride + tid] = c_state;
       p.h_out[static_cast<size_t>(t) * p.sstride + tid] = h_new;
       hs[tid] = h_new;
