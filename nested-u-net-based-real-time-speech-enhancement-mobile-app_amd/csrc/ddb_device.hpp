@@ -144,6 +144,21 @@ namespace nutls {
 
 typedef float ddb_f4 __attribute__((ext_vector_type(4)));
 
+// sum over G = 16 or 32 consecutive lanes (aligned), result in all of them: DPP quad / row exchanges, one
+// LDS-crossbar step only for the 32-lane case
+template <int CTRL>
+__device__ __forceinline__ float ddb_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float ddb_row_sum(float s, int G) {
+  s += ddb_dpp<0xB1>(s);      // quad_perm [1,0,3,2]
+  s += ddb_dpp<0x4E>(s);      // quad_perm [2,3,0,1]
+  s += ddb_dpp<0x141>(s);     // row_half_mirror
+  s += ddb_dpp<0x140>(s);     // row_mirror
+  if (G == 32) s += __shfl_xor(s, 16);
+  return s;
+}
+
 // K-split dense (2,3) conv:  out[f][co] = sum_{t,kw,ci} W[t][kw][ci][co] * X_t[f+kw-1][ci]
 //   X0 / X1: LDS rows [F][CI] of the previous / current frame; W: global [2][3][CI][CO]
 //   part: LDS [nks][F*CO/4] float4 partial sums.  All nthreads call; the result is left in part[0..] summed
@@ -265,13 +280,10 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
       float z = sml[G + g];
       for (int gi = 0; gi < G; ++gi) z = fmaf(w1l[gi * G + g], yv[f * G + gi], z);     // [gin][gout]
       // LayerNorm over the G channels of row f = G consecutive lanes
-      float s = z;
-      for (int msk = 1; msk < G; msk <<= 1) s += __shfl_xor(s, msk);
-      const float mean = s / static_cast<float>(G);
+      const float inv_g = 1.0f / static_cast<float>(G);
+      const float mean = ddb_row_sum(z, G) * inv_g;
       const float dv = z - mean;
-      float q2 = dv * dv;
-      for (int msk = 1; msk < G; msk <<= 1) q2 += __shfl_xor(q2, msk);
-      const float rstd = 1.0f / sqrtf(q2 / static_cast<float>(G) + 1e-8f);
+      const float rstd = __builtin_amdgcn_rsqf(ddb_row_sum(dv * dv, G) * inv_g + 1e-8f);
       o[k * FG + tid] = ddb_prelu(dv * rstd * sml[2 * G + g] + sml[3 * G + g], p.alpha[k - 1]);
     }
     __syncthreads();
