@@ -208,13 +208,22 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
   float* part = sm + 24 * G;          // K-split partial sums (<= 2048 floats)
   const size_t soff = static_cast<size_t>(stream) * p.sstride;
   const int step = *p.step;
+  // (`p` lives in global memory and the block stores to global memory: every p.field the loops below touched
+  //  would be re-read after each store -- take what the loops need into registers once)
+  const float* const px = p.x + soff;
+  float* const pst_in = p.st_in + soff;
+  float* const pst_out = p.st_out + soff;
+  const int x_ld = p.x_ld;
+  float* rp[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rp[k] = p.st_blk[k] + soff + static_cast<size_t>(step & ((1 << k) - 1)) * F * (k + 1) * G;
   // ---- phase A: everything that is already known
   for (int q = tid; q < FC; q += nthreads) {
     const int f = q / C, c = q - f * C;
-    xs[q] = p.x[soff + f * p.x_ld + c];
-    pin[q] = p.st_in[soff + q];
+    xs[q] = px[f * x_ld + c];
+    pin[q] = pst_in[q];
   }
-  for (int q = tid; q < FG; q += nthreads) pout[q] = p.st_out[soff + q];
+  for (int q = tid; q < FG; q += nthreads) pout[q] = pst_out[q];
   {
     // small weights: one packed blob in exactly this LDS order (wgs | w1s | sm), float4 copies, all independent
     const int n4 = (126 * G + 6 * G * G + 24 * G) / 4;
@@ -222,14 +231,16 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
     for (int q = tid; q < n4; q += nthreads) reinterpret_cast<ddb_f4*>(wgs)[q] = src[q];
     // history rings of the six blocks as one flat index space (block k starts at FG * k(k-1)/2)
     for (int q = tid; q < 21 * FG; q += nthreads) {
-      int k = 1, base = 0;
-      while (q >= base + k * FG) { base += k * FG; ++k; }
-      const int d = 1 << (k - 1);
-      rings[q] = p.st_blk[k - 1][soff + static_cast<size_t>(step & (d - 1)) * F * k * G + (q - base)];
+      // block k starts at FG * k(k-1)/2: q < FG -> 1, < 3FG -> 2, < 6FG -> 3, < 10FG -> 4, < 15FG -> 5, else 6
+      const int u = q / FG;
+      const int k = u < 1 ? 1 : (u < 3 ? 2 : (u < 6 ? 3 : (u < 10 ? 4 : (u < 15 ? 5 : 6))));
+      const int base = FG * (k * (k - 1) / 2);
+      const float* r = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
+      rings[q] = r[q - base];
     }
   }
   __syncthreads();
-  for (int q = tid; q < FC; q += nthreads) p.st_in[soff + q] = xs[q];      // prev_in <- x
+  for (int q = tid; q < FC; q += nthreads) pst_in[q] = xs[q];      // prev_in <- x
   // ---- o_0 = PReLU(conv(2,3)([prev_in ; x]))
   {
     const ddb_f4 s = ddb_dense23(pin, xs, p.w_in, F, C, G, part, tid, nthreads);
@@ -266,7 +277,7 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
     }
     // ring slot <- in_k of this frame (every read of the old slot went through LDS)
     {
-      float* ring = p.st_blk[k - 1] + soff + static_cast<size_t>(step & (d - 1)) * F * kG;
+      float* ring = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
       for (int q = tid; q < F * kG; q += nthreads) {
         const int f = q / kG, ch = q - f * kG;
         const int m = ch / G;
@@ -300,7 +311,7 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
       for (int j = 0; j < 4; ++j) r[j] = ddb_prelu(s[j] + p.b_out[4 * cq + j], p.a_out);
       *reinterpret_cast<ddb_f4*>(p.dst + soff + f * p.dst_ld + 4 * cq) = r;
     }
-    for (int q = tid; q < FG; q += nthreads) p.st_out[soff + q] = o[6 * FG + q];
+    for (int q = tid; q < FG; q += nthreads) pst_out[q] = o[6 * FG + q];
   }
   __syncthreads();
 }
