@@ -167,22 +167,33 @@ __device__ __forceinline__ ddb_f4 ddb_dense23(const float* X0, const float* X1, 
                                               int tid, int nthreads) {
   const int nq = F * CO / 4;                    // float4 outputs
   int nks = nthreads / nq;
-  const int entries = 6 * CI;                   // (t, kw, ci)
+  const int entries = 6 * CI;                   // (t, kw, ci); CI is a power of two
   while (entries % nks) nks >>= 1;              // whole entries per slice (entries = 3 * 2^n, nks a power of two)
-  const int epk = entries / nks;
+  const int epk = entries / nks;                // <= 24
   const int q = tid % nq, ks = tid / nq;
   const int f = q / (CO / 4), cq = q - f * (CO / 4);
+  int lci = 0;
+  while ((1 << lci) < CI) ++lci;
   ddb_f4 a = {0.f, 0.f, 0.f, 0.f};
   if (ks < nks) {
-    for (int e = ks * epk; e < (ks + 1) * epk; ++e) {
-      const int t = e / (3 * CI), r = e - t * 3 * CI;
-      const int kw = r / CI, ci = r - kw * CI;
-      const int fr = f + kw - 1;
-      if (fr < 0 || fr >= F) continue;
-      const ddb_f4 w = *reinterpret_cast<const ddb_f4 __attribute__((address_space(1)))*>(
-          (unsigned long long)(W + static_cast<size_t>(e) * CO + 4 * cq));
-      a += w * (t ? X1 : X0)[fr * CI + ci];
+    // all weight loads of the slice first (independent, one L2 latency), then the products
+    ddb_f4 w[24];
+    float xv[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+      if (j < epk) {
+        const int e = ks * epk + j;
+        const int t = e >= 3 * CI ? 1 : 0, r = e - t * 3 * CI;
+        const int kw = r >> lci, ci = r & (CI - 1);
+        const int fr = f + kw - 1;
+        const bool ok = fr >= 0 && fr < F;
+        w[j] = *reinterpret_cast<const ddb_f4 __attribute__((address_space(1)))*>((unsigned long long)(W + static_cast<size_t>(e) * CO + 4 * cq));
+        xv[j] = ok ? (t ? X1 : X0)[fr * CI + ci] : 0.f;
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 24; ++j)
+      if (j < epk) a += w[j] * xv[j];
     *reinterpret_cast<ddb_f4*>(part + (static_cast<size_t>(ks) * nq + q) * 4) = a;
   }
   __syncthreads();

@@ -918,7 +918,9 @@ __device__ __forceinline__ void out_conv_op(const OpWords& o, const StepArgs& a,
 
 // PROF = true: the profiling build of the same kernel (wall-clock stamps at op / phase boundaries of
 // workgroup 0); the production build carries none of the stamp code.
-template <bool PROF>
+// DDB = true: the baseline variant's kernel (dilated-dense bottlenecks, no LSTM code); the two model variants never
+// share a plan, and each build stays small enough for the instruction cache.
+template <bool PROF, bool DDB>
 __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* lds_in = lds;
@@ -959,7 +961,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
         // the next conv layer's first weights / epilogue parameters: requested before the op's own loads, so that
         // they have arrived when the op ends (requested after it, the next layer would start with an L2 round trip)
         if (nconv) prefetch_conv(nxt, wb, wave, tid, cy);
-        if (op == DEV_OP_LSTM) {
+        if (!DDB && op == DEV_OP_LSTM) {
           LstmParams p;
           decode_lstm(cur, a, p);
           lstm_layer(p, stream, sb, lds_out, lds_in, tid, nc_hand, nc_coff, nxt);
@@ -969,7 +971,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
           ctfa_layer<PROF>(p, stream, sb, lds_out, lds_in, tid, nc_hand, nc_coff, nxt, dbg);
         } else if (op == DEV_OP_INLAYER) {
           input_layer_op(cur, a, stream, lds_in, tid, nc_hand, nxt);
-        } else if (op == DEV_OP_DDB) {
+        } else if (DDB && op == DEV_OP_DDB) {
           ddb_block_wg(a.ddb[cur.w[0]], stream, lds_out, tid, MK_THREADS);
         } else {
           out_conv_op(cur, a, stream, tid);
@@ -983,17 +985,22 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
 
 hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s) {
   static bool attr_set = false;
+  const void* fns[4] = {reinterpret_cast<const void*>(nutls_stream_step_kernel<false, false>),
+                        reinterpret_cast<const void*>(nutls_stream_step_kernel<true, false>),
+                        reinterpret_cast<const void*>(nutls_stream_step_kernel<false, true>),
+                        reinterpret_cast<const void*>(nutls_stream_step_kernel<true, true>)};
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nutls_stream_step_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MK_LDS_BYTES));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(nutls_stream_step_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MK_LDS_BYTES));
-    if (e != hipSuccess) return e;
+    for (const void* f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MK_LDS_BYTES));
+      if (e != hipSuccess) return e;
+    }
     attr_set = true;
   }
-  if (a.prof) hipLaunchKernelGGL(nutls_stream_step_kernel<true>, dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
-  else hipLaunchKernelGGL(nutls_stream_step_kernel<false>, dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
+  const bool prof = a.prof != nullptr, ddb = a.ddb != nullptr;
+  if (!prof && !ddb) hipLaunchKernelGGL((nutls_stream_step_kernel<false, false>), dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
+  else if (prof && !ddb) hipLaunchKernelGGL((nutls_stream_step_kernel<true, false>), dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
+  else if (!prof && ddb) hipLaunchKernelGGL((nutls_stream_step_kernel<false, true>), dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
+  else hipLaunchKernelGGL((nutls_stream_step_kernel<true, true>), dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
