@@ -165,15 +165,22 @@ __device__ __forceinline__ float ddb_row_sum(float s, int G) {
 //   by the first F*CO/4 threads (returned in `acc` for those threads, valid when tid < F*CO/4).
 __device__ __forceinline__ ddb_f4 ddb_dense23(const float* X0, const float* X1, const float* W, int F, int CI, int CO, float* part,
                                               int tid, int nthreads) {
-  const int nq = F * CO / 4;                    // float4 outputs
-  int nks = nthreads / nq;
+  const int nq = (F * CO) >> 2;                 // float4 outputs (a power of two)
   const int entries = 6 * CI;                   // (t, kw, ci); CI is a power of two
-  while (entries % nks) nks >>= 1;              // whole entries per slice (entries = 3 * 2^n, nks a power of two)
-  const int epk = entries / nks;                // <= 24
-  const int q = tid % nq, ks = tid / nq;
-  const int f = q / (CO / 4), cq = q - f * (CO / 4);
-  int lci = 0;
+  // (F, CI, CO are powers of two: no integer divisions anywhere in this block -- a division by a run-time value
+  //  is ~40 instructions)
+  int lci = 0, lnq = 0, lcq = 0, lth = 0;
   while ((1 << lci) < CI) ++lci;
+  while ((1 << lnq) < nq) ++lnq;
+  while ((4 << lcq) < CO) ++lcq;
+  while ((2 << lth) <= nthreads) ++lth;         // floor(log2(nthreads))
+  // K slices: a power of two that divides 6*CI = 3 * 2^(lci+1), i.e. at most 2*CI, and fits the workgroup
+  int lks = lth - lnq;
+  if (lks > lci + 1) lks = lci + 1;
+  const int nks = 1 << lks;
+  const int epk = entries >> lks;               // <= 24
+  const int q = tid & (nq - 1), ks = tid >> lnq;
+  const int f = q >> lcq, cq = q & ((CO >> 2) - 1);
   ddb_f4 a = {0.f, 0.f, 0.f, 0.f};
   if (ks < nks) {
     // all weight loads of the slice first (independent, one L2 latency), then the products
@@ -204,9 +211,14 @@ __device__ __forceinline__ ddb_f4 ddb_dense23(const float* X0, const float* X1, 
 }
 
 // lds: >= 17.5K floats.  All nthreads (a multiple of 64, >= 256) call.
-__device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, float* lds, int tid, int nthreads) {
+__device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, float* lds, int tid, int nthreads,
+                                             unsigned long long* dbg_lds = nullptr) {
+#define DDB_T(k) do { if (dbg_lds && (tid & 63) == 0) dbg_lds[(tid >> 6) * 16 + (k)] = clock64(); } while (0)
+  DDB_T(0);
   const int F = p.F, C = p.C, G = C >> 1;
   const int FG = F * G, FC = F * C;
+  int lg = 0;
+  while ((1 << lg) < G) ++lg;                // G = 16 or 32, C = 2G
   float* xs = lds;                    // [F][C]   current input
   float* pin = xs + FC;               // [F][C]   previous input
   float* o = pin + FC;                // [7][F][G] o_0 .. o_6
@@ -230,7 +242,7 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
   for (int k = 0; k < 6; ++k) rp[k] = p.st_blk[k] + soff + static_cast<size_t>(step & ((1 << k) - 1)) * F * (k + 1) * G;
   // ---- phase A: everything that is already known
   for (int q = tid; q < FC; q += nthreads) {
-    const int f = q / C, c = q - f * C;
+    const int f = q >> (lg + 1), c = q & (C - 1);
     xs[q] = px[f * x_ld + c];
     pin[q] = pst_in[q];
   }
@@ -243,25 +255,27 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
     // history rings of the six blocks as one flat index space (block k starts at FG * k(k-1)/2)
     for (int q = tid; q < 21 * FG; q += nthreads) {
       // block k starts at FG * k(k-1)/2: q < FG -> 1, < 3FG -> 2, < 6FG -> 3, < 10FG -> 4, < 15FG -> 5, else 6
-      const int u = q / FG;
-      const int k = u < 1 ? 1 : (u < 3 ? 2 : (u < 6 ? 3 : (u < 10 ? 4 : (u < 15 ? 5 : 6))));
+      const int k = q < FG ? 1 : (q < 3 * FG ? 2 : (q < 6 * FG ? 3 : (q < 10 * FG ? 4 : (q < 15 * FG ? 5 : 6))));
       const int base = FG * (k * (k - 1) / 2);
       const float* r = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
       rings[q] = r[q - base];
     }
   }
+  DDB_T(1);
   __syncthreads();
+  DDB_T(2);
   for (int q = tid; q < FC; q += nthreads) pst_in[q] = xs[q];      // prev_in <- x
   // ---- o_0 = PReLU(conv(2,3)([prev_in ; x]))
   {
     const ddb_f4 s = ddb_dense23(pin, xs, p.w_in, F, C, G, part, tid, nthreads);
     if (tid < FG / 4) {
-      const int cq = tid % (G / 4);
+      const int cq = tid & ((G >> 2) - 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[4 * tid + j] = ddb_prelu(s[j] + p.b_in[4 * cq + j], p.a_in);
     }
     __syncthreads();
   }
+  DDB_T(3);
   // ---- blocks 1..6 (sequential: dense connectivity)
   int roff = 0, woff = 0;
   for (int k = 1; k <= 6; ++k) {
@@ -270,15 +284,15 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
     const float* wgl = wgs + woff;
     const float* sml = sm + (k - 1) * 4 * G;
     if (tid < FG) {
-      const int f = tid / G, g = tid - f * G;
+      const int f = tid >> lg, g = tid & (G - 1);
       float a = sml[g];
       for (int kw = 0; kw < 3; ++kw) {
         const int fr = f + (kw - 1) * d;
         if (fr < 0 || fr >= F) continue;
         for (int j = 0; j < k; ++j) {
           const int ch = g * k + j;             // channel of in_k seen by filter g
-          const int m = ch / G;                 // in_k = [o_{k-1}, ..., o_0]: chunk m is o_{k-1-m}
-          const float cur = o[(k - 1 - m) * FG + fr * G + (ch - m * G)];
+          const int m = ch >> lg;               // in_k = [o_{k-1}, ..., o_0]: chunk m is o_{k-1-m}
+          const float cur = o[(k - 1 - m) * FG + fr * G + (ch & (G - 1))];
           const float old = ringl[fr * kG + ch];
           a = fmaf(wgl[(kw * k + j) * G + g], old, a);
           a = fmaf(wgl[(3 * k + kw * k + j) * G + g], cur, a);
@@ -290,14 +304,14 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
     {
       float* ring = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
       for (int q = tid; q < F * kG; q += nthreads) {
-        const int f = q / kG, ch = q - f * kG;
-        const int m = ch / G;
-        ring[q] = o[(k - 1 - m) * FG + f * G + (ch - m * G)];
+        const int f = (q >= kG) + (q >= 2 * kG) + (q >= 3 * kG), ch = q - f * kG;      // F <= 4
+        const int m = ch >> lg;
+        ring[q] = o[(k - 1 - m) * FG + f * G + (ch & (G - 1))];
       }
     }
     __syncthreads();
     if (tid < FG) {
-      const int f = tid / G, g = tid - f * G;
+      const int f = tid >> lg, g = tid & (G - 1);
       const float* w1l = w1s + (k - 1) * G * G;
       float z = sml[G + g];
       for (int gi = 0; gi < G; ++gi) z = fmaf(w1l[gi * G + g], yv[f * G + gi], z);     // [gin][gout]
@@ -312,11 +326,12 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
     roff += F * kG;
     woff += 6 * kG;
   }
+  DDB_T(4);
   // ---- out conv over [prev_out ; o_6], then prev_out <- o_6
   {
     const ddb_f4 s = ddb_dense23(pout, o + 6 * FG, p.w_out, F, G, C, part, tid, nthreads);
     if (tid < FC / 4) {
-      const int f = tid / (C / 4), cq = tid - f * (C / 4);
+      const int f = tid >> (lg - 1), cq = tid & ((C >> 2) - 1);
       ddb_f4 r;
 #pragma unroll
       for (int j = 0; j < 4; ++j) r[j] = ddb_prelu(s[j] + p.b_out[4 * cq + j], p.a_out);
@@ -324,7 +339,10 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
     }
     for (int q = tid; q < FG; q += nthreads) pst_out[q] = o[6 * FG + q];
   }
+  DDB_T(5);
   __syncthreads();
+  DDB_T(6);
+#undef DDB_T
 }
 
 }  // namespace nutls
