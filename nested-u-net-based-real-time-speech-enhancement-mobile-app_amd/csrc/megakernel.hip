@@ -656,6 +656,8 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, gcb_
   float* hn = z + 96;              // [32]
   const float* sb = p.x + static_cast<size_t>(stream) * p.sstride;         // stream slice of the input tensor
   const int n4 = tid % 21, sl = tid / 21;                                    // sl < 16 for tid < 336
+  // x_cols / dst_cols are 32 or 64: shifts, not run-time integer divisions (~40 instructions each, one per K element)
+  const int xshift = p.x_cols == 64 ? 6 : 5, dshift = p.dst_cols == 64 ? 6 : 5;
   const int kn = p.Din >> 4, k0 = sl * kn;                                   // kn in {2, 4, 8, 16}
   const bool mv = tid < 336;
   // ---- x . Wx: weights + inputs of this thread's K slice
@@ -667,7 +669,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, gcb_
       if (j < kn) {
         const int k = k0 + j;
         w4[j] = ld4(p.wxT, static_cast<unsigned>(k * 84 + 4 * n4));
-        const int f = k / p.x_cols, c = k - f * p.x_cols;
+        const int f = k >> xshift, c = k & (p.x_cols - 1);
         xv[j] = ld1(sb, static_cast<unsigned>(f * p.x_ld + c));
       }
   }
@@ -726,7 +728,7 @@ __device__ __forceinline__ void lstm_layer(const LstmParams& p, int stream, gcb_
     float a = bd;
 #pragma unroll
     for (int u = 0; u < 21; ++u) a = fmaf(wd[u], hn[u], a);
-    const int f = tid / p.dst_cols, c = tid - f * p.dst_cols;
+    const int f = tid >> dshift, c = tid & (p.dst_cols - 1);
     st1(p.dst + static_cast<size_t>(stream) * p.sstride, static_cast<unsigned>(f * p.dst_ld + c), a);
     if (hand) img_put1(nx, lds_in, f, fwd_coff + c, a);
   }
