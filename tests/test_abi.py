@@ -34,6 +34,12 @@ def test_bad_arguments_are_reported(lib):
     assert b"null" in lib.nutls_last_error()
     assert lib.nutls_create(b"x", 1, 7, 1, 0, ctypes.byref(h)) == -1      # unknown variant
     assert lib.nutls_state_count(None) == -1
+    # the widened entry points (STFT front end, offline mode) validate before touching the device
+    assert lib.nutls_create_offline(b"x", 1, 0, 0, ctypes.byref(h)) == -1       # max_frames < 1
+    assert b"max_frames" in lib.nutls_last_error()
+    assert lib.nutls_process_block_host(None, None, None, 1) == -1
+    assert lib.nutls_enhance_hop_host(None, None, None, 0) == -1
+    assert lib.nutls_stft_hop(None, None, None) == -1
 
 
 def test_no_cpu_fallback(lib):
@@ -42,6 +48,8 @@ def test_no_cpu_fallback(lib):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
         nunet_amd.NutlsEngine(batch=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
+        nunet_amd.NutlsOffline(max_frames=8)
 
 
 def test_product_path_does_not_import_oracle():
