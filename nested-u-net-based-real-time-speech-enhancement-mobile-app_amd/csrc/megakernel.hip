@@ -882,13 +882,9 @@ __device__ __forceinline__ void input_layer_op(const OpWords& o, const StepArgs&
   for (int pos = tid >> 4; pos < NUTLS_DEV_BINS; pos += MK_THREADS / 16) {
     const float x = GF(p.x)[static_cast<size_t>(stream) * NUTLS_DEV_BINS + pos];
     f32x4 y = w * x + bb;
-    float s = y[0] + y[1] + y[2] + y[3];
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    const float s = group_sum<16>(y[0] + y[1] + y[2] + y[3]);           // DPP lane exchanges (16 lanes = one position)
     y -= s * (1.0f / 64.0f);
-    float q = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+    const float q = group_sum<16>(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
     const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / 64.0f) + MK_LN_EPS);
     f32x4 o4;
 #pragma unroll
@@ -910,9 +906,7 @@ __device__ __forceinline__ void out_conv_op(const OpWords& o, const StepArgs& a,
   const f32x4 w = *G4(p.w + 4 * c4);
   for (int pos = tid >> 4; pos < NUTLS_DEV_BINS; pos += MK_THREADS / 16) {
     const f32x4 xv = *G4(p.x + static_cast<size_t>(stream) * p.sstride + static_cast<size_t>(pos) * p.x_ld + 4 * c4);
-    float s = xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    const float s = group_sum<16>(xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3]);
     if (c4 == 0) GFW(p.y)[static_cast<size_t>(stream) * NUTLS_DEV_BINS + pos] = s + p.bias;
   }
   __syncthreads();
