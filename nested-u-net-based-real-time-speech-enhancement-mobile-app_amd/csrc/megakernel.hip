@@ -338,17 +338,19 @@ __device__ __forceinline__ void chunk_mfma32(f32x16& acc0, f32x16& acc1, bool tw
                                              int lbA1, int lbB1) {
   f32x4 b[4];
   b[0] = lds4(lds_in, lbA0); b[1] = lds4(lds_in, lbA0 + 32); b[2] = lds4(lds_in, lbB0); b[3] = lds4(lds_in, lbB0 + 32);
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], b[u][j], acc0, 0, 0, 0);
+  f32x4 d[4] = {b[0], b[1], b[2], b[3]};
   if (two) {
-    f32x4 d[4];
     d[0] = lds4(lds_in, lbA1); d[1] = lds4(lds_in, lbA1 + 32); d[2] = lds4(lds_in, lbB1); d[3] = lds4(lds_in, lbB1 + 32);
+  }
+  // the second tile's MFMAs are interleaved with the first tile's (two independent accumulator chains keep the
+  // pipe full from one wave), each behind its own wave-uniform branch: acc0 keeps a single update site
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], d[u][j], acc1, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], b[u][j], acc0, 0, 0, 0);
+      if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], d[u][j], acc1, 0, 0, 0);
+    }
   }
 }
 __device__ __forceinline__ void chunk_mfma16(f32x4& acc, const f32x4 (&w)[4], float* lds_in, int lbA, int lbB) {
