@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from nunet_amd import stream_enhance as SE
 from oracle.nutls_ref import NutlsRef
@@ -42,3 +43,23 @@ def test_config1_clip_snr_with_oracle_runner():
     assert abs(SE.snr_db(clean[:n], enh[:n]) - 11.63) < 0.05
     assert abs(SE.si_snr_db(clean[:n], enh[:n]) - 13.28) < 0.05
     assert float(np.max(np.abs(enh[:n] - clip["enhanced"][:n]))) < 1e-5
+
+
+def test_device_loop_validates_its_arguments_without_a_gpu():
+    """enhance_batch_on_device is host plumbing around engine.enhance_hop: shape checks and the output alignment
+    can be exercised with a stand-in engine (identity on every hop)."""
+    class Identity:
+        batch = 2
+
+        def enhance_hop(self, hop, dc_mode="edge"):
+            assert hop.shape == (2, SE.FRAME_STEP) and hop.dtype == np.float32 and hop.flags["C_CONTIGUOUS"]
+            return hop
+
+    audio = np.arange(2 * 1280, dtype=np.float32).reshape(2, 1280)
+    out = SE.enhance_batch_on_device(audio, Identity())
+    assert out.shape == (2, 1280)
+    # 4 hops are processed ((1280 - 256) // 256); the first 256 output samples are dropped like the reference does
+    np.testing.assert_array_equal(out[:, :768], audio[:, 256:1024])
+    assert not out[:, 768:].any()
+    with pytest.raises(ValueError):
+        SE.enhance_batch_on_device(audio[:1], Identity())
