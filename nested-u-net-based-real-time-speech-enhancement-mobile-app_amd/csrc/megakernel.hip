@@ -539,7 +539,9 @@ __device__ __forceinline__ void conv_layer(const OpWords& o_in, OpWords& n, cpla
 #pragma unroll
         for (int u = 0; u < 4; ++u) wn[u] = ldb(wb, nxt + u * wstep_b + lane16);
       }
-      if (rem == 0 && (!last || hand)) {
+      // (rounds before the last: with the round's FIRST chunk, so that the rows have a whole round to arrive;
+      //  the last round: with the last chunk, behind every weight load of the layer)
+      if (last ? (rem == 0 && hand) : rem + nfr == gpk) {
         ImgSrc is;
         is.src0 = last ? o.w[22] : o.w[0]; is.dtap = last ? o.w[17] : o.w[1];
         is.ld = static_cast<unsigned>(last ? cv_hx_ld_b(o) : cv_src_ld_b(o));
