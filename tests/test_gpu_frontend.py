@@ -135,3 +135,22 @@ def test_dc_modes_and_bad_arguments(clip):
     with pytest.raises(ValueError):
         eng.enhance_hop(np.zeros((1, 256), np.float32), "mirror")
     eng.close()
+
+
+def test_quality_harness_on_a_directory_of_wav_pairs(clip, tmp_path):
+    """the directory harness (wav pairs in, SNR / SI-SNR out, whole loop on the GPU) reproduces the
+    golden clip's numbers; a second, shorter pair rides in the same batch."""
+    from scipy.io import wavfile
+    from nunet_amd.evaluate import evaluate_directory, find_pairs
+    wavfile.write(str(tmp_path / "40hc020i_0.wav"), 16000, clip["noisy_i16"])
+    wavfile.write(str(tmp_path / "40hc020i.wav"), 16000, clip["clean_i16"])
+    wavfile.write(str(tmp_path / "short_0.wav"), 16000, clip["noisy_i16"][:20000])
+    wavfile.write(str(tmp_path / "short.wav"), 16000, clip["clean_i16"][:20000])
+    wavfile.write(str(tmp_path / "orphan_0.wav"), 16000, clip["noisy_i16"][:4000])        # no clean partner: ignored
+    assert [p["name"] for p in find_pairs(str(tmp_path))] == ["40hc020i", "short"]
+    rows = {r["name"]: r for r in evaluate_directory(str(tmp_path), out_dir=str(tmp_path / "out"))}
+    full = rows["40hc020i"]
+    assert abs(full["snr_before"] - float(clip["snr_before"])) < 0.05 and abs(full["snr_after"] - float(clip["snr_after"])) < 0.05
+    assert abs(full["sisnr_after"] - float(clip["sisnr_after"])) < 0.05
+    assert rows["short"]["snr_after"] > rows["short"]["snr_before"] + 5.0
+    assert (tmp_path / "out" / "short_enhanced.wav").exists()
