@@ -105,11 +105,13 @@ int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_ou
 int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out);
 
 /* Execution mode of nutls_step:
- *   2 (default)  persistent kernel: ONE launch per frame, one 1024-thread workgroup per stream runs
- *                every layer of the step (layer boundary = workgroup barrier, not a kernel boundary);
+ *   3            fused kernel (LSTM variant): ONE launch per frame, one 512-thread workgroup per stream; every
+ *                op of the step is its own specialised instruction stream (static schedule, no plan decoding);
+ *   2            persistent kernel: ONE launch per frame, one 512-thread workgroup per stream interprets
+ *                the device-resident plan (layer boundary = workgroup barrier, not a kernel boundary);
  *   1            one kernel per layer, the ~160 launches captured in a hipGraph (one per state parity);
  *   0            one kernel per layer, plain launches.
- * All three compute the same function. */
+ * All of them compute the same function (tests/test_gpu_parity.py::test_execution_modes_agree). */
 int nutls_set_mode(nutls_handle* h, int mode);
 /* enable != 0: mode 1 (capture + replay); enable == 0: mode 0. */
 int nutls_use_graph(nutls_handle* h, int enable);
@@ -153,6 +155,12 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n);
 /* Persistent-mode twin of nutls_profile_step: runs one step in mode 2 with workgroup 0 stamping
  * wall_clock64() at every layer boundary; writes microseconds per layer to us[0..n). */
 int nutls_profile_persistent(nutls_handle* h, double* us, int n);
+
+/* Fused-mode twin: op count / names / algorithmic flops per stream of the static schedule, and one profiled
+ * step (workgroup 0 stamps every op boundary); microseconds per op to us[0..nutls_fused_num_ops()). */
+int nutls_fused_num_ops(void);
+int nutls_fused_op_info(int index, const char** name, double* flops);
+int nutls_profile_fused(nutls_handle* h, double* us, int n);
 
 const char* nutls_last_error(void);
 const char* nutls_version(void);

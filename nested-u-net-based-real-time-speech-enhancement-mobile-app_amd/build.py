@@ -2,8 +2,9 @@
 
     python -m nunet_amd.build        (or: from nunet_amd.build import build; build())
 
-hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with
-the working-tree snapshot.
+hipcc cross-compiles without a GPU.  Every source is compiled to its own object (in parallel; the fused
+kernel's 154 specialised ops take minutes, everything else seconds) and only re-compiled when it or a header
+changed; the objects and the .so are git-ignored, the .so travels to the GPU box with the working-tree snapshot.
 """
 from __future__ import annotations
 
@@ -11,39 +12,65 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnutls_hip.so")
-SOURCES = ["kernels.hip", "megakernel.hip", "stft.hip", "offline.hip", "weights.cpp", "engine.cpp"]
-HEADERS = ["nutls_internal.hpp", os.path.join("..", "..", "include", "nutls.h")]
+SOURCES = ["fused_step.hip", "fused_step_prof.hip", "kernels.hip", "megakernel.hip", "stft.hip", "offline.hip", "weights.cpp", "fused_host.cpp", "engine.cpp"]
+HEADERS = ["nutls_internal.hpp", "ddb_device.hpp", "fused_plan.hpp", "fused_plan_lstm.inc", os.path.join("..", "..", "include", "nutls.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
-
-
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
+def _hipcc() -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libnutls_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    return hipcc
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def _newest_header() -> float:
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+
+def _stale_sources(force: bool):
+    hdr = _newest_header()
+    out = []
+    for s in SOURCES:
+        o = _obj(s)
+        dep = max(os.path.getmtime(os.path.join(CSRC, s)), hdr)
+        if s == "fused_step_prof.hip":
+            dep = max(dep, os.path.getmtime(os.path.join(CSRC, "fused_step.hip")))
+        if force or not os.path.exists(o) or os.path.getmtime(o) < dep:
+            out.append(s)
+    return out
+
+
+def _run(cmd, verbose):
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libnutls_hip.so")
+        raise RuntimeError("hipcc failed: " + " ".join(cmd[-3:]))
     if verbose and (r.stdout or r.stderr):
         print(r.stdout + r.stderr)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    todo = _stale_sources(force)
+    if not todo and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(_obj(s)) for s in SOURCES):
+        return LIB
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(lambda s: _run([hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", _obj(s)], verbose), todo))
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in SOURCES], verbose)
     return LIB
 
 

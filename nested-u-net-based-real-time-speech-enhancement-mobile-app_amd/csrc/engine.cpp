@@ -127,7 +127,10 @@ struct Engine {
   std::vector<Launch> plan_off;   // plan[0] with 'previous frame' = one arena slot earlier
   float* zx = nullptr;   // [offline][84] LSTM input products of a block
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
-  int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel
+  int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel (plan interpreter),
+                         // 3 fused kernel (statically scheduled, LSTM variant only)
+  float* fz_blob = nullptr;              // weight blob of the fused kernel (plan order)
+  unsigned long long* fz_prof = nullptr; // op boundary stamps of workgroup 0 (profiling build)
   CompactOp* dplan[2] = {nullptr, nullptr};
   unsigned long long* dprof = nullptr;
   int n_cu = 256;
@@ -458,15 +461,21 @@ static int add_state(Engine* e, const std::string& prev, const std::string& cur,
   st.d1 = d1;
   const int idx = static_cast<int>(e->states.size());
   e->states.push_back(st);
-  if (ring_d > 0) {
-    slot_reserve(e, static_cast<size_t>(d0) * d1, &e->states[idx].buf[0]);   // single buffer, updated in place
-    e->states[idx].buf[1] = nullptr;                                        // aliased to buf[0] after arena_commit
-  } else {
-    for (int i = 0; i < 2; ++i) slot_reserve(e, static_cast<size_t>(d0) * d1, &e->states[idx].buf[i]);
-  }
+  e->states[idx].buf[0] = e->states[idx].buf[1] = nullptr;      // slots: allocate_states()
   e->state_index[prev] = idx;
   e->state_index[cur] = idx;
   return idx;
+}
+
+// Arena slots of the state tensors: all first buffers in signature order, then all second buffers in the same
+// order -- `cur` and `prev` of EVERY ping-pong tensor are the same constant apart (the fused kernel addresses
+// them as parity base + one offset, tools/gen_fused_plan.py mirrors this layout) -- then the in-place rings.
+static void allocate_states(Engine* e) {
+  for (int b = 0; b < 2; ++b)
+    for (StateTensor& st : e->states)
+      if (st.ring_d == 0) slot_reserve(e, st.per_stream(), &st.buf[b]);
+  for (StateTensor& st : e->states)
+    if (st.ring_d > 0) slot_reserve(e, st.per_stream(), &st.buf[0]);      // single buffer; buf[1] aliased after arena_commit
 }
 
 // State inventory in the order of the reference's signature (converter_proposed.py:27-186).
@@ -878,6 +887,42 @@ static int run_persistent(Engine* e, int par, hipStream_t s, bool prof) {
   return NUTLS_OK;
 }
 
+// ---- fused kernel (mode 3): weight blob in plan order + the check that the arena is laid out as the plan says ----
+static int fused_setup(Engine* e, const WeightMap& wm) {
+  const bool same_count = static_cast<int>(e->states.size()) == fused_num_states();
+  bool ok = same_count && e->sstride >= static_cast<size_t>(fused_arena_floats());
+  for (int i = 0; ok && i < fused_num_states(); ++i) {
+    const StateTensor& st = e->states[i];
+    ok = st.name_prev == fused_state_name(i) && st.buf[0] - e->arena == fused_state_off(i) && st.buf[1] - st.buf[0] == fused_parity_stride();
+  }
+  const float* scratch[10] = {e->t_inlayer, e->t_y, e->t_d, e->t_up, e->upcat[0], e->upcat[1], e->upcat[2], e->upcat[3], e->upcat[4], e->upcat[5]};
+  for (int i = 0; ok && i < fused_num_scratch() && i < 10; ++i) ok = scratch[i] - e->arena == fused_scratch_off(i);
+  if (!ok) return fail(NUTLS_ERR_ARG, "fused plan (tools/gen_fused_plan.py) does not match the engine's arena layout");
+  std::vector<float> blob;
+  std::string err;
+  if (!fused_pack_blob(wm, &blob, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, blob.size() * sizeof(float)));
+  e->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+  e->fz_blob = static_cast<float*>(p);
+  void* q = nullptr;
+  HIP_TRY(hipMalloc(&q, (fused_num_ops() + 1) * sizeof(unsigned long long)));
+  e->allocs.push_back(q);
+  HIP_TRY(hipMemset(q, 0, (fused_num_ops() + 1) * sizeof(unsigned long long)));
+  e->fz_prof = static_cast<unsigned long long*>(q);
+  HIP_TRY(fused_step_set_attributes());
+  return NUTLS_OK;
+}
+
+static int run_fused(Engine* e, int par, hipStream_t s, bool prof) {
+  if (!e->fz_blob) return fail(NUTLS_ERR_ARG, "fused mode is not available for this handle");
+  hipError_t err = launch_fused_step(e->arena, static_cast<long long>(e->sstride), e->fz_blob, e->io_in, e->io_out, e->B, par,
+                                     prof ? e->fz_prof : nullptr, e->B, s);
+  if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("fused step launch: ") + hipGetErrorString(err));
+  return NUTLS_OK;
+}
+
 static int capture_graphs(Engine* e) {
   for (int par = 0; par < 2; ++par) {
     if (e->gexec[par]) continue;
@@ -986,6 +1031,7 @@ static int create_common(const void* weights, size_t n_bytes, int variant, int b
   }
   e->states.reserve(320);   // slot_reserve keeps pointers into this vector: it must never reallocate (130 or 208 states)
   if ((rc = build_states(e))) return rc;
+  allocate_states(e);
   const size_t B = static_cast<size_t>(batch);
   if ((rc = dev_alloc(e, B * NUTLS_BINS, &e->io_in, true))) return rc;
   if ((rc = dev_alloc(e, B * NUTLS_BINS, &e->io_out, true))) return rc;
@@ -1003,6 +1049,14 @@ static int create_common(const void* weights, size_t n_bytes, int variant, int b
     return fail(NUTLS_ERR_ARG, std::string("plan: ") + ex.what());
   }
   if (rc) return rc;
+  if (variant == NUTLS_VARIANT_LSTM && offline_frames == 0) {
+    try {
+      rc = fused_setup(e, wm);
+    } catch (const std::exception& ex) {
+      return fail(NUTLS_ERR_WEIGHTS, std::string("fused plan weights: ") + ex.what());
+    }
+    if (rc) return rc;
+  }
   e->n_cu = prop.multiProcessorCount;
   e->debug["input_layer"] = {e->t_inlayer, 256 * 64};
   e->debug["msfe6_de.y"] = {e->t_y, 256 * 64};
@@ -1136,7 +1190,9 @@ int nutls_use_graph(nutls_handle* h, int enable) {
 }
 
 int nutls_set_mode(nutls_handle* h, int mode) {
-  if (!h || mode < 0 || mode > 2) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode must be 0, 1 or 2");
+  if (!h || mode < 0 || mode > 3) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode must be 0, 1, 2 or 3");
+  if (mode == 3 && !h->eng.fz_blob) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 3 (fused kernel) exists for streaming handles of the LSTM variant only");
+  if (h->eng.offline && mode != 0) return fail(NUTLS_ERR_ARG, "nutls_set_mode: offline handles run per-layer launches (mode 0)");
   if (mode == 1) return nutls_use_graph(h, 1);
   h->eng.mode = mode;
   return NUTLS_OK;
@@ -1150,7 +1206,10 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   const size_t bytes = static_cast<size_t>(e->B) * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
   const int par = e->next_parity;
-  if (e->mode == 2) {
+  if (e->mode == 3) {
+    int rc = run_fused(e, par, s, false);
+    if (rc) return rc;
+  } else if (e->mode == 2) {
     int rc = run_persistent(e, par, s, false);
     if (rc) return rc;
   } else if (e->mode == 1) {
@@ -1426,6 +1485,35 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (size_t i = 0; i < plan.size(); ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
   for (auto& x : ev) (void)hipEventDestroy(x);
+  e->next_parity = 1 - par;
+  e->steps += 1;
+  return NUTLS_OK;
+}
+
+int nutls_fused_num_ops(void) { return fused_num_ops(); }
+
+int nutls_fused_op_info(int index, const char** name, double* flops) {
+  if (index < 0 || index >= fused_num_ops()) return fail(NUTLS_ERR_ARG, "nutls_fused_op_info: bad index");
+  if (name) *name = fused_op_name(index);
+  if (flops) *flops = fused_op_flops(index);
+  return NUTLS_OK;
+}
+
+int nutls_profile_fused(nutls_handle* h, double* us, int n) {
+  if (!h || !us) return fail(NUTLS_ERR_ARG, "nutls_profile_fused: null pointer");
+  Engine* e = &h->eng;
+  if (n != fused_num_ops()) return fail(NUTLS_ERR_ARG, "nutls_profile_fused: n must equal nutls_fused_num_ops()");
+  HIP_TRY(hipSetDevice(e->device));
+  const int par = e->next_parity;
+  int rc = run_fused(e, par, e->stream, true);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<unsigned long long> t(n + 1);
+  HIP_TRY(hipMemcpy(t.data(), e->fz_prof, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device);
+  if (khz <= 0) khz = 100000;
+  for (int i = 0; i < n; ++i) us[i] = static_cast<double>(t[i + 1] - t[i]) * 1000.0 / khz;
   e->next_parity = 1 - par;
   e->steps += 1;
   return NUTLS_OK;

@@ -1,0 +1,170 @@
+// Host side of the fused frame-step kernel (fused_step.hip): packs the weight blob in the order of the static
+// plan (fused_plan_lstm.inc) and checks that the engine's arena layout is the one the plan addresses.
+#include <cstring>
+
+#include "nutls_internal.hpp"
+#include "fused_plan.hpp"
+
+namespace nutls {
+namespace fz {
+#include "fused_plan_lstm.inc"
+}  // namespace fz
+
+namespace {
+
+const HostTensor* get(const WeightMap& w, const std::string& k, std::string* err) {
+  auto it = w.find(k);
+  if (it == w.end()) {
+    if (err->empty()) *err = "weight tensor missing: " + k;
+    return nullptr;
+  }
+  return &it->second;
+}
+
+// Output-channel order of a conv op: the sub-pixel shuffle (proposed.py:227-251) is folded into it, so that
+// packed channel r * gc + c of position f IS out[2 f + r, c].
+std::vector<int> channel_perm(const fz::OpD& d) {
+  std::vector<int> p(d.N);
+  for (int n = 0; n < d.N; ++n) p[n] = n;
+  if (d.kind == fz::K_DL && d.N == 64)
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 32; ++c) p[r * 32 + c] = 2 * c + r;
+  if (d.kind == fz::K_DL && d.N == 128)
+    for (int r = 0; r < 2; ++r)
+      for (int c2 = 0; c2 < 64; ++c2) p[r * 64 + c2] = r * 64 + (c2 % 32) * 2 + c2 / 32;
+  return p;
+}
+
+}  // namespace
+
+int fused_blob_floats() { return fz::kBlobFloats; }
+int fused_num_ops() { return fz::kNumOps; }
+const char* fused_op_name(int i) { return (i >= 0 && i < fz::kNumOps) ? fz::kOpNames[i] : "?"; }
+double fused_op_flops(int i) { return (i >= 0 && i < fz::kNumOps) ? fz::kOpFlops[i] : 0.0; }
+int fused_parity_stride() { return fz::kParityStride; }
+int fused_arena_floats() { return fz::kArenaFloats; }
+int fused_num_states() { return fz::kNumStateOffs; }
+const char* fused_state_name(int i) { return fz::kStateOffs[i].name; }
+int fused_state_off(int i) { return fz::kStateOffs[i].off; }
+int fused_num_scratch() { return static_cast<int>(sizeof(fz::kScratchOffs) / sizeof(fz::kScratchOffs[0])); }
+const char* fused_scratch_name(int i) { return fz::kScratchOffs[i].name; }
+int fused_scratch_off(int i) { return fz::kScratchOffs[i].off; }
+
+// Weight blob of the fused kernel, in plan order.
+//   conv fragments (float index): for segment s (time tap t, frequency tap kw) for K group g for channel tile T for lane for j
+//       32x32x2 tiles: n' = 32 T + (lane & 31), c = 8 g + 4 (lane >> 5) + j
+//       16x16x4 tiles: n' = 16 T + (lane & 15), c = 16 g + 4 (lane >> 4) + j
+//       value = W[perm[n']][t][kw][c]                       (OHWI weights, converter_proposed.py Conv2D kernels)
+bool fused_pack_blob(const WeightMap& wm, std::vector<float>* out, std::string* err) {
+  out->assign(static_cast<size_t>(fz::kBlobFloats), 0.f);
+  err->clear();
+  for (int it = 0; it < fz::kNumBlobItems; ++it) {
+    const fz::BlobItem& bi = fz::kBlobItems[it];
+    const fz::OpD& d = fz::kOps[bi.op];
+    float* dst = out->data() + bi.off;
+    const std::string key = bi.key;
+    if (bi.what == 0) {
+      const HostTensor* w = get(wm, key + ".w", err);
+      if (!w) return false;
+      if (w->dims.size() != 4 || w->dims[0] != d.N || w->dims[3] != d.cin) { *err = "unexpected weight shape for " + key; return false; }
+      const int th = w->dims[1], kw = w->dims[2];
+      const std::vector<int> perm = channel_perm(d);
+      const bool r32 = d.path == fz::P_R32;
+      const int G = d.cin / (r32 ? 8 : 16), TN = d.N / (r32 ? 32 : 16);
+      size_t o = 0;
+      for (int s = 0; s < d.nseg; ++s) {
+        const int t = fz::kSegTk[bi.op][s] >> 2, k = fz::kSegTk[bi.op][s] & 3;
+        if (t >= th || k >= kw) { *err = "segment outside the kernel of " + key; return false; }
+        for (int g = 0; g < G; ++g)
+          for (int T = 0; T < TN; ++T)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 4; ++j) {
+                const int np = r32 ? 32 * T + (lane & 31) : 16 * T + (lane & 15);
+                const int c = r32 ? 8 * g + 4 * (lane >> 5) + j : 16 * g + 4 * (lane >> 4) + j;
+                dst[o++] = w->data[((static_cast<size_t>(perm[np]) * th + t) * kw + k) * d.cin + c];
+              }
+      }
+      if (static_cast<int>(o) != bi.floats) { *err = "fragment count mismatch for " + key; return false; }
+    } else if (bi.what == 1) {
+      const HostTensor* b = get(wm, key + ".b", err);
+      if (!b) return false;
+      if (static_cast<int>(b->size()) != d.N) { *err = "unexpected bias size for " + key; return false; }
+      const std::vector<int> perm = channel_perm(d);
+      const int reps = d.kind == fz::K_UP ? 2 : 1;         // the up-sampling bias applies to even and odd output rows
+      for (int r = 0; r < reps; ++r)
+        for (int n = 0; n < d.N; ++n) dst[r * d.N + n] = b->data[perm[n]];
+      if (d.ln) {
+        const HostTensor* g = get(wm, key + ".gamma", err);
+        const HostTensor* bt = get(wm, key + ".beta", err);
+        const HostTensor* al = get(wm, key + ".alpha", err);
+        if (!g || !bt || !al) return false;
+        if (static_cast<int>(g->size()) != d.gc || static_cast<int>(bt->size()) != d.gc || al->size() < 1) { *err = "unexpected LayerNorm / PReLU size for " + key; return false; }
+        const int nt = reps * d.N;
+        std::memcpy(dst + nt, g->data.data(), d.gc * sizeof(float));
+        std::memcpy(dst + nt + d.gc, bt->data.data(), d.gc * sizeof(float));
+        dst[nt + 2 * d.gc] = al->data[0];
+      }
+    } else if (bi.what == 2) {
+      const std::string ln = key.empty() ? "lstm" : key + "_lstm", dn = key.empty() ? "dense" : key + "_dense";
+      const HostTensor* wx = get(wm, ln + ".wx", err);
+      const HostTensor* wh = get(wm, ln + ".wh", err);
+      const HostTensor* b = get(wm, ln + ".b", err);
+      const HostTensor* wd = get(wm, dn + ".w", err);
+      const HostTensor* bd = get(wm, dn + ".b", err);
+      if (!wx || !wh || !b || !wd || !bd) return false;
+      const int din = d.din, dout = d.dout;
+      if (wx->dims.size() != 2 || wx->dims[0] != 84 || wx->dims[1] != din || wh->size() != 84u * 21u || b->size() != 84u ||
+          wd->dims.size() != 2 || wd->dims[0] != dout || wd->dims[1] != 21 || static_cast<int>(bd->size()) != dout) {
+        *err = "unexpected LSTM / Dense shape for " + ln;
+        return false;
+      }
+      for (int k = 0; k < din; ++k)
+        for (int n = 0; n < 84; ++n) dst[k * 84 + n] = wx->data[static_cast<size_t>(n) * din + k];
+      for (int u = 0; u < 21; ++u)
+        for (int n = 0; n < 84; ++n) dst[(din + u) * 84 + n] = wh->data[static_cast<size_t>(n) * 21 + u];
+      for (int n = 0; n < 84; ++n) dst[(din + 21) * 84 + n] = b->data[n];
+      float* wdT = dst + (din + 22) * 84;
+      for (int u = 0; u < 21; ++u)
+        for (int n = 0; n < dout; ++n) wdT[u * dout + n] = wd->data[static_cast<size_t>(n) * 21 + u];
+      for (int n = 0; n < dout; ++n) wdT[21 * dout + n] = bd->data[n];
+    } else if (bi.what == 3) {
+      int o = 0;
+      for (const char* br : {"_ta", "_fa"}) {
+        const HostTensor* w1 = get(wm, key + br + ".w1", err);
+        const HostTensor* b1 = get(wm, key + br + ".b1", err);
+        const HostTensor* w2 = get(wm, key + br + ".w2", err);
+        const HostTensor* b2 = get(wm, key + br + ".b2", err);
+        if (!w1 || !b1 || !w2 || !b2) return false;
+        if (w1->size() != 16u * 64u || w2->size() != 64u * 16u || b1->size() != 16u || b2->size() != 64u) { *err = "unexpected CTFA shape " + key + br; return false; }
+        for (int c = 0; c < 64; ++c)
+          for (int u = 0; u < 16; ++u) dst[o + c * 16 + u] = w1->data[static_cast<size_t>(u) * 64 + c];     // w1T [64][16]
+        std::memcpy(dst + o + 1024, b1->data.data(), 16 * sizeof(float));
+        std::memcpy(dst + o + 1040, w2->data.data(), 1024 * sizeof(float));                                // w2 [64][16] as stored
+        std::memcpy(dst + o + 2064, b2->data.data(), 64 * sizeof(float));
+        o += 2128;
+      }
+      const HostTensor* ow = get(wm, "out_conv.w", err);
+      const HostTensor* ob = get(wm, "out_conv.b", err);
+      if (!ow || !ob) return false;
+      if (ow->size() != 64u || ob->size() < 1) { *err = "unexpected output conv shape"; return false; }
+      std::memcpy(dst + 4256, ow->data.data(), 64 * sizeof(float));
+      dst[4320] = ob->data[0];
+    } else {
+      const HostTensor* iw = get(wm, "input_layer.w", err);
+      const HostTensor* ib = get(wm, "input_layer.b", err);
+      const HostTensor* ig = get(wm, "input_layer.gamma", err);
+      const HostTensor* ibt = get(wm, "input_layer.beta", err);
+      const HostTensor* ia = get(wm, "input_layer.alpha", err);
+      if (!iw || !ib || !ig || !ibt || !ia) return false;
+      if (iw->size() != 64u || ib->size() != 64u || ig->size() != 64u || ibt->size() != 64u || ia->size() < 1) { *err = "unexpected input layer shape"; return false; }
+      std::memcpy(dst, iw->data.data(), 256);
+      std::memcpy(dst + 64, ib->data.data(), 256);
+      std::memcpy(dst + 128, ig->data.data(), 256);
+      std::memcpy(dst + 192, ibt->data.data(), 256);
+      dst[256] = ia->data[0];
+    }
+  }
+  return true;
+}
+
+}  // namespace nutls

@@ -1,0 +1,72 @@
+// Static schedule of the fused ("one specialised instruction stream per op") frame-step kernel.
+//
+// The NUNet-TLS-LSTM step has a fixed topology (reference: TFL_SIGNITURE.nutls_lstm,
+// dnn_model/converter_proposed.py:188-867): every shape, every LDS address and every offset into the
+// per-stream HBM arena / the weight blob is known before the kernel is compiled.  tools/gen_fused_plan.py
+// writes them down as one constexpr record per op (fused_plan_lstm.inc); fused_step.hip instantiates one
+// template per record, so the kernel carries no run-time plan decoding at all.
+#pragma once
+
+namespace nutls {
+namespace fz {
+
+enum OpType : int { T_INPUT = 0, T_CONV = 1, T_LSTM = 2, T_CTFA = 3 };
+enum CKind : int { K_IN = 0, K_EL = 1, K_DL = 2, K_DOWN = 3, K_UP = 4 };
+enum Path : int { P_R32 = 0, P_X16 = 1 };
+enum Src : int { S_PREV = 0, S_CUR = 1, S_SCRATCH = 2 };   // HBM base a float offset is relative to
+
+constexpr int LDS_BYTES = 160 * 1024;
+constexpr int SCR_BYTES = 8192;                      // LSTM / CTFA scratch at the top of LDS
+constexpr int SCR_B = LDS_BYTES - SCR_BYTES;
+constexpr int MAX_PARTS = 4, MAX_ZERO = 4, MAX_SEG = 6;
+constexpr int CARRY_FRAGS = 8;                       // weight fragments (float4 per lane) prefetched by the previous op: 32x32 tiles
+constexpr int CARRY_FRAGS_X16 = 12;                  // ... 16x16 tiles (small accumulators, short K loops)
+
+// A rectangular block of an HBM tensor that is copied into an LDS image through registers.
+struct Part {
+  int src, off, ld;      // HBM: base selector, float offset of (row 0, first channel), floats between rows
+  int rows, c4s;         // block size: rows x (c4s float4)
+  int lds_b;             // LDS byte address of image row 0 at the block's first channel
+  int row0;              // image row of block row 0
+  int la;                // 1: loads issued by the op that builds the image, 2: one op earlier
+  int round2;            // belongs to the second round of a two-round image
+};
+struct Zero { int lds_b, n4; };   // halo: n4 float4 of zeros
+
+// LDS image (B operand of the MFMAs) of a conv op: rows x channels per time tap, padded pitch.
+//   address(lr, c) = tap * tap_b + (pair ? (lr >> 1) * pitch_b + (lr & 1) * half_b : lr * pitch_b) + 4 c
+struct Img {
+  int taps, tap_b, pitch_b, pair, half_b, row0, bytes;
+  int nparts; Part parts[MAX_PARTS];
+  int nzero; Zero zero[MAX_ZERO];
+};
+
+// Where an op's output rows go inside the LDS image of the op that consumes them next.
+struct Fwd { int on, base_b, pitch_b, pair, half_b, row0; };
+
+struct OpD {
+  int type;
+  // ---- conv ------------------------------------------------------------------------------------
+  int kind, P, cin, N, taps, kf, stride;   // P output positions, N conv channels (UP: per output-row parity)
+  int path, PT, NT, PG, CG, KSt, KSg;      // tiling: PT x NT tiles per wave, PG x CG x (KSt x KSg) wave tasks
+  int ln, R, gc;                           // LayerNorm+PReLU?, output rows per position, channels per output row
+  int rounds;                              // 2: the two time taps use the same LDS region one after the other
+  int nseg, seg_b[MAX_SEG];                // (tap, frequency tap) segments of K: byte offset of each inside the image
+  int ex_b;                                // exchange buffer (X16 path)
+  int w_off, p_off;                        // weight blob (floats): MFMA fragments; bias | gamma | beta | alpha
+  int d0_on, d0_src, d0_off, d0_ld, d1_on, d1_src, d1_off, d1_ld;   // HBM destinations (row 0, first channel)
+  int row_mul, row_add;                    // output row of position p, sub-row r:  p * row_mul + row_add + r
+  Fwd fwd;
+  Img img;                                 // geometry of this op's own image + how it is staged
+  int nxt;                                 // op whose image this op completes (forward + staging), -1: none
+  // ---- lstm ------------------------------------------------------------------------------------
+  int din, dout, x_b, x_pitch_b, x_cols, y_b, h_off, c_off, ldst_on, ldst_off, ldst_ld;
+  int lw_off;                              // wxT | whT | bias | wdT | bd
+  // ---- ctfa ------------------------------------------------------------------------------------
+  int F, e0_off, e0_ld, last, cw_off;      // operates in place on fwd-described rows; cw: ta(w1T,b1,w2,b2) | fa(...)
+  // ---- all -------------------------------------------------------------------------------------
+  int drain;                               // every wave drains its memory counter before the op's last barrier
+};
+
+}  // namespace fz
+}  // namespace nutls

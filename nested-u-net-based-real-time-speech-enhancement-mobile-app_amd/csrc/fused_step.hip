@@ -1,0 +1,816 @@
+// Fused frame-step kernel: the whole NUNet-TLS-LSTM step of one stream as ONE specialised instruction
+// stream per op.  One 512-thread workgroup (8 waves) owns a stream (streams are independent);
+// the 154 ops of the step (fused_plan_lstm.inc, written by tools/gen_fused_plan.py) are instantiated one
+// after the other from templates, so every shape, LDS address, arena offset and weight offset is an
+// immediate -- there is no plan to decode at run time.  Straight-line code of this size costs nothing on
+// gfx950 (tools/ubench/icache.hip: 256 KB unrolled = 5.1 ticks / instruction vs 4.7 in a loop).
+//
+// Reference semantics: TFL_SIGNITURE.nutls_lstm, dnn_model/converter_proposed.py:188-867; blocks
+// dnn_model/models/proposed.py:162-282.
+//
+// Data flow of a conv op I (inconv / strided conv / sub-pixel conv / down / up, proposed.py:198-265):
+//   * its B operand is an LDS image [time tap][row][channel] with zero halo rows; the op BEFORE it completes
+//     that image: the rows it produces go there straight from registers, everything else (previous-frame
+//     tap = the other parity of the state tensor in HBM, skip-connection channels) is loaded from HBM into
+//     registers one or two ops ahead and stored into the image between the two barriers of the op before;
+//   * its A operand (weights, MFMA fragment order, one blob in plan order) streams from L2 through a
+//     12-fragment register ring whose first fill is issued by the previous op;
+//   * large layers: 32x32x2 fp32 MFMA tiles, each wave owns whole LayerNorm groups, epilogue in registers;
+//     small layers (<= 64 positions): 16x16x4 tiles, K split over the waves, partial tiles meet in an LDS
+//     exchange buffer and a row-wise epilogue finishes them (LayerNorm over channels with DPP exchanges);
+//   * the epilogue writes the state tensor (HBM, `cur` parity) and the next image (LDS).
+// Barriers order LDS only; the memory counter is never drained except at the plan's drain points (after
+// every LSTM and CTFA), which is what makes same-frame HBM hand-offs of skip connections safe.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "nutls_internal.hpp"
+#include "fused_plan.hpp"
+
+namespace nutls {
+namespace fz {
+
+#include "fused_plan_lstm.inc"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const char __attribute__((address_space(1))) * gcb_t;
+typedef char __attribute__((address_space(1))) * gb_t;
+typedef const f32x4 __attribute__((address_space(1))) * gc4_t;
+typedef f32x4 __attribute__((address_space(1))) * g4_t;
+typedef const float __attribute__((address_space(1))) * gcf_t;
+typedef float __attribute__((address_space(1))) * gf_t;
+
+constexpr int THREADS = 512;
+#define FZ_LN_EPS 1e-8f
+
+struct Ctx {
+  gcb_t sbp, sbc, sbs, wb;     // this stream's `prev` / `cur` state bases, arena slice base; weight blob
+  gcf_t io_in;                 // this stream's 256 input magnitudes
+  gf_t io_out;
+  unsigned long long* prof;
+};
+
+// ---- memory helpers (byte offsets) ---------------------------------------------------------------
+__device__ __forceinline__ f32x4 ldb(gcb_t base, unsigned boff) { return *(gc4_t)(base + static_cast<unsigned long long>(boff)); }
+__device__ __forceinline__ float ldb1(gcb_t base, unsigned boff) { return *(gcf_t)(base + static_cast<unsigned long long>(boff)); }
+__device__ __forceinline__ void stb(gcb_t base, unsigned boff, f32x4 v) { *(g4_t)((gb_t)(unsigned long long)base + static_cast<unsigned long long>(boff)) = v; }
+__device__ __forceinline__ void stb1(gcb_t base, unsigned boff, float v) { *(gf_t)((gb_t)(unsigned long long)base + static_cast<unsigned long long>(boff)) = v; }
+extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ f32x4& lds4(int boff) { return *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + boff); }
+__device__ __forceinline__ float& lds1(int boff) { return *reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + boff); }
+// workgroup barrier that orders LDS traffic only (global loads / stores stay in flight across it)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <class F, int... Is>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+#define FZ_LIKELY(x) __builtin_expect(!!(x), 1)
+// nothing is scheduled across this point: keeps asynchronous loads where they were written (the machine scheduler
+// otherwise sinks a load down to its first use to shorten the live range -- and the wave then waits for it on the spot)
+__device__ __forceinline__ void sched_pin() { __builtin_amdgcn_sched_barrier(0); }
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int clog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+constexpr int img_row_b(int pitch_b, int pair, int half_b, int lr) { return pair ? (lr >> 1) * pitch_b + (lr & 1) * half_b : lr * pitch_b; }
+__device__ __forceinline__ int img_row_rt(int pitch_b, int pair, int half_b, int lr) { return pair ? (lr >> 1) * pitch_b + (lr & 1) * half_b : lr * pitch_b; }
+
+// ---- DPP lane exchanges -----------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int LPG>
+__device__ __forceinline__ float group_sum(float s) {      // sum over LPG consecutive lanes (aligned), result in all of them
+  s += dpp_mov<0xB1>(s);                  // quad_perm [1,0,3,2]
+  s += dpp_mov<0x4E>(s);                  // quad_perm [2,3,0,1]
+  if (LPG >= 8) s += dpp_mov<0x141>(s);   // row_half_mirror
+  if (LPG >= 16) s += dpp_mov<0x140>(s);  // row_mirror
+  if (LPG >= 32) s += __shfl_xor(s, 16);
+  return s;
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// ---- static facts about an op ------------------------------------------------------------------------
+constexpr bool is_up(const OpD& d) { return d.kind == K_UP; }
+constexpr int ntot(const OpD& d) { return d.N * (is_up(d) ? 2 : 1); }
+constexpr int kgroups(const OpD& d) { return d.cin / (d.path == P_R32 ? 8 : 16); }            // K groups per segment
+constexpr int gw(const OpD& d) { return kgroups(d) / d.KSg; }                                     // ... per wave
+constexpr int segw(const OpD& d) { return is_up(d) ? 3 : d.nseg / d.KSt; }                       // segments per wave
+constexpr int tn(const OpD& d) { return d.N / (d.path == P_R32 ? 32 : 16); }                     // channel tiles per segment row of the blob
+constexpr int conv_nf(const OpD& d) { return segw(d) * gw(d) * d.NT; }                            // weight fragments per wave
+constexpr int ntask(const OpD& d) { return d.PG * d.CG * d.KSt * d.KSg; }
+constexpr int nparams(const OpD& d) { return ntot(d) + 2 * d.gc + 1; }
+// blob float offset of fragment f of a wave, relative to its wave base
+constexpr int frag_imm(const OpD& d, int f) {
+  const int nt = f % d.NT, sg = f / d.NT, s = sg / gw(d), g = sg % gw(d);
+  return ((s * kgroups(d) + g) * tn(d) + nt) * 256;
+}
+constexpr int part_cls(const Part& p) { return p.round2 ? 3 : p.la; }
+constexpr int part_n(const Part& p) { return (p.rows * p.c4s + THREADS - 1) / THREADS; }
+constexpr int parts_regs(const Img& g, int cls) {
+  int n = 0;
+  for (int k = 0; k < g.nparts; ++k) if (part_cls(g.parts[k]) == cls) n += part_n(g.parts[k]);
+  return n;
+}
+constexpr int part_base(const Img& g, int cls, int k) {
+  int n = 0;
+  for (int kk = 0; kk < k; ++kk) if (part_cls(g.parts[kk]) == cls) n += part_n(g.parts[kk]);
+  return n;
+}
+constexpr int nxt_of(int i) { return (i >= 0 && i < kNumOps) ? kOps[i].nxt : -1; }
+constexpr int nxt_regs(int i, int cls) { return nxt_of(i) >= 0 ? parts_regs(kOps[nxt_of(i)].img, cls) : 0; }
+constexpr int own_regs(int i, int cls) { return (i < kNumOps && kOps[i].type == T_CONV) ? parts_regs(kOps[i].img, cls) : 0; }
+constexpr int ctfa_ni(const OpD& d) { return (d.F + 31) / 32; }
+constexpr int carry_w(int i) {
+  if (i >= kNumOps) return 0;
+  const OpD& d = kOps[i];
+  if (d.type == T_CONV) return cmin(conv_nf(d), d.path == P_X16 ? CARRY_FRAGS_X16 : CARRY_FRAGS);
+  if (d.type == T_LSTM) return d.din / 16;
+  if (d.type == T_CTFA) return ctfa_ni(d);
+  return 0;
+}
+
+// What travels in registers from op I-1 to op I: the first weight fragments of op I (or the LSTM's input
+// weights / the CTFA's residual rows and gate matrices) and the far-ahead staged parts of the image op I completes.
+template <int I>
+struct Carry {
+  f32x4 w[cmax(1, carry_w(I))];
+  f32x4 p[cmax(1, nxt_regs(I, 2))];
+  f32x4 prm;                   // conv ops: this thread's float4 of the epilogue parameter block (bias | gamma | beta | alpha)
+};
+
+// ---- staging: HBM tensor blocks -> registers -> LDS image -------------------------------------------------
+template <int J, int CLS, int NR>
+__device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR]) {
+  if constexpr (J >= 0 && J < kNumOps) {
+    constexpr Img g = kOps[J].img;
+    sfor<g.nparts>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      constexpr Part p = g.parts[K];
+      if constexpr (part_cls(p) == CLS) {
+        constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K), cs = clog2(p.c4s);
+        const gcb_t src = p.src == S_PREV ? cx.sbp : (p.src == S_CUR ? cx.sbc : cx.sbs);
+        sfor<part_n(p)>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          int q = tid + THREADS * i;
+          if ((i + 1) * THREADS > items) q = q < items ? q : items - 1;      // lanes past the end re-load the last item
+          const int row = q >> cs, c4 = q & (p.c4s - 1);
+          r[base + i] = ldb(src, static_cast<unsigned>(p.off * 4 + row * (p.ld * 4) + c4 * 16));
+        });
+      }
+    });
+  }
+}
+template <int J, int CLS, int NR>
+__device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
+  if constexpr (J >= 0 && J < kNumOps) {
+    constexpr Img g = kOps[J].img;
+    sfor<g.nparts>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      constexpr Part p = g.parts[K];
+      if constexpr (part_cls(p) == CLS) {
+        constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K), cs = clog2(p.c4s);
+        sfor<part_n(p)>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          const int q = tid + THREADS * i;
+          const int row = q >> cs, c4 = q & (p.c4s - 1);
+          const int a = p.lds_b + img_row_rt(g.pitch_b, g.pair, g.half_b, p.row0 + row) + c4 * 16;
+          if ((i + 1) * THREADS <= items || FZ_LIKELY(q < items)) lds4(a) = r[base + i];
+        });
+      }
+    });
+  }
+}
+template <int J>
+__device__ __forceinline__ void zero_halos(int tid) {
+  if constexpr (J >= 0 && J < kNumOps) {
+    constexpr Img g = kOps[J].img;
+    float zf = 0.f;
+    asm volatile("" : "+v"(zf));
+    const f32x4 z = {zf, zf, zf, zf};
+    sfor<g.nzero>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      constexpr int t0 = K * 32;                    // (a halo row is at most 32 float4)
+      if (FZ_LIKELY(static_cast<unsigned>(tid - t0) < static_cast<unsigned>(g.zero[K].n4))) lds4(g.zero[K].lds_b + (tid - t0) * 16) = z;
+    });
+  }
+}
+
+// ---- wave task of a conv op -----------------------------------------------------------------------------------
+struct Task { int active, wbase_f, a, b, ks; };   // a/b: (pg, cg) on the R32 path, (ct, ks_t | ks_g) decoded by the caller on X16
+template <int I>
+__device__ __forceinline__ Task conv_task(int wave) {
+  constexpr OpD d = kOps[I];
+  Task t;
+  t.active = wave < ntask(d);
+  if constexpr (d.path == P_R32) {
+    t.a = wave & (d.PG - 1);           // position group
+    t.b = (wave >> clog2(d.PG)) & (d.CG - 1);   // channel group
+    t.ks = 0;
+    t.wbase_f = t.b * d.NT * 256;
+  } else {
+    const int ct = wave & (d.CG - 1), ks = (wave >> clog2(d.CG)) & (d.KSt * d.KSg - 1);
+    const int ks_g = ks & (d.KSg - 1), ks_t = ks >> clog2(d.KSg);
+    t.a = ct; t.b = ks_t * 256 + ks_g; t.ks = ks;
+    t.wbase_f = ((ks_t * segw(d) * kgroups(d) + ks_g * gw(d)) * tn(d) + ct) * 256;
+  }
+  return t;
+}
+
+// ---- prefetch of what op I needs first (issued by op I-1) ---------------------------------------------------------
+template <int I, int NW>
+__device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW], f32x4& prm) {
+  if constexpr (I < kNumOps) {
+    constexpr OpD d = kOps[I];
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (d.type == T_CONV) {
+      const Task t = conv_task<I>(wave);
+      if (t.active) {
+        // wave-uniform base (SGPR pair) + lane offset (VGPR) + immediate: no 64-bit vector address arithmetic
+        const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
+        sfor<carry_w(I)>([&](auto ff) {
+          constexpr int f = decltype(ff)::value;
+          w[f] = ldb(wbase + static_cast<unsigned long long>(frag_imm(d, f) * 4), static_cast<unsigned>(lane * 16));
+        });
+      }
+      if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>(tid * 16));
+    } else if constexpr (d.type == T_LSTM) {
+      constexpr int KN = d.din / 16;
+      if (tid < 336) {
+        const int n4 = tid % 21, sl = tid / 21;
+        sfor<KN>([&](auto jj) {
+          constexpr int j = decltype(jj)::value;
+          w[j] = ldb(cx.wb, static_cast<unsigned>((d.lw_off + (sl * KN + j) * 84 + 4 * n4) * 4));
+        });
+      }
+    } else if constexpr (d.type == T_CTFA) {
+      constexpr int NI = ctfa_ni(d);
+      const int c4 = tid & 15, rg = tid >> 4;
+      sfor<NI>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        int f = rg + 32 * i;
+        if (f > d.F - 1) f = d.F - 1;
+        w[i] = ldb(cx.sbc, static_cast<unsigned>((d.e0_off + f * d.e0_ld + 4 * c4) * 4));
+      });
+    }
+  }
+}
+
+// ---- completing the next image: staged parts + halos (between the two barriers of op I) --------------------------
+template <int I, int N1, int N2>
+__device__ __forceinline__ void build_next(int tid, const f32x4 (&p1)[N1], const f32x4 (&p2)[N2]) {
+  constexpr int J = nxt_of(I);
+  stage_store<J, 1>(tid, p1);
+  stage_store<J, 2>(tid, p2);
+  zero_halos<J>(tid);
+}
+
+// LDS address of (output row `row`, channel byte offset cb) inside the forward target of op d
+template <int I>
+__device__ __forceinline__ int fwd_addr(int row, int cb) {
+  constexpr Fwd f = kOps[I].fwd;
+  return f.base_b + img_row_rt(f.pitch_b, f.pair, f.half_b, f.row0 + row) + cb;
+}
+
+// ---- row-wise epilogue of the X16 path ----------------------------------------------------------------------------
+// LPG lanes per output row (float4 each): K-slice sum + bias, LayerNorm over the row's channels, PReLU, stores.
+template <int I>
+__device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
+  constexpr OpD d = kOps[I];
+  constexpr int GC = d.gc, LPG = GC / 4, R = d.R, NTOT = ntot(d), KS = d.KSt * d.KSg, OPB = (NTOT + 4) * 4;
+  constexpr int total = d.P * NTOT / 4, passes = (total + THREADS - 1) / THREADS;
+  const int li = tid & (LPG - 1);
+  const int u0 = tid >> clog2(LPG);
+  const int r = u0 & (R - 1);
+  const f32x4 bias = lds4(SCR_B + (r * GC + 4 * li) * 4);
+  f32x4 gm = bias, bt = bias;
+  float alpha = 0.f;
+  if constexpr (d.ln) {
+    gm = lds4(SCR_B + (NTOT + 4 * li) * 4);
+    bt = lds4(SCR_B + (NTOT + GC + 4 * li) * 4);
+    alpha = lds1(SCR_B + (NTOT + 2 * GC) * 4);
+  }
+  sfor<passes>([&](auto pp) {
+    constexpr int ps = decltype(pp)::value;
+    const int u = u0 + ps * (THREADS / LPG);
+    if ((ps + 1) * THREADS <= total || FZ_LIKELY(u * LPG < total)) {
+      const int pos = u >> clog2(R);
+      const int eb = d.ex_b + pos * OPB + (r * GC + 4 * li) * 4;
+      f32x4 v = bias;
+      sfor<KS>([&](auto kk) { v += lds4(eb + decltype(kk)::value * (d.P * OPB)); });
+      if constexpr (d.ln) {
+        const float mean = group_sum<LPG>(v[0] + v[1] + v[2] + v[3]) * (1.0f / GC);
+        v -= mean;
+        const float q = group_sum<LPG>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / GC) + FZ_LN_EPS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y = v[i] * rstd * gm[i] + bt[i];
+          v[i] = y >= 0.f ? y : alpha * y;
+        }
+      }
+      const int row = pos * d.row_mul + d.row_add + r;
+      if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4), v);
+      if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4), v);
+      if constexpr (d.fwd.on) lds4(fwd_addr<I>(row, 16 * li)) = v;
+    }
+  });
+}
+
+// ---- conv op, small layers: 16x16x4 tiles, K split over waves, LDS exchange -----------------------------------------
+template <int I, int N1, int N3>
+__device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
+  constexpr OpD d = kOps[I];
+  constexpr bool UP = is_up(d);
+  constexpr int PT = d.PT, GW = gw(d), NF = conv_nf(d), CW = carry_w(I), NTOT = ntot(d), OPB = (NTOT + 4) * 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Task t = conv_task<I>(wave);
+  const int ks_t = t.b >> 8, ks_g = t.b & 255;
+  const int j = lane & 15, h = lane >> 4;
+  int lane_b[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    int pos = 16 * pt + j;
+    if (pos > d.P - 1) pos = d.P - 1;
+    lane_b[pt] = pos * d.img.pitch_b + 16 * h + ks_t * d.img.tap_b + ks_g * (GW * 64);
+  }
+  f32x4 acc[PT], acco[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) { acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f}; acco[pt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
+  const unsigned lane16 = static_cast<unsigned>(lane * 16);
+  auto half = [&](auto lo_, auto hi_) {
+    constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
+    if (t.active) {
+      sfor<hi - lo>([&](auto ff) {
+        constexpr int f = lo + decltype(ff)::value;
+        constexpr int s = f / GW, g = f % GW;
+        const f32x4 a = c.w[f % CW];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const f32x4 b = lds4(lane_b[pt] + d.seg_b[s] + g * 64);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (UP && s == 2) acco[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acco[pt], 0, 0, 0);
+            else acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc[pt], 0, 0, 0);
+          }
+        }
+        if constexpr (f + CW < NF) {
+          c.w[f % CW] = ldb(wbase + static_cast<unsigned long long>(frag_imm(d, f + CW) * 4), lane16);
+          sched_pin();
+        }
+      });
+    }
+  };
+  if constexpr (d.rounds == 2) {
+    half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{});
+    lds_barrier();
+    stage_store<I, 3>(tid, p3);
+    lds_barrier();
+    half(std::integral_constant<int, NF / 2>{}, std::integral_constant<int, NF>{});
+  } else {
+    half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{});
+  }
+  if (t.active) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int pos = 16 * pt + j;
+      if (pos < d.P) {
+        const int eb = d.ex_b + (t.ks * d.P + pos) * OPB + (16 * t.a + 4 * h) * 4;
+        lds4(eb) = acc[pt];
+        if (UP) lds4(eb + d.N * 4) = acco[pt];
+      }
+    }
+  }
+  if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
+  lds_barrier();
+  x_epilogue<I>(cx, tid);
+  build_next<I>(tid, p1, c.p);
+}
+
+// ---- conv op, large layers: 32x32x2 tiles, whole LayerNorm groups per wave, epilogue in registers ----------------------
+__device__ __forceinline__ float xor32_sum(float s) { return s + __shfl_xor(s, 32); }
+
+template <int I, int N1, int N3>
+__device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
+  constexpr OpD d = kOps[I];
+  constexpr bool UP = is_up(d);
+  constexpr int PT = d.PT, NT = d.NT, G = kgroups(d), NF = conv_nf(d), CW = carry_w(I), NTOT = ntot(d);
+  constexpr int NA = UP ? 2 : NT;                    // accumulator tiles per position tile (UP: even row, odd row)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Task t = conv_task<I>(wave);
+  const int j = lane & 31, h = lane >> 5;
+  int lane_b[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) lane_b[pt] = (32 * (t.a * PT + pt) + j) * d.img.pitch_b + 16 * h;
+  f32x16 acc[PT][NA];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int n = 0; n < NA; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[pt][n][e] = 0.f;
+  const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
+  const unsigned lane16 = static_cast<unsigned>(lane * 16);
+  f32x4 b[PT];
+  auto half = [&](auto lo_, auto hi_) {
+    constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
+    if (t.active) {
+      sfor<hi - lo>([&](auto ff) {
+        constexpr int f = lo + decltype(ff)::value;
+        constexpr int nt = f % NT, sg = f / NT, s = sg / G, g = sg % G;
+        constexpr int na = UP ? (s == 2 ? 1 : 0) : nt;
+        if constexpr (nt == 0) {
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) b[pt] = lds4(lane_b[pt] + d.seg_b[s] + g * 32);
+        }
+        const f32x4 a = c.w[f % CW];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[pt][na] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[pt][q], acc[pt][na], 0, 0, 0);
+        if constexpr (f + CW < NF) {
+          c.w[f % CW] = ldb(wbase + static_cast<unsigned long long>(frag_imm(d, f + CW) * 4), lane16);
+          sched_pin();
+        }
+      });
+    }
+  };
+  if constexpr (d.rounds == 2) {
+    half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{});
+    lds_barrier();
+    stage_store<I, 3>(tid, p3);
+    lds_barrier();
+    half(std::integral_constant<int, NF / 2>{}, std::integral_constant<int, NF>{});
+  } else {
+    half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{});
+  }
+  if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
+  lds_barrier();                      // every wave is done with this op's image; parameters are in LDS
+  if (t.active) {
+    float alpha = 0.f;
+    if constexpr (d.ln) alpha = lds1(SCR_B + (NTOT + 2 * d.gc) * 4);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int pos = 32 * (t.a * PT + pt) + j;
+      // packed channel of accumulator element e of tile n: nb(n) + 8 (e >> 2) + 4 h + (e & 3)
+      if constexpr (d.ln) {
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+          const int nb = 32 * (t.b * NT + n);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bi = lds4(SCR_B + (nb + 8 * q + 4 * h) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[pt][n][4 * q + e] += bi[e]; s += acc[pt][n][4 * q + e]; }
+          }
+        }
+        const float mean = xor32_sum(s) * (1.0f / d.gc);
+        float qq = 0.f;
+#pragma unroll
+        for (int n = 0; n < NA; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { acc[pt][n][e] -= mean; qq += acc[pt][n][e] * acc[pt][n][e]; }
+        const float rstd = __builtin_amdgcn_rsqf(xor32_sum(qq) * (1.0f / d.gc) + FZ_LN_EPS);
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+          const int c0 = (32 * (t.b * NT + n)) & (d.gc - 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 gm = lds4(SCR_B + (NTOT + c0 + 8 * q + 4 * h) * 4);
+            const f32x4 bt = lds4(SCR_B + (NTOT + d.gc + c0 + 8 * q + 4 * h) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = acc[pt][n][4 * q + e] * rstd * gm[e] + bt[e];
+              acc[pt][n][4 * q + e] = y >= 0.f ? y : alpha * y;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NA; ++n) {
+          const int nb = UP ? (n * d.N + 32 * t.b) : 32 * (t.b * NT + n);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bi = lds4(SCR_B + (nb + 8 * q + 4 * h) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[pt][n][4 * q + e] += bi[e];
+          }
+        }
+      }
+      // stores: tile n covers channels c0 .. c0+31 of output row  pos * row_mul + row_add + r
+#pragma unroll
+      for (int n = 0; n < NA; ++n) {
+        const int nb = UP ? (n * d.N + 32 * t.b) : 32 * (t.b * NT + n);
+        const int r = nb / d.gc, c0 = nb & (d.gc - 1);
+        const int row = pos * d.row_mul + d.row_add + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
+          const int cc = c0 + 8 * q + 4 * h;
+          if constexpr (d.fwd.on) lds4(fwd_addr<I>(row, cc * 4)) = v;
+          if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4), v);
+          if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4), v);
+        }
+      }
+    }
+  }
+  build_next<I>(tid, p1, c.p);
+}
+
+// ---- input layer: 1 -> 64 conv + LN + PReLU (proposed.py:218-225), straight into the image of msfe6_en_in ---------------
+template <int I>
+__device__ __forceinline__ void input_op(const Ctx& cx, int tid) {
+  constexpr OpD d = kOps[I];
+  const int c4 = tid & 15;
+  const unsigned pb = static_cast<unsigned>(d.p_off * 4 + c4 * 16);
+  const f32x4 w = ldb(cx.wb, pb), bb = ldb(cx.wb, pb + 256), gm = ldb(cx.wb, pb + 512), bt = ldb(cx.wb, pb + 768);
+  const float alpha = ldb1(cx.wb, static_cast<unsigned>(d.p_off * 4 + 1024));
+  float x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = cx.io_in[(tid >> 4) + 32 * i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int pos = (tid >> 4) + 32 * i;
+    f32x4 y = w * x[i] + bb;
+    const float s = group_sum<16>(y[0] + y[1] + y[2] + y[3]);
+    y -= s * (1.0f / 64.0f);
+    const float q = group_sum<16>(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
+    const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / 64.0f) + FZ_LN_EPS);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = y[e] * rstd * gm[e] + bt[e];
+      o[e] = v >= 0.f ? v : alpha * v;
+    }
+    lds4(fwd_addr<I>(pos, 16 * c4)) = o;
+  }
+}
+
+// ---- LSTM cell + Dense (proposed.py:70-119; converter_proposed.py:234-237), in place on the next conv's image ------------
+template <int I>
+__device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
+  constexpr OpD d = kOps[I];
+  constexpr int KN = d.din / 16, XS = clog2(d.x_cols);
+  constexpr int PART = SCR_B, Z = SCR_B + 16 * 84 * 4, HN = Z + 96 * 4;
+  // recurrent product, bias, cell state, dense weights: requested now, used after the first barrier
+  float wh[21], hprev[21], wd[21];
+  float bias = 0.f, c_old = 0.f, bd = 0.f;
+  if (tid < 84) {
+#pragma unroll
+    for (int u = 0; u < 21; ++u) {
+      wh[u] = ldb1(cx.wb, static_cast<unsigned>((d.lw_off + (d.din + u) * 84 + tid) * 4));
+      hprev[u] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + u) * 4));
+    }
+    bias = ldb1(cx.wb, static_cast<unsigned>((d.lw_off + (d.din + 21) * 84 + tid) * 4));
+  }
+  if (tid < 21) c_old = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + tid) * 4));
+  if (tid < d.dout) {
+#pragma unroll
+    for (int u = 0; u < 21; ++u) wd[u] = ldb1(cx.wb, static_cast<unsigned>((d.lw_off + (d.din + 22) * 84 + u * d.dout + tid) * 4));
+    bd = ldb1(cx.wb, static_cast<unsigned>((d.lw_off + (d.din + 22) * 84 + 21 * d.dout + tid) * 4));
+  }
+  if (tid < 336) {
+    const int n4 = tid % 21, sl = tid / 21;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KN; ++j) {
+      const int k = sl * KN + j;
+      a += c.w[j] * lds1(d.x_b + (k >> XS) * d.x_pitch_b + (k & (d.x_cols - 1)) * 4);
+    }
+    lds4(PART + (sl * 84 + 4 * n4) * 4) = a;
+  }
+  lds_barrier();
+  if (tid < 84) {
+    float a = bias;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) a += lds1(PART + (s2 * 84 + tid) * 4);
+    float r = 0.f;
+#pragma unroll
+    for (int u = 0; u < 21; ++u) r = fmaf(wh[u], hprev[u], r);
+    lds1(Z + tid * 4) = a + r;
+  }
+  lds_barrier();
+  if (tid < 21) {
+    const float gi = fast_sigmoid(lds1(Z + tid * 4)), gf = fast_sigmoid(lds1(Z + (21 + tid) * 4));
+    const float gg = fast_tanh(lds1(Z + (42 + tid) * 4)), go = fast_sigmoid(lds1(Z + (63 + tid) * 4));
+    const float c_new = gf * c_old + gi * gg;
+    const float h_new = go * fast_tanh(c_new);
+    stb1(cx.sbc, static_cast<unsigned>((d.c_off + tid) * 4), c_new);
+    stb1(cx.sbc, static_cast<unsigned>((d.h_off + tid) * 4), h_new);
+    lds1(HN + tid * 4) = h_new;
+  }
+  lds_barrier();
+  if (tid < d.dout) {
+    float a = bd;
+#pragma unroll
+    for (int u = 0; u < 21; ++u) a = fmaf(wd[u], lds1(HN + u * 4), a);
+    const int f = tid >> XS, cc = tid & (d.x_cols - 1);
+    lds1(d.y_b + f * d.x_pitch_b + cc * 4) = a;
+    if constexpr (d.ldst_on) stb1(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4), a);
+  }
+}
+
+// 64 -> 16 (ReLU) -> 64 perceptron of the CTFA gates, evaluated by ONE wave without barriers (lane c = channel c)
+__device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1)[4], float b1_u, const f32x4 (&w2)[4], float b2, int scr_b, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) lds4(scr_b + (lane * 20 + 4 * q) * 4) = w1[q] * in;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int u = lane & 15, qtr = lane >> 4;
+  float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    h0 += lds1(scr_b + ((qtr * 16 + i) * 20 + u) * 4);
+    h1 += lds1(scr_b + ((qtr * 16 + i + 1) * 20 + u) * 4);
+  }
+  float hsum = h0 + h1;
+  hsum += __shfl_xor(hsum, 16);
+  hsum += __shfl_xor(hsum, 32);
+  const float hid = fmaxf(hsum + b1_u, 0.f);
+  float a0 = b2, a1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    a0 = fmaf(w2[k >> 2][k & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hid), k)), a0);
+    a1 = fmaf(w2[(k + 1) >> 2][(k + 1) & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hid), k + 1)), a1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return a0 + a1;
+}
+
+// ---- CTFA gate + residual (ctfa_rt, proposed.py:162-196), in place on the next image; the network's last
+//      one also applies the output 1x1 conv (proposed.py:65) and writes the enhanced magnitudes ---------------------------
+template <int I>
+__device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
+  constexpr OpD d = kOps[I];
+  constexpr int NI = ctfa_ni(d);
+  constexpr int PART = SCR_B, GATE = SCR_B + 512 * 4, MSCR = GATE + 64 * 4;
+  const int c4 = tid & 15, rg = tid >> 4, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float b1t = 0.f, b1f = 0.f, b2t = 0.f, b2f = 0.f;
+  f32x4 ow = {0.f, 0.f, 0.f, 0.f};
+  float ob = 0.f;
+  f32x4 w1t[4], w2t[4], w1f[4], w2f[4];       // gate perceptrons: lane c holds its 16 input / output weights of each matrix
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      w1t[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + lane * 16 + 4 * q) * 4));                  // ta w1T [64][16]
+      w2t[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 1040 + lane * 16 + 4 * q) * 4));           // ta w2  [64][16]
+      w1f[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + lane * 16 + 4 * q) * 4));           // fa w1T
+      w2f[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 3168 + lane * 16 + 4 * q) * 4));           // fa w2
+    }
+    b1t = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 1024 + (lane & 15)) * 4));
+    b2t = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2064 + lane) * 4));
+    b1f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 1024 + (lane & 15)) * 4));
+    b2f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 2064 + lane) * 4));
+  }
+  if constexpr (d.last) {
+    ow = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 4256 + 4 * c4) * 4));
+    ob = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 4320) * 4));
+  }
+  f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = rg + 32 * i;
+    if (f < d.F) s4 += lds4(fwd_addr<I>(f, 16 * c4));
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s4[e] += __shfl_xor(s4[e], 16);
+    s4[e] += __shfl_xor(s4[e], 32);
+  }
+  if (lane < 16) lds4(PART + (wave * 64 + 4 * c4) * 4) = s4;
+  lds_barrier();
+  if (wave == 0) {
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) m += lds1(PART + (r * 64 + lane) * 4);
+    m = m * (1.0f / d.F);
+    const float ta = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t, MSCR, lane));
+    const float fa = fast_sigmoid(gate_mlp(ta * (1.0f / 32.0f), w1f, b1f, w2f, b2f, MSCR, lane));
+    lds1(GATE + lane * 4) = fa * ta;
+  }
+  lds_barrier();
+  const f32x4 g4 = lds4(GATE + 16 * c4);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int f = rg + 32 * i;
+    if (f < d.F) {
+      const f32x4 y = lds4(fwd_addr<I>(f, 16 * c4)) * g4 + c.w[i];      // (re-read: cheaper than 32 registers held across the gates)
+      if constexpr (d.last) {
+        const float s = group_sum<16>(y[0] * ow[0] + y[1] * ow[1] + y[2] * ow[2] + y[3] * ow[3]);
+        if (c4 == 0) cx.io_out[f] = s + ob;
+      } else {
+        lds4(fwd_addr<I>(f, 16 * c4)) = y;
+      }
+    }
+  }
+}
+
+// ---- one op -----------------------------------------------------------------------------------------------------------
+template <int I, bool PROF>
+__device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
+  constexpr OpD d = kOps[I];
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));          // per-op thread id: nothing derived from it is hoisted across ops
+  if (PROF && cx.prof && tid == 0) cx.prof[I] = wall_clock64();
+  // loads in the order they are needed: parts this op stores itself, its epilogue parameters, what the next op needs first
+  f32x4 p1[cmax(1, nxt_regs(I, 1))];
+  f32x4 p3[cmax(1, own_regs(I, 3))];
+  stage_load<nxt_of(I), 1>(cx, tid, p1);
+  stage_load<I, 3>(cx, tid, p3);
+  prefetch_w<I + 1>(cx, tid, n.w, n.prm);
+  stage_load<nxt_of(I + 1), 2>(cx, tid, n.p);
+  sched_pin();
+
+  if constexpr (d.type == T_INPUT) {
+    input_op<I>(cx, tid);
+    build_next<I>(tid, p1, c.p);
+  } else if constexpr (d.type == T_CONV) {
+    if constexpr (d.path == P_X16) conv_x16<I>(cx, tid, c, p1, p3);
+    else conv_r32<I>(cx, tid, c, p1, p3);
+  } else if constexpr (d.type == T_LSTM) {
+    lstm_op<I>(cx, tid, c);
+  } else {
+    ctfa_op<I>(cx, tid, c);
+  }
+  if constexpr (d.drain) drain_vm();
+  lds_barrier();
+}
+
+template <int I, bool PROF>
+__device__ __forceinline__ void run_from(const Ctx& cx, Carry<I>& c) {
+  if constexpr (I < kNumOps) {
+    Carry<I + 1> n;
+    run_op<I, PROF>(cx, c, n);
+    run_from<I + 1, PROF>(cx, n);
+  }
+}
+
+struct FzArgs {
+  float* arena; long long sstride; const float* blob; const float* io_in; float* io_out; int B, par; unsigned long long* prof;
+};
+
+#ifndef FZ_PROF
+#define FZ_PROF 0
+#endif
+#if FZ_PROF
+#define FZ_KERNEL nutls_fused_step_prof_kernel
+#else
+#define FZ_KERNEL nutls_fused_step_kernel
+#endif
+__global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
+  constexpr bool PROF = FZ_PROF != 0;
+  for (int stream = blockIdx.x; stream < a.B; stream += gridDim.x) {
+    const float* slice = a.arena + static_cast<size_t>(stream) * a.sstride;
+    Ctx cx;
+    cx.sbs = (gcb_t)(unsigned long long)slice;
+    cx.sbc = (gcb_t)(unsigned long long)(slice + (a.par ? kParityStride : 0));
+    cx.sbp = (gcb_t)(unsigned long long)(slice + (a.par ? 0 : kParityStride));
+    cx.wb = (gcb_t)(unsigned long long)a.blob;
+    cx.io_in = (gcf_t)(unsigned long long)(a.io_in + static_cast<size_t>(stream) * 256);
+    cx.io_out = (gf_t)(unsigned long long)(a.io_out + static_cast<size_t>(stream) * 256);
+    cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
+    Carry<0> c0;
+    run_from<0, PROF>(cx, c0);
+    if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();
+  }
+}
+
+}  // namespace fz
+
+#if FZ_PROF
+hipError_t launch_fused_step_prof(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                                  unsigned long long* prof, int grid, hipStream_t s) {
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, prof};
+  hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+hipError_t fused_step_prof_set_attributes() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(fz::FZ_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+}
+#else
+hipError_t launch_fused_step_prof(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                                  unsigned long long* prof, int grid, hipStream_t s);
+hipError_t fused_step_prof_set_attributes();
+hipError_t launch_fused_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                             unsigned long long* prof, int grid, hipStream_t s) {
+  if (prof) return launch_fused_step_prof(arena, sstride, blob, io_in, io_out, B, par, prof, grid, s);
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr};
+  hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+hipError_t fused_step_set_attributes() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fz::FZ_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+  return e != hipSuccess ? e : fused_step_prof_set_attributes();
+}
+#endif
+
+}  // namespace nutls

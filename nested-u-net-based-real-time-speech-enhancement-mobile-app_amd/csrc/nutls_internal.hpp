@@ -240,4 +240,24 @@ std::vector<float> pack_conv_weights16(const HostTensor& w, const std::vector<in
 // Re-plans a layer with F_out <= 16 for 16x16x4 tiles (no-op otherwise).
 void apply_s16_plan(ConvPlan* c, const ConvParams& p);
 
+
+// ------------------------------------------------------------------ fused (statically scheduled) kernel ----
+// fused_step.hip / fused_host.cpp: the LSTM variant's frame step as one specialised instruction stream per op.
+hipError_t launch_fused_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                             unsigned long long* prof, int grid, hipStream_t s);
+hipError_t fused_step_set_attributes();
+bool fused_pack_blob(const WeightMap& wm, std::vector<float>* out, std::string* err);
+int fused_blob_floats();
+int fused_num_ops();
+const char* fused_op_name(int i);
+double fused_op_flops(int i);
+int fused_parity_stride();
+int fused_arena_floats();
+int fused_num_states();
+const char* fused_state_name(int i);
+int fused_state_off(int i);
+int fused_num_scratch();
+const char* fused_scratch_name(int i);
+int fused_scratch_off(int i);
+
 }  // namespace nutls

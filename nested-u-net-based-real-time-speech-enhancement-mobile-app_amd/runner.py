@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "nutls_version",
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
     "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
+    "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
 )
 
 
@@ -79,6 +80,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_create_offline.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
     lib.nutls_process_block.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_process_block_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
+    lib.nutls_fused_num_ops.argtypes = []
+    lib.nutls_fused_op_info.argtypes = [c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
+    lib.nutls_profile_fused.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:
@@ -106,7 +110,7 @@ def _fptr(a: np.ndarray):
 class NutlsEngine:
     """B streams, device-resident state.  ``step`` takes/returns ``[B,256]`` magnitudes."""
 
-    MODES = {"launches": 0, "graph": 1, "persistent": 2}
+    MODES = {"launches": 0, "graph": 1, "persistent": 2, "fused": 3}
     VARIANTS = {"lstm": 0, "baseline": 1}
 
     def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: str = "persistent", variant: str = "lstm"):
@@ -281,6 +285,22 @@ class NutlsEngine:
         (wall clock); returns microseconds per layer."""
         us = np.zeros(self.launches_per_step, np.float64)
         _check(self._lib, self._lib.nutls_profile_persistent(
+            self._h, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), us.size))
+        return us
+
+    def fused_plan(self) -> List[Dict[str, object]]:
+        """The fused kernel's static schedule: op name and algorithmic flops per stream."""
+        res = []
+        for i in range(self._lib.nutls_fused_num_ops()):
+            name, fl = ctypes.c_char_p(), ctypes.c_double()
+            _check(self._lib, self._lib.nutls_fused_op_info(i, ctypes.byref(name), ctypes.byref(fl)))
+            res.append({"layer": name.value.decode(), "flops": fl.value})
+        return res
+
+    def profile_fused(self) -> np.ndarray:
+        """One fused-mode step with workgroup 0 time-stamping every op boundary; microseconds per op."""
+        us = np.zeros(self._lib.nutls_fused_num_ops(), np.float64)
+        _check(self._lib, self._lib.nutls_profile_fused(
             self._h, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), us.size))
         return us
 

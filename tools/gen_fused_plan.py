@@ -1,0 +1,499 @@
+#!/usr/bin/env python3
+"""Static schedule of the fused frame-step kernel  ->  csrc/fused_plan_lstm.inc  (+ a JSON twin).
+
+The streaming NUNet-TLS-LSTM step (reference: TFL_SIGNITURE.nutls_lstm,
+/root/reference/dnn_model/converter_proposed.py:188-867; blocks models/proposed.py:162-282) has a fixed
+topology, so everything the kernel would otherwise decode per layer is decided here, once:
+
+  * the op list (154 ops: input layer, 12 MSFE stages, central LSTM; the two phases of an up-sampling
+    layer are one op, the output conv rides on the last CTFA);
+  * for every conv op its LDS image (the B operand of the MFMAs: rows x channels per time tap, padded
+    pitch), which part of that image the producing op forwards from registers, which parts are staged
+    from HBM (previous-frame tap, skip-connection channels) and how far ahead their loads are issued;
+  * the tiling of every conv op over the 8 waves of a workgroup (32x32x2 tiles with an in-register
+    epilogue for the large layers, 16x16x4 tiles + K split + LDS exchange for the small ones);
+  * every offset into the per-stream HBM arena (state tensors, parity-strided) and into the weight blob.
+
+Run:  python tools/gen_fused_plan.py            (rewrites the .inc and tests/golden/fused_plan_lstm.json)
+      python tools/gen_fused_plan.py --check    (exit 1 if the committed files are stale)
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "nested-u-net-based-real-time-speech-enhancement-mobile-app_amd")
+INC = os.path.join(PKG, "csrc", "fused_plan_lstm.inc")
+JSN = os.path.join(ROOT, "tests", "golden", "fused_plan_lstm.json")
+
+# (prefix, depth, f0, conv state tag, sub-pixel state tag, resample layer)   converter_proposed.py:221-727
+ENC = [("msfe6_en", 6, 256, "msfe6_ee", "msfe6_ed", "msfe6_down_sampling"),
+       ("msfe5_en", 5, 128, "msfe5_ee", "msfe5_ed", "msfe5_down_sampling"),
+       ("msfe4_en", 4, 64, "msfe4_ee", "msfe4_ed", "msfe4_down_sampling"),
+       ("msfe4_en2", 4, 32, "msfe4_ee2", "msfe4_ed2", "msfe4_down_sampling2"),
+       ("msfe4_en3", 4, 16, "msfe4_ee3", "msfe4_ed3", "msfe4_down_sampling3"),
+       ("msfe3_en", 3, 8, "msfe3_ee", "msfe3_ed", "msfe3_down_sampling")]
+DEC = [("msfe3_de", 3, 8, "msfe3_de", "msfe3_dd", "msfe3_upsampling"),
+       ("msfe4_de", 4, 16, "msfe4_de", "msfe4_dd", "msfe4_upsampling"),
+       ("msfe4_de2", 4, 32, "msfe4_de2", "msfe4_dd2", "msfe4_upsampling2"),
+       ("msfe4_de3", 4, 64, "msfe4_de3", "msfe4_dd3", "msfe4_upsampling3"),
+       ("msfe5_de", 5, 128, "msfe5_de", "msfe5_dd", "msfe5_upsampling"),
+       ("msfe6_de", 6, 256, "msfe6_de", "msfe6_dd", "msfe6_upsampling")]
+
+T_INPUT, T_CONV, T_LSTM, T_CTFA = 0, 1, 2, 3
+K_IN, K_EL, K_DL, K_DOWN, K_UP = 0, 1, 2, 3, 4
+P_R32, P_X16 = 0, 1
+S_PREV, S_CUR, S_SCRATCH = 0, 1, 2
+LDS_BYTES = 160 * 1024
+SCR_BYTES = 8192
+SCR_B = LDS_BYTES - SCR_BYTES
+MAX_PARTS, MAX_ZERO, MAX_SEG, CARRY_FRAGS = 4, 4, 6, 12
+
+
+def r64(n):
+    return (n + 63) // 64 * 64
+
+
+# --------------------------------------------------------------------------------- arena layout
+class Arena:
+    """Per-stream HBM arena, mirrored by engine.cpp (allocate_states): all first buffers of the state
+    tensors in signature order, then all second buffers in the same order (so `cur` and `prev` of every
+    tensor differ by the constant PS), then the scratch tensors."""
+
+    def __init__(self):
+        self.states = []   # (name, rows, cols)
+        for side, stages in ((0, ENC), (1, DEC)):
+            for (p, D, f0, ct, st, _rs) in stages:
+                for i in range(1, D + 1):
+                    c = (128 if side else 64) if i == 1 else (64 if side else 32)
+                    self.states.append(("%s_prev%d" % (ct, i), f0 >> (i - 1), c))
+                for j in range(1, D + 1):
+                    self.states.append(("%s_prev%d" % (st, j), (f0 >> D) << (j - 1), 64))
+        for (p, *_r) in ENC:
+            self.states += [(p + "_h", 21, 1), (p + "_c", 21, 1)]
+        self.states += [("state_h", 21, 1), ("state_c", 21, 1)]
+        for (p, *_r) in DEC:
+            self.states += [(p + "_h", 21, 1), (p + "_c", 21, 1)]
+        self.off = {}
+        cur = 0
+        for (n, r, c) in self.states:
+            self.off[n] = cur
+            cur += r64(r * c)
+        self.PS = cur
+        cur *= 2
+        self.scratch = {}
+        for n, sz in [("t_inlayer", 256 * 64), ("t_y", 256 * 64), ("t_d", 256 * 64), ("t_up", 256 * 128)] + \
+                     [("upcat%d" % s, (DEC[s][2] // 2) * 128) for s in range(6)]:
+            self.scratch[n] = cur
+            cur += r64(sz)
+        self.floats = cur
+
+
+# --------------------------------------------------------------------------------- weight blob
+class Blob:
+    def __init__(self):
+        self.cur = 0
+        self.items = []    # (offset, floats, what, layer key)
+
+    def add(self, n, what, key):
+        off = self.cur
+        self.items.append((off, n, what, key))
+        self.cur += r64(n)
+        return off
+
+
+def conv_geom(kind, side, i_or_j, D):
+    """(cin, N, taps, kf, stride, ln, R, gc) of a conv op (models/proposed.py:198-265)."""
+    if kind == K_IN:
+        return (128 if side else 64, 64, 1, 1, 1, 1, 1, 64)
+    if kind == K_EL:
+        cin = (128 if side else 64) if i_or_j == 1 else (64 if side else 32)
+        return (cin, 32, 2, 3, 2, 1, 1, 32)
+    if kind == K_DL:
+        return (64, 128, 2, 3, 1, 1, 2, 64) if i_or_j == D else (64, 64, 2, 3, 1, 1, 2, 32)
+    if kind == K_DOWN:
+        return (64, 64, 1, 3, 2, 0, 1, 64)
+    if kind == K_UP:
+        return (128, 128, 1, 2, 1, 0, 2, 128)
+    raise ValueError(kind)
+
+
+R32_TABLE = {   # (kind, N, P) -> (PT, NT, PG, CG)
+    (K_IN, 64, 256): (1, 2, 8, 1), (K_IN, 64, 128): (1, 2, 4, 1),
+    (K_EL, 32, 128): (1, 1, 4, 1),
+    (K_DL, 64, 64): (1, 1, 2, 2),
+    (K_DL, 128, 128): (2, 2, 2, 2), (K_DL, 128, 64): (1, 2, 2, 2),
+    (K_DOWN, 64, 128): (1, 1, 4, 2), (K_DOWN, 64, 64): (1, 1, 2, 2),
+    (K_UP, 128, 128): (2, 1, 2, 4), (K_UP, 128, 64): (1, 1, 2, 4), (K_UP, 128, 32): (1, 1, 1, 4),
+}
+
+
+def tiling(kind, N, P, cin, taps, rounds=1):
+    """-> dict(path, PT, NT, PG, CG, KSt, KSg)"""
+    if (kind, N, P) in R32_TABLE:
+        PT, NT, PG, CG = R32_TABLE[(kind, N, P)]
+        return dict(path=P_R32, PT=PT, NT=NT, PG=PG, CG=CG, KSt=1, KSg=1)
+    assert P <= 64, (kind, N, P)
+    CT = N // 16
+    G16 = cin // 16
+    KS = max(1, 8 // CT)
+    KSt = 1 if rounds == 2 else min(taps, KS)      # a two-round image holds one time tap at a time
+    KSg = KS // KSt
+    while G16 % KSg:
+        KSg //= 2
+    return dict(path=P_X16, PT=(P + 15) // 16, NT=1, PG=1, CG=CT, KSt=KSt, KSg=KSg)
+
+
+def make_img(kind, P, cin, rounds=1):
+    """LDS image geometry of a conv op: dict(taps, tap_b, pitch_b, pair, half_b, row0, bytes, zero[], seg_b[], seg_tk[])."""
+    if kind == K_IN:
+        pitch = (cin + 4) * 4
+        g = dict(taps=1, pitch_b=pitch, pair=0, half_b=0, row0=0, one=P * pitch, zero=[])
+        segs = [(0, 0, 0)]
+    elif kind == K_EL:
+        pitch = (2 * cin + 4) * 4
+        half = cin * 4
+        g = dict(taps=2, pitch_b=pitch, pair=1, half_b=half, row0=1, one=(P + 1) * pitch,
+                 zero=[(0, cin // 4), (P * pitch + half, cin // 4)])
+        segs = [(t, k, (k >> 1) * pitch + (k & 1) * half) for t in (0, 1) for k in (0, 1, 2)]
+    elif kind == K_DL:
+        pitch = (cin + 4) * 4
+        g = dict(taps=2, pitch_b=pitch, pair=0, half_b=0, row0=1, one=(P + 2) * pitch,
+                 zero=[(0, cin // 4), ((P + 1) * pitch, cin // 4)])
+        segs = [(t, k, k * pitch) for t in (0, 1) for k in (0, 1, 2)]
+    elif kind == K_DOWN:
+        pitch = (2 * cin + 4) * 4
+        half = cin * 4
+        g = dict(taps=1, pitch_b=pitch, pair=1, half_b=half, row0=0, one=(P + 1) * pitch, zero=[(P * pitch, cin // 4)])
+        segs = [(0, k, (k >> 1) * pitch + (k & 1) * half) for k in (0, 1, 2)]
+    elif kind == K_UP:
+        # Conv2DTranspose (1,3) stride 2 (proposed.py:260-265): out[2i] = W0 x[i] + W2 x[i-1], out[2i+1] = W1 x[i]
+        pitch = (cin + 4) * 4
+        g = dict(taps=1, pitch_b=pitch, pair=0, half_b=0, row0=1, one=(P + 1) * pitch, zero=[(0, cin // 4)])
+        segs = [(0, 2, 0), (0, 0, pitch), (0, 1, pitch)]      # (t, kw, byte offset): two even segments, one odd
+    else:
+        raise ValueError(kind)
+    one = (g.pop("one") + 255) // 256 * 256
+    if g["taps"] == 2 and rounds == 2:
+        g["tap_b"] = 0
+        g["bytes"] = one
+        segs = [s for s in segs if s[0] == 1] + [s for s in segs if s[0] == 0]     # current-frame tap first
+        g["seg_b"] = [s[2] for s in segs]
+    else:
+        g["tap_b"] = one if g["taps"] == 2 else 0
+        g["bytes"] = one * g["taps"]
+        g["seg_b"] = [s[0] * g["tap_b"] + s[2] for s in segs]
+        zs = []
+        for t in range(g["taps"]):
+            zs += [(t * g["tap_b"] + z[0], z[1]) for z in g["zero"]]
+        g["zero"] = zs
+    g["seg_tk"] = [s[0] * 4 + s[1] for s in segs]
+    return g
+
+
+def build():
+    A = Arena()
+    W = Blob()
+    ops = []
+
+    def new_op(**kw):
+        d = dict(type=T_CONV, name="", kind=0, P=0, cin=0, N=0, taps=0, kf=0, stride=0, path=0, PT=1, NT=1, PG=1, CG=1, KSt=1, KSg=1,
+                 ln=0, R=1, gc=0, rounds=1, nseg=0, seg_b=[], seg_tk=[], ex_b=0, w_off=0, p_off=0,
+                 d0=None, d1=None, row_mul=1, row_add=0, fwd=None, img=None, nxt=-1, parts=[],
+                 din=0, dout=0, x_b=0, x_pitch_b=0, x_cols=0, y_b=0, h_off=0, c_off=0, ldst=None, lw_off=0,
+                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, wkey="", flops=0)
+        d.update(kw)
+        ops.append(d)
+        return d
+
+    def conv_op(name, wkey, kind, side, idx, D, P, d0=None, d1=None, row_mul=1, row_add=0):
+        cin, N, taps, kf, stride, ln, R, gc = conv_geom(kind, side, idx, D)
+        rounds = 2 if (kind == K_EL and cin == 128 and P >= 64) else 1     # both taps of these images do not fit LDS
+        o = new_op(type=T_CONV, name=name, wkey=wkey, kind=kind, P=P, cin=cin, N=N, taps=taps, kf=kf, stride=stride, ln=ln, R=R, gc=gc,
+                   rounds=rounds, d0=d0, d1=d1, row_mul=row_mul, row_add=row_add)
+        o.update(tiling(kind, N, P, cin, taps, rounds))
+        g = make_img(kind, P, cin, rounds)
+        o["img"] = g
+        o["nseg"] = len(g["seg_b"])
+        o["seg_b"] = g["seg_b"]
+        o["seg_tk"] = g["seg_tk"]
+        ntot = N * (2 if kind == K_UP else 1)
+        K = (3 * cin) if kind == K_UP else taps * kf * cin
+        o["flops"] = 2 * P * (K * N if kind != K_UP else 3 * cin * N)
+        o["w_off"] = W.add((3 * cin * N) if kind == K_UP else K * N, "conv_w", wkey)
+        o["p_off"] = W.add(ntot + 2 * gc + 1, "conv_p", wkey)
+        if o["path"] == P_X16:
+            ks = o["KSt"] * o["KSg"]
+            ex = ks * P * (ntot + 4) * 4
+            o["ex_b"] = (SCR_B - ex) // 256 * 256
+        return o
+
+    # ---- op list --------------------------------------------------------------------------------
+    inp = new_op(type=T_INPUT, name="input_layer")
+    inp["p_off"] = W.add(64 * 4 + 1, "input_p", "input_layer")
+
+    def st_off(tag, i):
+        return A.off["%s_prev%d" % (tag, i)]
+
+    def stage(side, s):
+        p, D, f0, ct, stg, rs = (DEC if side else ENC)[s]
+        fd = f0 >> D
+        c1 = 128 if side else 64
+        pair = DEC[5 - s] if not side else None
+        lst = []
+        lst.append(conv_op(p + "_in", p + "_in", K_IN, side, 0, D, f0, d0=(S_CUR, st_off(ct, 1), c1)))
+        for i in range(1, D + 1):
+            if i < D:
+                ci1 = 64 if side else 32
+                d0 = (S_CUR, st_off(ct, i + 1), ci1)
+                d1 = (S_CUR, st_off(stg, D - i + 1) + 32, 64)
+            else:
+                d0 = (S_CUR, st_off(stg, 1) + 32, 64)
+                d1 = None
+            lst.append(conv_op("%s_conv%d" % (p, i), "%s_conv%d" % (p, i), K_EL, side, i, D, f0 >> i, d0=d0, d1=d1))
+        l = new_op(type=T_LSTM, name=p + "_lstm", wkey=p, din=fd * 32, dout=fd * 32, x_cols=32,
+                   h_off=A.off[p + "_h"], c_off=A.off[p + "_c"], ldst=(S_CUR, st_off(stg, 1), 64), drain=1)
+        l["lw_off"] = W.add((l["din"] + 21 + 1) * 84 + 21 * l["dout"] + l["dout"], "lstm", p)
+        lst.append(l)
+        for j in range(1, D + 1):
+            P = fd << (j - 1)
+            if j < D:
+                d0 = (S_CUR, st_off(stg, j + 1), 64)
+                d1 = (S_CUR, st_off(pair[3], D - j + 1) + 32, 64) if pair else None
+            else:
+                d0 = (S_CUR, st_off(pair[3], 1) + 64, 128) if pair else None
+                d1 = None
+            lst.append(conv_op("%s_spconv%d" % (p, j), "%s_spconv%d" % (p, j), K_DL, side, j, D, P, d0=d0, d1=d1, row_mul=2))
+        c = new_op(type=T_CTFA, name=p + "_ctfa", wkey=p, F=f0, e0_off=st_off(ct, 1), e0_ld=c1, drain=1)
+        c["cw_off"] = W.add(2 * (64 * 16 + 16 + 64 * 16 + 64) + 65, "ctfa", p)
+        lst.append(c)
+        return lst
+
+    stage_ops = {}
+    downs = {}
+    for s in range(6):
+        stage_ops[(0, s)] = stage(0, s)
+        p, D, f0, ct, stg, rs = ENC[s]
+        downs[s] = conv_op(rs, rs, K_DOWN, 0, 0, D, f0 // 2, d0=(S_SCRATCH, A.scratch["upcat%d" % (5 - s)] + 64, 128))
+    cl = new_op(type=T_LSTM, name="lstm", wkey="", din=256, dout=256, x_cols=64, h_off=A.off["state_h"], c_off=A.off["state_c"], ldst=None, drain=1)
+    cl["lw_off"] = W.add((256 + 21 + 1) * 84 + 21 * 256 + 256, "lstm", "")
+    ups = {}
+    for s in range(6):
+        p, D, f0, ct, stg, rs = DEC[s]
+        ups[s] = conv_op(rs, rs, K_UP, 1, 0, D, f0 // 2, row_mul=2)
+        stage_ops[(1, s)] = stage(1, s)
+    for i, o in enumerate(ops):
+        o["idx"] = i
+    n_ops = len(ops)
+
+    # ---- who completes whose image -----------------------------------------------------------------
+    conv_idx = [o["idx"] for o in ops if o["type"] == T_CONV]
+    for a, b in zip([0] + conv_idx[:-1], conv_idx):
+        ops[a]["nxt"] = b
+    last_conv = ops[conv_idx[-1]]
+
+    def fwd_into(o, tgt, coff):
+        g = tgt["img"]
+        cur_tap = g["taps"] - 1
+        o["fwd"] = dict(on=1, base_b=cur_tap * g["tap_b"] + coff * 4, pitch_b=g["pitch_b"], pair=g["pair"], half_b=g["half_b"], row0=g["row0"])
+
+    for o in ops:
+        if o["type"] not in (T_CONV, T_INPUT) or o["nxt"] < 0:
+            continue
+        tgt = ops[o["nxt"]]
+        coff = 0
+        if o["type"] == T_CONV and o["kind"] == K_EL and tgt["kind"] == K_DL:
+            coff = 32          # e_D -> channels [32,64) of sub-pixel conv 1's input; the LSTM writes [0,32)
+        if o["type"] == T_CONV and o["kind"] == K_DOWN and tgt["kind"] == K_UP:
+            coff = 64          # z -> channels [64,128) of the first up-sampling input; the central LSTM writes [0,64)
+        fwd_into(o, tgt, coff)
+    # the last sub-pixel conv of the network feeds the last CTFA (+ output conv): plain [256][64+4] rows at LDS 0
+    last_conv["fwd"] = dict(on=1, base_b=0, pitch_b=68 * 4, pair=0, half_b=0, row0=0)
+
+    # LSTM / CTFA work in place on the image of the conv op that follows them
+    for o in ops:
+        if o["type"] == T_LSTM:
+            tgt = ops[o["idx"] + 1]
+            g = tgt["img"]
+            base = (g["taps"] - 1) * g["tap_b"] + g["row0"] * g["pitch_b"]
+            assert not g["pair"]
+            o["x_b"] = base + o["x_cols"] * 4
+            o["y_b"] = base
+            o["x_pitch_b"] = g["pitch_b"]
+        if o["type"] == T_CTFA:
+            o["fwd"] = dict(ops[o["idx"] - 1]["fwd"])
+            o["last"] = 1 if o["idx"] == n_ops - 1 else 0
+    assert ops[-1]["type"] == T_CTFA and ops[-1]["last"]
+
+    # ---- staged parts of every image --------------------------------------------------------------
+    def part(src, off, ld, rows, c4s, lds_b, row0, la, round2=0):
+        return dict(src=src, off=off, ld=ld, rows=rows, c4s=c4s, lds_b=lds_b, row0=row0, la=la, round2=round2)
+
+    def la_of(rows, c4s):
+        return 2 if (rows * c4s + 511) // 512 <= 2 else 1
+
+    for side in (0, 1):
+        for s in range(6):
+            p, D, f0, ct, stg, rs = (DEC if side else ENC)[s]
+            lst = stage_ops[(side, s)]
+            for i in range(1, D + 1):
+                o = lst[i]
+                g = o["img"]
+                rows, cin = f0 >> (i - 1), o["cin"]
+                parts = []
+                r2 = 1 if o["rounds"] == 2 else 0
+                parts.append(part(S_PREV, st_off(ct, i), cin, rows, cin // 4, 0, g["row0"], 1 if r2 else la_of(rows, cin // 4), r2))
+                if side:
+                    sk = 64 if i == 1 else 32
+                    parts.append(part(S_CUR, st_off(ct, i) + sk, cin, rows, sk // 4, g["tap_b"] + sk * 4, g["row0"], la_of(rows, sk // 4)))
+                o["parts"] = parts
+            for j in range(1, D + 1):
+                o = lst[D + 1 + j]
+                g = o["img"]
+                rows = o["P"]
+                parts = [part(S_PREV, st_off(stg, j), 64, rows, 16, 0, g["row0"], la_of(rows, 16))]
+                if j >= 2:
+                    # e_{D-j+1}, written this frame by strided conv D-j+1: visible after the LSTM's drain point,
+                    # i.e. its loads may be issued by sub-pixel conv 1 at the earliest
+                    la = 1 if j == 2 else la_of(rows, 8)
+                    parts.append(part(S_CUR, st_off(stg, j) + 32, 64, rows, 8, g["tap_b"] + 32 * 4, g["row0"], la))
+                o["parts"] = parts
+            if side and s >= 1:
+                o = ups[s]
+                g = o["img"]
+                rows = o["P"]
+                o["parts"] = [part(S_SCRATCH, A.scratch["upcat%d" % s] + 64, 128, rows, 16, 64 * 4, g["row0"], la_of(rows, 16))]
+
+    # ---- checks -----------------------------------------------------------------------------------
+    for o in ops:
+        if o["type"] != T_CONV:
+            continue
+        g = o["img"]
+        lim = o["ex_b"] if o["path"] == P_X16 else SCR_B
+        assert g["bytes"] <= lim, (o["name"], g["bytes"], lim)
+        if o["nxt"] >= 0:
+            assert ops[o["nxt"]]["img"]["bytes"] <= lim, (o["name"], "next image over the exchange buffer")
+        assert len(o["parts"]) <= MAX_PARTS and len(g["zero"]) <= MAX_ZERO and o["nseg"] <= MAX_SEG
+        tasks = o["PG"] * o["CG"] * o["KSt"] * o["KSg"]
+        assert tasks in (1, 2, 4, 8), (o["name"], tasks)
+        if o["path"] == P_R32:
+            assert o["P"] % (32 * o["PT"] * o["PG"]) == 0 and (not o["ln"] or o["NT"] * 32 == o["gc"])
+    # Same-frame HBM hand-offs (skip connections): the loads of a staged part may only be issued after a
+    # drain point (every wave has waited for its own stores) that follows the producing op.
+    builder = {o["nxt"]: o["idx"] for o in ops if o["nxt"] >= 0}
+    for o in ops:
+        for p in o["parts"]:
+            if p["src"] == S_PREV:
+                continue
+            prod = [q["idx"] for q in ops for d in (q["d0"], q["d1"]) if d and d[0] == p["src"] and d[1] == p["off"] and d[2] == p["ld"]]
+            assert len(prod) == 1, (o["name"], p)
+            issue = builder[o["idx"]] - (p["la"] - 1)
+            assert any(ops[k]["drain"] for k in range(prod[0], issue)), (o["name"], p, prod, issue)
+            p["producer"] = prod[0]
+    return A, W, ops
+
+
+# --------------------------------------------------------------------------------- emit
+def c_part(p):
+    return "{%d,%d,%d,%d,%d,%d,%d,%d,%d}" % (p["src"], p["off"], p["ld"], p["rows"], p["c4s"], p["lds_b"], p["row0"], p["la"], p["round2"])
+
+
+def c_img(o):
+    g = o["img"]
+    if g is None:
+        return "{0,0,0,0,0,0,0,0,{%s},0,{%s}}" % (",".join(["{0,0,0,0,0,0,0,0,0}"] * MAX_PARTS), ",".join(["{0,0}"] * MAX_ZERO))
+    parts = [c_part(p) for p in o["parts"]] + ["{0,0,0,0,0,0,0,0,0}"] * (MAX_PARTS - len(o["parts"]))
+    zs = ["{%d,%d}" % z for z in g["zero"]] + ["{0,0}"] * (MAX_ZERO - len(g["zero"]))
+    return "{%d,%d,%d,%d,%d,%d,%d,%d,{%s},%d,{%s}}" % (g["taps"], g["tap_b"], g["pitch_b"], g["pair"], g["half_b"], g["row0"], g["bytes"],
+                                                       len(o["parts"]), ",".join(parts), len(g["zero"]), ",".join(zs))
+
+
+def c_fwd(f):
+    if not f:
+        return "{0,0,0,0,0,0}"
+    return "{%d,%d,%d,%d,%d,%d}" % (f["on"], f["base_b"], f["pitch_b"], f["pair"], f["half_b"], f["row0"])
+
+
+def c_dst(d):
+    return "0,0,0,0" if d is None else "1,%d,%d,%d" % d
+
+
+def pad(lst, n):
+    return list(lst) + [0] * (n - len(lst))
+
+
+def emit(A, W, ops):
+    L = []
+    L.append("// GENERATED by tools/gen_fused_plan.py -- do not edit (tests/test_fused_plan.py checks it is current).")
+    L.append("constexpr int kNumOps = %d;" % len(ops))
+    L.append("constexpr int kParityStride = %d;      // floats between the two buffers of every state tensor" % A.PS)
+    L.append("constexpr int kArenaFloats = %d;       // per-stream arena the plan addresses (engine.cpp lays it out identically)" % A.floats)
+    L.append("constexpr int kBlobFloats = %d;        // weight blob in plan order" % W.cur)
+    L.append("constexpr OpD kOps[kNumOps] = {")
+    for o in ops:
+        seg_b = ",".join(str(x) for x in pad(o["seg_b"], MAX_SEG))
+        ldst = o["ldst"]
+        row = ("{%d, /*conv*/ %d,%d,%d,%d,%d,%d,%d, %d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, %d,{%s}, %d, %d,%d, %s, %s, %d,%d, %s, %s, %d, "
+               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d},   // %d %s") % (
+            o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
+            o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
+            o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
+            c_fwd(o["fwd"]), c_img(o), o["nxt"],
+            o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
+            1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["lw_off"],
+            o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["idx"], o["name"])
+        L.append("  " + row)
+    L.append("};")
+    # what the host needs to pack the blob / check the arena
+    L.append("struct BlobItem { int off, floats, what, op; const char* key; };   // what: 0 conv fragments, 1 conv params, 2 lstm, 3 ctfa, 4 input layer")
+    what_code = {"conv_w": 0, "conv_p": 1, "lstm": 2, "ctfa": 3, "input_p": 4}
+    item_op = {}
+    for o in ops:
+        for k in ("w_off", "p_off", "lw_off", "cw_off"):
+            if o.get(k) or (k == "p_off" and o["type"] == T_INPUT):
+                item_op.setdefault(o[k], o["idx"])
+    L.append("constexpr int kNumBlobItems = %d;" % len(W.items))
+    L.append("static const BlobItem kBlobItems[kNumBlobItems] = {")
+    for (off, n, what, key) in W.items:
+        L.append('  {%d, %d, %d, %d, "%s"},' % (off, n, what_code[what], item_op[off], key))
+    L.append("};")
+    L.append("struct StateOff { const char* name; int off; };")
+    L.append("constexpr int kNumStateOffs = %d;" % len(A.states))
+    L.append("static const StateOff kStateOffs[kNumStateOffs] = {")
+    for (n, r, c) in A.states:
+        L.append('  {"%s", %d},' % (n, A.off[n]))
+    L.append("};")
+    L.append("static const StateOff kScratchOffs[%d] = {" % len(A.scratch))
+    for n, off in A.scratch.items():
+        L.append('  {"%s", %d},' % (n, off))
+    L.append("};")
+    L.append("// (time tap, frequency tap) of every K segment, in the order the kernel walks them: t * 4 + kw")
+    L.append("static const int kSegTk[kNumOps][%d] = {" % MAX_SEG)
+    for o in ops:
+        L.append("  {%s}," % ",".join(str(x) for x in pad(o["seg_tk"], MAX_SEG)))
+    L.append("};")
+    L.append("static const char* const kOpNames[kNumOps] = {%s};" % ", ".join('"%s"' % o["name"] for o in ops))
+    L.append("static const double kOpFlops[kNumOps] = {%s};" % ", ".join("%d" % o["flops"] for o in ops))
+    return "\n".join(L) + "\n"
+
+
+def main():
+    A, W, ops = build()
+    inc = emit(A, W, ops)
+    js = json.dumps(dict(parity_stride=A.PS, arena_floats=A.floats, blob_floats=W.cur, state_off=A.off, scratch=A.scratch,
+                         blob=[list(x) for x in W.items], ops=ops), indent=1, sort_keys=True)
+    if "--check" in sys.argv:
+        ok = open(INC).read() == inc and open(JSN).read() == js
+        print("fused plan is %s" % ("current" if ok else "STALE"))
+        sys.exit(0 if ok else 1)
+    open(INC, "w").write(inc)
+    open(JSN, "w").write(js)
+    r32 = [o for o in ops if o["type"] == T_CONV and o["path"] == P_R32]
+    print("ops %d (conv %d, of which %d on 32x32 tiles), arena %d floats (parity stride %d), blob %d floats" % (
+        len(ops), sum(o["type"] == T_CONV for o in ops), len(r32), A.floats, A.PS, W.cur))
+
+
+if __name__ == "__main__":
+    main()
