@@ -161,6 +161,10 @@ int nutls_profile_persistent(nutls_handle* h, double* us, int n);
 int nutls_fused_num_ops(void);
 int nutls_fused_op_info(int index, const char** name, double* flops);
 int nutls_profile_fused(nutls_handle* h, double* us, int n);
+/* Host-only (works without a GPU): the fused kernel's weight blob for a container -- conv kernels int8 in MFMA fragment
+ * order, everything else fp32, in the order of the static schedule.  n_floats must equal nutls_fused_blob_floats(). */
+int nutls_fused_blob_floats(void);
+int nutls_fused_pack_blob(const void* weights, size_t n_bytes, float* out, size_t n_floats);
 
 const char* nutls_last_error(void);
 const char* nutls_version(void);

@@ -907,9 +907,9 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   HIP_TRY(hipMemcpy(p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
   e->fz_blob = static_cast<float*>(p);
   void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, (fused_num_ops() + 1) * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&q, (fused_num_ops() * 9 + 1) * sizeof(unsigned long long)));     // op starts + 8 phase stamps per op
   e->allocs.push_back(q);
-  HIP_TRY(hipMemset(q, 0, (fused_num_ops() + 1) * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(q, 0, (fused_num_ops() * 9 + 1) * sizeof(unsigned long long)));
   e->fz_prof = static_cast<unsigned long long*>(q);
   HIP_TRY(fused_step_set_attributes());
   return NUTLS_OK;
@@ -1492,6 +1492,25 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
 
 int nutls_fused_num_ops(void) { return fused_num_ops(); }
 
+int nutls_fused_blob_floats(void) { return fused_blob_floats(); }
+
+/* Host-only (no GPU needed): the weight blob of the fused kernel for a container, for tests of the packing. */
+int nutls_fused_pack_blob(const void* weights, size_t n_bytes, float* out, size_t n_floats) {
+  if (!weights || !out) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: null pointer");
+  if (n_floats != static_cast<size_t>(fused_blob_floats())) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: n_floats must equal nutls_fused_blob_floats()");
+  WeightMap wm;
+  std::string err;
+  std::vector<float> blob;
+  try {
+    if (!parse_weight_blob(weights, n_bytes, &wm, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
+    if (!fused_pack_blob(wm, &blob, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
+  } catch (const std::exception& ex) {
+    return fail(NUTLS_ERR_WEIGHTS, std::string("weight container: ") + ex.what());
+  }
+  std::memcpy(out, blob.data(), blob.size() * sizeof(float));
+  return NUTLS_OK;
+}
+
 int nutls_fused_op_info(int index, const char** name, double* flops) {
   if (index < 0 || index >= fused_num_ops()) return fail(NUTLS_ERR_ARG, "nutls_fused_op_info: bad index");
   if (name) *name = fused_op_name(index);
@@ -1516,6 +1535,23 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n) {
   for (int i = 0; i < n; ++i) us[i] = static_cast<double>(t[i + 1] - t[i]) * 1000.0 / khz;
   e->next_parity = 1 - par;
   e->steps += 1;
+  if (const char* dump = getenv("NUTLS_FUSED_PHASES")) {     // debugging aid: phase stamps of every conv op (wave 0 of workgroup 0)
+    std::vector<unsigned long long> sub(static_cast<size_t>(n) * 8);
+    HIP_TRY(hipMemcpy(sub.data(), e->fz_prof + n + 1, sub.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(dump, "w")) {
+      for (int i = 0; i < n; ++i) {
+        fprintf(f, "%-24s total %6.2f |", fused_op_name(i), us[i]);
+        const char* nm[5] = {"issue", "mfma", "bar1", "epi", "build"};
+        unsigned long long prev = t[i];
+        for (int k = 0; k < 5; ++k) {
+          const unsigned long long v = sub[8 * i + k];
+          if (v >= t[i] && v <= t[i + 1]) { fprintf(f, " %s %5.2f", nm[k], static_cast<double>(v - prev) * 1000.0 / khz); prev = v; }
+        }
+        fprintf(f, " bar2 %5.2f\n", static_cast<double>(t[i + 1] - prev) * 1000.0 / khz);
+      }
+      fclose(f);
+    }
+  }
   return NUTLS_OK;
 }
 

@@ -50,11 +50,13 @@ int fused_num_scratch() { return static_cast<int>(sizeof(fz::kScratchOffs) / siz
 const char* fused_scratch_name(int i) { return fz::kScratchOffs[i].name; }
 int fused_scratch_off(int i) { return fz::kScratchOffs[i].off; }
 
-// Weight blob of the fused kernel, in plan order.
-//   conv fragments (float index): for segment s (time tap t, frequency tap kw) for K group g for channel tile T for lane for j
-//       32x32x2 tiles: n' = 32 T + (lane & 31), c = 8 g + 4 (lane >> 5) + j
-//       16x16x4 tiles: n' = 16 T + (lane & 15), c = 16 g + 4 (lane >> 4) + j
-//       value = W[perm[n']][t][kw][c]                       (OHWI weights, converter_proposed.py Conv2D kernels)
+// Weight blob of the fused kernel, in plan order.  Conv kernels stay int8 (the container's payload, what the reference's
+// .tflite stores; `w = q * scale[out channel]`, converter_proposed.py:901) and the kernel applies the scale in its epilogue.
+//   conv fragments: for wave task for fragment f of the task (4 fragments = 16 bytes per lane) for lane for q
+//       fragment f -> K segment (time tap t, frequency tap kw), K group g, channel tile T  (same walk as fused_step.hip)
+//       32x32x2 tiles: n' = 32 T + (lane & 31), c = 8 g + 4 (lane >> 5) + q
+//       16x16x4 tiles: n' = 16 T + (lane & 15), c = 16 g + 4 (lane >> 4) + q
+//       byte = Q[perm[n']][t][kw][c]                        (OHWI weights, converter_proposed.py Conv2D kernels)
 bool fused_pack_blob(const WeightMap& wm, std::vector<float>* out, std::string* err) {
   out->assign(static_cast<size_t>(fz::kBlobFloats), 0.f);
   err->clear();
@@ -67,42 +69,63 @@ bool fused_pack_blob(const WeightMap& wm, std::vector<float>* out, std::string* 
       const HostTensor* w = get(wm, key + ".w", err);
       if (!w) return false;
       if (w->dims.size() != 4 || w->dims[0] != d.N || w->dims[3] != d.cin) { *err = "unexpected weight shape for " + key; return false; }
+      if (w->q.size() != w->data.size() || (w->scales.size() != 1 && static_cast<int>(w->scales.size()) != d.N)) {
+        *err = "fused mode keeps conv weights int8 on the device; " + key + ".w is not an int8 tensor of the container";
+        return false;
+      }
       const int th = w->dims[1], kw = w->dims[2];
       const std::vector<int> perm = channel_perm(d);
       const bool r32 = d.path == fz::P_R32;
-      const int G = d.cin / (r32 ? 8 : 16), TN = d.N / (r32 ? 32 : 16);
-      size_t o = 0;
-      for (int s = 0; s < d.nseg; ++s) {
-        const int t = fz::kSegTk[bi.op][s] >> 2, k = fz::kSegTk[bi.op][s] & 3;
-        if (t >= th || k >= kw) { *err = "segment outside the kernel of " + key; return false; }
-        for (int g = 0; g < G; ++g)
-          for (int T = 0; T < TN; ++T)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int j = 0; j < 4; ++j) {
-                const int np = r32 ? 32 * T + (lane & 31) : 16 * T + (lane & 15);
-                const int c = r32 ? 8 * g + 4 * (lane >> 5) + j : 16 * g + 4 * (lane >> 4) + j;
-                dst[o++] = w->data[((static_cast<size_t>(perm[np]) * th + t) * kw + k) * d.cin + c];
-              }
+      const int G = d.cin / (r32 ? 8 : 16), GW = G / d.KSg;
+      const int segw = d.kind == fz::K_UP ? 3 : d.nseg / d.KSt;
+      const int nf = segw * GW * d.NT, nsf = (nf + 3) / 4, wtasks = d.CG * d.KSt * d.KSg;
+      if (wtasks * nsf * 256 != bi.floats) { *err = "fragment count mismatch for " + key; return false; }
+      int8_t* dst8 = reinterpret_cast<int8_t*>(dst);
+      for (int task = 0; task < wtasks; ++task) {
+        const int ct = task % d.CG, ks = task / d.CG, ks_g = ks % d.KSg, ks_t = ks / d.KSg;
+        for (int f = 0; f < nf; ++f) {
+          int sg, g, T;
+          if (r32) {
+            const int nt = f % d.NT, sgi = f / d.NT;
+            sg = sgi / G; g = sgi % G; T = ct * d.NT + nt;
+          } else {
+            sg = ks_t * segw + f / GW; g = ks_g * GW + f % GW; T = ct;
+          }
+          const int t = fz::kSegTk[bi.op][sg] >> 2, k = fz::kSegTk[bi.op][sg] & 3;
+          if (sg >= d.nseg || t >= th || k >= kw) { *err = "segment outside the kernel of " + key; return false; }
+          for (int lane = 0; lane < 64; ++lane)
+            for (int q = 0; q < 4; ++q) {
+              const int np = r32 ? 32 * T + (lane & 31) : 16 * T + (lane & 15);
+              const int c = r32 ? 8 * g + 4 * (lane >> 5) + q : 16 * g + 4 * (lane >> 4) + q;
+              dst8[((static_cast<size_t>(task) * nsf + f / 4) * 64 + lane) * 16 + (f % 4) * 4 + q] =
+                  w->q[((static_cast<size_t>(perm[np]) * th + t) * kw + k) * d.cin + c];
+            }
+        }
       }
-      if (static_cast<int>(o) != bi.floats) { *err = "fragment count mismatch for " + key; return false; }
     } else if (bi.what == 1) {
+      // bias | per-channel weight scale | gamma | beta | alpha   (packed channel order)
       const HostTensor* b = get(wm, key + ".b", err);
-      if (!b) return false;
+      const HostTensor* w = get(wm, key + ".w", err);
+      if (!b || !w) return false;
       if (static_cast<int>(b->size()) != d.N) { *err = "unexpected bias size for " + key; return false; }
+      if (w->scales.size() != 1 && static_cast<int>(w->scales.size()) != d.N) { *err = "unexpected scale count for " + key; return false; }
       const std::vector<int> perm = channel_perm(d);
-      const int reps = d.kind == fz::K_UP ? 2 : 1;         // the up-sampling bias applies to even and odd output rows
+      const int reps = d.kind == fz::K_UP ? 2 : 1;         // the up-sampling layer's parameters apply to even and odd output rows
+      const int nt = reps * d.N;
       for (int r = 0; r < reps; ++r)
-        for (int n = 0; n < d.N; ++n) dst[r * d.N + n] = b->data[perm[n]];
+        for (int n = 0; n < d.N; ++n) {
+          dst[r * d.N + n] = b->data[perm[n]];
+          dst[nt + r * d.N + n] = w->scales.size() == 1 ? w->scales[0] : w->scales[perm[n]];
+        }
       if (d.ln) {
         const HostTensor* g = get(wm, key + ".gamma", err);
         const HostTensor* bt = get(wm, key + ".beta", err);
         const HostTensor* al = get(wm, key + ".alpha", err);
         if (!g || !bt || !al) return false;
         if (static_cast<int>(g->size()) != d.gc || static_cast<int>(bt->size()) != d.gc || al->size() < 1) { *err = "unexpected LayerNorm / PReLU size for " + key; return false; }
-        const int nt = reps * d.N;
-        std::memcpy(dst + nt, g->data.data(), d.gc * sizeof(float));
-        std::memcpy(dst + nt + d.gc, bt->data.data(), d.gc * sizeof(float));
-        dst[nt + 2 * d.gc] = al->data[0];
+        std::memcpy(dst + 2 * nt, g->data.data(), d.gc * sizeof(float));
+        std::memcpy(dst + 2 * nt + d.gc, bt->data.data(), d.gc * sizeof(float));
+        dst[2 * nt + 2 * d.gc] = al->data[0];
       }
     } else if (bi.what == 2) {
       const std::string ln = key.empty() ? "lstm" : key + "_lstm", dn = key.empty() ? "dense" : key + "_dense";

@@ -19,8 +19,7 @@ constexpr int LDS_BYTES = 160 * 1024;
 constexpr int SCR_BYTES = 8192;                      // LSTM / CTFA scratch at the top of LDS
 constexpr int SCR_B = LDS_BYTES - SCR_BYTES;
 constexpr int MAX_PARTS = 4, MAX_ZERO = 4, MAX_SEG = 6;
-constexpr int CARRY_FRAGS = 8;                       // weight fragments (float4 per lane) prefetched by the previous op: 32x32 tiles
-constexpr int CARRY_FRAGS_X16 = 12;                  // ... 16x16 tiles (small accumulators, short K loops)
+constexpr int RING_SF = 3;                           // weight ring of a wave: 3 x (dwordx4 per lane = 4 int8 MFMA fragments), first fill by the previous op
 
 // A rectangular block of an HBM tensor that is copied into an LDS image through registers.
 struct Part {

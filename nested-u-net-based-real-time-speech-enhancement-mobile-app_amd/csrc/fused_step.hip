@@ -29,6 +29,10 @@
 #include "nutls_internal.hpp"
 #include "fused_plan.hpp"
 
+#ifndef FZ_PROF
+#define FZ_PROF 0
+#endif
+
 namespace nutls {
 namespace fz {
 
@@ -52,6 +56,9 @@ struct Ctx {
   gf_t io_out;
   unsigned long long* prof;
 };
+
+// profiling build: phase stamps inside an op (wave 0 of workgroup 0), slot k of op I at prof[kNumOps + 1 + 8 I + k]
+#define FZ_STAMP(I, k) do { if (FZ_PROF && cx.prof && tid == 0) cx.prof[kNumOps + 1 + 8 * (I) + (k)] = wall_clock64(); } while (0)
 
 // ---- memory helpers (byte offsets) ---------------------------------------------------------------
 __device__ __forceinline__ f32x4 ldb(gcb_t base, unsigned boff) { return *(gc4_t)(base + static_cast<unsigned long long>(boff)); }
@@ -107,12 +114,9 @@ constexpr int segw(const OpD& d) { return is_up(d) ? 3 : d.nseg / d.KSt; }      
 constexpr int tn(const OpD& d) { return d.N / (d.path == P_R32 ? 32 : 16); }                     // channel tiles per segment row of the blob
 constexpr int conv_nf(const OpD& d) { return segw(d) * gw(d) * d.NT; }                            // weight fragments per wave
 constexpr int ntask(const OpD& d) { return d.PG * d.CG * d.KSt * d.KSg; }
-constexpr int nparams(const OpD& d) { return ntot(d) + 2 * d.gc + 1; }
-// blob float offset of fragment f of a wave, relative to its wave base
-constexpr int frag_imm(const OpD& d, int f) {
-  const int nt = f % d.NT, sg = f / d.NT, s = sg / gw(d), g = sg % gw(d);
-  return ((s * kgroups(d) + g) * tn(d) + nt) * 256;
-}
+constexpr int nparams(const OpD& d) { return 2 * ntot(d) + 2 * d.gc + 1; }      // bias | weight scale | gamma | beta | alpha
+constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 3) / 4; }             // "super-fragments": 4 int8 fragments = one dwordx4 per lane
+constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), RING_SF); }
 constexpr int part_cls(const Part& p) { return p.round2 ? 3 : p.la; }
 constexpr int part_n(const Part& p) { return (p.rows * p.c4s + THREADS - 1) / THREADS; }
 constexpr int parts_regs(const Img& g, int cls) {
@@ -132,7 +136,7 @@ constexpr int ctfa_ni(const OpD& d) { return (d.F + 31) / 32; }
 constexpr int carry_w(int i) {
   if (i >= kNumOps) return 0;
   const OpD& d = kOps[i];
-  if (d.type == T_CONV) return cmin(conv_nf(d), d.path == P_X16 ? CARRY_FRAGS_X16 : CARRY_FRAGS);
+  if (d.type == T_CONV) return ring_sf(d);
   if (d.type == T_LSTM) return d.din / 16;
   if (d.type == T_CTFA) return ctfa_ni(d);
   return 0;
@@ -204,6 +208,21 @@ __device__ __forceinline__ void zero_halos(int tid) {
   }
 }
 
+// A operand of the MFMAs: byte q of the lane's dword of fragment f (int8 weight, exact in fp32); the per-channel scale
+// of the quantisation is applied to the accumulators in the epilogue.
+__device__ __forceinline__ float wq(const f32x4& sfrag, int j, int q) {
+  const float x = sfrag[j];           // (a scalar copy first: __builtin_bit_cast applied to `vec[j]` directly reads element 0, ROCm 7.2 clang)
+  const int v = __builtin_bit_cast(int, x);
+  return static_cast<float>(static_cast<signed char>(v >> (8 * q)));
+}
+// The carried weights become visible to the optimiser only here: without this it hoists the byte extraction up to the
+// loads in the previous op -- and waits for them there, which turns the prefetch into a synchronous load.
+template <int N>
+__device__ __forceinline__ void pin_regs(f32x4 (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
+}
+
 // ---- wave task of a conv op -----------------------------------------------------------------------------------
 struct Task { int active, wbase_f, a, b, ks; };   // a/b: (pg, cg) on the R32 path, (ct, ks_t | ks_g) decoded by the caller on X16
 template <int I>
@@ -215,12 +234,12 @@ __device__ __forceinline__ Task conv_task(int wave) {
     t.a = wave & (d.PG - 1);           // position group
     t.b = (wave >> clog2(d.PG)) & (d.CG - 1);   // channel group
     t.ks = 0;
-    t.wbase_f = t.b * d.NT * 256;
+    t.wbase_f = t.b * (conv_nsf(d) * 256);
   } else {
     const int ct = wave & (d.CG - 1), ks = (wave >> clog2(d.CG)) & (d.KSt * d.KSg - 1);
     const int ks_g = ks & (d.KSg - 1), ks_t = ks >> clog2(d.KSg);
     t.a = ct; t.b = ks_t * 256 + ks_g; t.ks = ks;
-    t.wbase_f = ((ks_t * segw(d) * kgroups(d) + ks_g * gw(d)) * tn(d) + ct) * 256;
+    t.wbase_f = (wave & (ntask(d) - 1)) * (conv_nsf(d) * 256);
   }
   return t;
 }
@@ -237,8 +256,8 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
         // wave-uniform base (SGPR pair) + lane offset (VGPR) + immediate: no 64-bit vector address arithmetic
         const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
         sfor<carry_w(I)>([&](auto ff) {
-          constexpr int f = decltype(ff)::value;
-          w[f] = ldb(wbase + static_cast<unsigned long long>(frag_imm(d, f) * 4), static_cast<unsigned>(lane * 16));
+          constexpr int sf = decltype(ff)::value;
+          w[sf] = ldb(wbase + static_cast<unsigned long long>(sf * 1024), static_cast<unsigned>(lane * 16));
         });
       }
       if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>(tid * 16));
@@ -291,12 +310,13 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
   const int u0 = tid >> clog2(LPG);
   const int r = u0 & (R - 1);
   const f32x4 bias = lds4(SCR_B + (r * GC + 4 * li) * 4);
+  const f32x4 wsc = lds4(SCR_B + (NTOT + r * GC + 4 * li) * 4);
   f32x4 gm = bias, bt = bias;
   float alpha = 0.f;
   if constexpr (d.ln) {
-    gm = lds4(SCR_B + (NTOT + 4 * li) * 4);
-    bt = lds4(SCR_B + (NTOT + GC + 4 * li) * 4);
-    alpha = lds1(SCR_B + (NTOT + 2 * GC) * 4);
+    gm = lds4(SCR_B + (2 * NTOT + 4 * li) * 4);
+    bt = lds4(SCR_B + (2 * NTOT + GC + 4 * li) * 4);
+    alpha = lds1(SCR_B + (2 * NTOT + 2 * GC) * 4);
   }
   sfor<passes>([&](auto pp) {
     constexpr int ps = decltype(pp)::value;
@@ -304,8 +324,9 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
     if ((ps + 1) * THREADS <= total || FZ_LIKELY(u * LPG < total)) {
       const int pos = u >> clog2(R);
       const int eb = d.ex_b + pos * OPB + (r * GC + 4 * li) * 4;
-      f32x4 v = bias;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       sfor<KS>([&](auto kk) { v += lds4(eb + decltype(kk)::value * (d.P * OPB)); });
+      v = v * wsc + bias;
       if constexpr (d.ln) {
         const float mean = group_sum<LPG>(v[0] + v[1] + v[2] + v[3]) * (1.0f / GC);
         v -= mean;
@@ -330,7 +351,7 @@ template <int I, int N1, int N3>
 __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
   constexpr OpD d = kOps[I];
   constexpr bool UP = is_up(d);
-  constexpr int PT = d.PT, GW = gw(d), NF = conv_nf(d), CW = carry_w(I), NTOT = ntot(d), OPB = (NTOT + 4) * 4;
+  constexpr int PT = d.PT, GW = gw(d), NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d), OPB = (NTOT + 4) * 4;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Task t = conv_task<I>(wave);
   const int ks_t = t.b >> 8, ks_g = t.b & 255;
@@ -347,13 +368,15 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
   for (int pt = 0; pt < PT; ++pt) { acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f}; acco[pt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
+  if (t.active) pin_regs(c.w);
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
     if (t.active) {
       sfor<hi - lo>([&](auto ff) {
         constexpr int f = lo + decltype(ff)::value;
         constexpr int s = f / GW, g = f % GW;
-        const f32x4 a = c.w[f % CW];
+        constexpr int sf = f / 4;
+        const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
           const f32x4 b = lds4(lane_b[pt] + d.seg_b[s] + g * 64);
@@ -363,8 +386,8 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
             else acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc[pt], 0, 0, 0);
           }
         }
-        if constexpr (f + CW < NF) {
-          c.w[f % CW] = ldb(wbase + static_cast<unsigned long long>(frag_imm(d, f + CW) * 4), lane16);
+        if constexpr ((f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
+          c.w[sf % CW] = ldb(wbase + static_cast<unsigned long long>((sf + CW) * 1024), lane16);
           sched_pin();
         }
       });
@@ -391,9 +414,13 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
     }
   }
   if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
+  FZ_STAMP(I, 1);
   lds_barrier();
+  FZ_STAMP(I, 2);
   x_epilogue<I>(cx, tid);
+  FZ_STAMP(I, 3);
   build_next<I>(tid, p1, c.p);
+  FZ_STAMP(I, 4);
 }
 
 // ---- conv op, large layers: 32x32x2 tiles, whole LayerNorm groups per wave, epilogue in registers ----------------------
@@ -403,7 +430,7 @@ template <int I, int N1, int N3>
 __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
   constexpr OpD d = kOps[I];
   constexpr bool UP = is_up(d);
-  constexpr int PT = d.PT, NT = d.NT, G = kgroups(d), NF = conv_nf(d), CW = carry_w(I), NTOT = ntot(d);
+  constexpr int PT = d.PT, NT = d.NT, G = kgroups(d), NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d);
   constexpr int NA = UP ? 2 : NT;                    // accumulator tiles per position tile (UP: even row, odd row)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Task t = conv_task<I>(wave);
@@ -420,6 +447,7 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
       for (int e = 0; e < 16; ++e) acc[pt][n][e] = 0.f;
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
+  if (t.active) pin_regs(c.w);
   f32x4 b[PT];
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
@@ -432,13 +460,14 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) b[pt] = lds4(lane_b[pt] + d.seg_b[s] + g * 32);
         }
-        const f32x4 a = c.w[f % CW];
+        constexpr int sf = f / 4;
+        const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) acc[pt][na] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[pt][q], acc[pt][na], 0, 0, 0);
-        if constexpr (f + CW < NF) {
-          c.w[f % CW] = ldb(wbase + static_cast<unsigned long long>(frag_imm(d, f + CW) * 4), lane16);
+        if constexpr ((f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
+          c.w[sf % CW] = ldb(wbase + static_cast<unsigned long long>((sf + CW) * 1024), lane16);
           sched_pin();
         }
       });
@@ -454,10 +483,12 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{});
   }
   if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
+  FZ_STAMP(I, 1);
   lds_barrier();                      // every wave is done with this op's image; parameters are in LDS
+  FZ_STAMP(I, 2);
   if (t.active) {
     float alpha = 0.f;
-    if constexpr (d.ln) alpha = lds1(SCR_B + (NTOT + 2 * d.gc) * 4);
+    if constexpr (d.ln) alpha = lds1(SCR_B + (2 * NTOT + 2 * d.gc) * 4);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int pos = 32 * (t.a * PT + pt) + j;
@@ -469,9 +500,9 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
           const int nb = 32 * (t.b * NT + n);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 bi = lds4(SCR_B + (nb + 8 * q + 4 * h) * 4);
+            const f32x4 bi = lds4(SCR_B + (nb + 8 * q + 4 * h) * 4), sc = lds4(SCR_B + (NTOT + nb + 8 * q + 4 * h) * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[pt][n][4 * q + e] += bi[e]; s += acc[pt][n][4 * q + e]; }
+            for (int e = 0; e < 4; ++e) { acc[pt][n][4 * q + e] = acc[pt][n][4 * q + e] * sc[e] + bi[e]; s += acc[pt][n][4 * q + e]; }
           }
         }
         const float mean = xor32_sum(s) * (1.0f / d.gc);
@@ -486,8 +517,8 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
           const int c0 = (32 * (t.b * NT + n)) & (d.gc - 1);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 gm = lds4(SCR_B + (NTOT + c0 + 8 * q + 4 * h) * 4);
-            const f32x4 bt = lds4(SCR_B + (NTOT + d.gc + c0 + 8 * q + 4 * h) * 4);
+            const f32x4 gm = lds4(SCR_B + (2 * NTOT + c0 + 8 * q + 4 * h) * 4);
+            const f32x4 bt = lds4(SCR_B + (2 * NTOT + d.gc + c0 + 8 * q + 4 * h) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float y = acc[pt][n][4 * q + e] * rstd * gm[e] + bt[e];
@@ -501,9 +532,9 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
           const int nb = UP ? (n * d.N + 32 * t.b) : 32 * (t.b * NT + n);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x4 bi = lds4(SCR_B + (nb + 8 * q + 4 * h) * 4);
+            const f32x4 bi = lds4(SCR_B + (nb + 8 * q + 4 * h) * 4), sc = lds4(SCR_B + (NTOT + nb + 8 * q + 4 * h) * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[pt][n][4 * q + e] += bi[e];
+            for (int e = 0; e < 4; ++e) acc[pt][n][4 * q + e] = acc[pt][n][4 * q + e] * sc[e] + bi[e];
           }
         }
       }
@@ -524,7 +555,9 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
       }
     }
   }
+  FZ_STAMP(I, 3);
   build_next<I>(tid, p1, c.p);
+  FZ_STAMP(I, 4);
 }
 
 // ---- input layer: 1 -> 64 conv + LN + PReLU (proposed.py:218-225), straight into the image of msfe6_en_in ---------------
@@ -729,6 +762,7 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
   prefetch_w<I + 1>(cx, tid, n.w, n.prm);
   stage_load<nxt_of(I + 1), 2>(cx, tid, n.p);
   sched_pin();
+  FZ_STAMP(I, 0);
 
   if constexpr (d.type == T_INPUT) {
     input_op<I>(cx, tid);

@@ -16,6 +16,9 @@ namespace nutls {
 struct HostTensor {
   std::vector<int> dims;
   std::vector<float> data;  // de-quantised (int8 * scale), exactly the graph's DEQUANTIZE
+  // int8 tensors of the container also keep their raw form: data[k] == q[k] * scales[per-channel ? k / inner : 0]
+  std::vector<int8_t> q;
+  std::vector<float> scales;   // 1 entry (per tensor) or dims[0] entries (per output channel)
   size_t size() const { return data.size(); }
 };
 using WeightMap = std::map<std::string, HostTensor>;

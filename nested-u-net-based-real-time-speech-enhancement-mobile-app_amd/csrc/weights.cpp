@@ -55,6 +55,8 @@ bool parse_weight_blob(const void* blob, size_t n, WeightMap* out, std::string* 
       const int8_t* q = reinterpret_cast<const int8_t*>(c.p + c.off);
       const size_t inner = cnt / t.dims[0];
       for (size_t k = 0; k < cnt; ++k) t.data[k] = static_cast<float>(q[k]) * scales[ns == 1 ? 0 : k / inner];
+      t.q.assign(q, q + cnt);
+      t.scales = scales;
       c.off += cnt + ((4 - cnt % 4) % 4);
     } else {
       *err = "unknown dtype code in " + name;

@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
     "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
+    "nutls_fused_blob_floats", "nutls_fused_pack_blob",
 )
 
 
@@ -83,6 +84,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_fused_num_ops.argtypes = []
     lib.nutls_fused_op_info.argtypes = [c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
     lib.nutls_profile_fused.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
+    lib.nutls_fused_blob_floats.argtypes = []
+    lib.nutls_fused_pack_blob.argtypes = [c.c_void_p, c.c_size_t, fp, c.c_size_t]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:

@@ -222,8 +222,14 @@ def build():
         ntot = N * (2 if kind == K_UP else 1)
         K = (3 * cin) if kind == K_UP else taps * kf * cin
         o["flops"] = 2 * P * (K * N if kind != K_UP else 3 * cin * N)
-        o["w_off"] = W.add((3 * cin * N) if kind == K_UP else K * N, "conv_w", wkey)
-        o["p_off"] = W.add(ntot + 2 * gc + 1, "conv_p", wkey)
+        # int8 weights, MFMA fragment order: per wave task a run of "super-fragments" (4 fragments = one dwordx4 per lane)
+        r32 = o["path"] == P_R32
+        G = cin // (8 if r32 else 16)
+        segw = 3 if kind == K_UP else len(g["seg_b"]) // o["KSt"]
+        nf = segw * (G // o["KSg"]) * o["NT"]
+        wtasks = o["CG"] * o["KSt"] * o["KSg"]
+        o["w_off"] = W.add(wtasks * ((nf + 3) // 4) * 256, "conv_w", wkey)
+        o["p_off"] = W.add(2 * ntot + 2 * gc + 1, "conv_p", wkey)      # bias | gamma | beta | alpha | per-channel weight scale
         if o["path"] == P_X16:
             ks = o["KSt"] * o["KSg"]
             ex = ks * P * (ntot + 4) * 4
