@@ -900,7 +900,11 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   if (!ok) return fail(NUTLS_ERR_ARG, "fused plan (tools/gen_fused_plan.py) does not match the engine's arena layout");
   std::vector<float> blob;
   std::string err;
-  if (!fused_pack_blob(wm, &blob, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
+  if (!fused_pack_blob(wm, &blob, &err)) {
+    // a container with float conv kernels (no int8 payload): fine, it runs on the plan-interpreter kernel (mode 2)
+    if (err.find("not an int8 tensor") != std::string::npos) return NUTLS_OK;
+    return fail(NUTLS_ERR_WEIGHTS, err);
+  }
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, blob.size() * sizeof(float)));
   e->allocs.push_back(p);
@@ -1056,6 +1060,7 @@ static int create_common(const void* weights, size_t n_bytes, int variant, int b
       return fail(NUTLS_ERR_WEIGHTS, std::string("fused plan weights: ") + ex.what());
     }
     if (rc) return rc;
+    if (e->fz_blob) e->mode = 3;          // the default for streaming handles of the LSTM variant
   }
   e->n_cu = prop.multiProcessorCount;
   e->debug["input_layer"] = {e->t_inlayer, 256 * 64};

@@ -116,9 +116,11 @@ class NutlsEngine:
     MODES = {"launches": 0, "graph": 1, "persistent": 2, "fused": 3}
     VARIANTS = {"lstm": 0, "baseline": 1}
 
-    def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: str = "persistent", variant: str = "lstm"):
-        """``mode``: "persistent" (default; one launch per frame, one workgroup per stream),
-        "graph" (one kernel per layer, hipGraph replay) or "launches" (one kernel per layer).
+    def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: Optional[str] = None, variant: str = "lstm"):
+        """``mode``: "fused" (default for the LSTM variant: one launch per frame, one workgroup per stream, every op its
+        own specialised instruction stream), "persistent" (default for the baseline variant: one launch per frame, one
+        workgroup per stream interprets the device-resident plan), "graph" (one kernel per layer, hipGraph replay) or
+        "launches" (one kernel per layer).
         ``variant``: "lstm" (NUNet-TLS-LSTM, trained weights ship in weights/) or "baseline"
         (dilated-dense bottleneck; no trained weights exist -- pass a container, e.g.
         ``weights.write_blob(weights.synthetic_weights("baseline"))``)."""
@@ -138,7 +140,13 @@ class NutlsEngine:
         pin, pout = ctypes.c_void_p(), ctypes.c_void_p()
         _check(self._lib, self._lib.nutls_io_buffers(self._h, ctypes.byref(pin), ctypes.byref(pout)))
         self.io_in_ptr, self.io_out_ptr = pin.value, pout.value
-        self.set_mode(mode)
+        if mode is not None:
+            self.set_mode(mode)
+        else:       # library default: fused for the LSTM variant when the container holds int8 conv kernels, else persistent
+            try:
+                self.set_mode("fused" if variant == "lstm" else "persistent")
+            except ValueError:
+                self.set_mode("persistent")
 
     # -- lifetime --------------------------------------------------------------------------
     def close(self):
@@ -325,7 +333,7 @@ class NutlsRunner:
 
     signature_key = "nutls_lstm_sm"
 
-    def __init__(self, weights=None, device: int = 0, mode: str = "persistent", variant: str = "lstm"):
+    def __init__(self, weights=None, device: int = 0, mode: Optional[str] = None, variant: str = "lstm"):
         """``variant="baseline"`` mirrors the 'nutls' signature of converter_nunet_tls.py:1542 (208 states;
         interpreter_nunet_tls.py:549) -- weights must be supplied, none are shipped."""
         self.engine = NutlsEngine(weights, batch=1, device=device, mode=mode, variant=variant)

@@ -103,19 +103,42 @@ def test_batch_256_synthetic_vs_oracle():
     eng.close()
 
 
-def test_three_execution_modes_agree(clip):
-    """persistent kernel == per-layer hipGraph replay == per-layer plain launches (the per-layer
-    modes are bit-identical to each other; the persistent kernel splits K across waves, so it may
-    differ from them in the last bits only)."""
-    a, b, c = (NutlsEngine(batch=2, mode=m) for m in ("graph", "launches", "persistent"))
+def test_execution_modes_agree(clip):
+    """fused kernel == plan-interpreter kernel == per-layer hipGraph replay == per-layer plain launches (the
+    per-layer modes are bit-identical to each other; the one-launch kernels split K across waves -- and the fused
+    one applies the int8 weight scale after the sum instead of before it -- so they may differ from them in the
+    last bits only).  Default mode of the LSTM variant = fused."""
+    a, b, c, d = (NutlsEngine(batch=2, mode=m) for m in ("graph", "launches", "persistent", "fused"))
+    dflt = NutlsEngine(batch=2)
+    assert dflt.mode == "fused"
     for i in range(5):
         x = clip["mags_in"][2 * i:2 * i + 2]
-        oa, ob, oc = a.step(x), b.step(x), c.step(x)
+        oa, ob, oc, od = a.step(x), b.step(x), c.step(x), d.step(x)
         assert np.array_equal(oa, ob)
         assert rms(oa, oc) < 1e-6
-    for name in ("msfe6_ee_prev1", "msfe4_dd3_prev2", "msfe3_de_prev1", "state_c"):
+        assert rms(oa, od) < 1e-6
+        assert np.array_equal(od, dflt.step(x))
+    for base, shp in T.state_specs():
+        name = base if len(shp) == 1 else base.format("prev")
         np.testing.assert_allclose(a.state_get(name), c.state_get(name), rtol=1e-4, atol=1e-4, err_msg=name)
-    a.close(); b.close(); c.close()
+        np.testing.assert_allclose(a.state_get(name), d.state_get(name), rtol=1e-4, atol=1e-4, err_msg=name)
+    for e in (a, b, c, d, dflt):
+        e.close()
+
+
+def test_fused_mode_needs_the_int8_container(clip):
+    """The fused kernel keeps the conv kernels int8 on the device (what the reference's .tflite stores); a container
+    with float conv weights still works, on the plan-interpreter kernel, and says so when asked for mode 3."""
+    from nunet_amd.weights import load_weights, write_blob
+    blob = write_blob(load_weights())                   # the same parameters, de-quantised to float32
+    eng = NutlsEngine(blob, batch=1)
+    assert eng.mode == "persistent"
+    with pytest.raises(ValueError):
+        eng.set_mode("fused")
+    ref = NutlsEngine(batch=1)
+    for i in range(3):
+        assert rms(eng.step(clip["mags_in"][i:i + 1]), ref.step(clip["mags_in"][i:i + 1])) < 1e-6
+    eng.close(); ref.close()
 
 
 def test_torch_device_tensors_zero_copy(clip):
@@ -269,11 +292,30 @@ def test_baseline_signature_runner(baseline_weights):
     assert out["ddb_cur6"].shape == (1, 32, 4, 192)
 
 
-def test_config5_size_1024_streams_properties():
-    """BASELINE config 5 size (B = 1024, four streams per CU): size-independent properties -- identical inputs
+def test_baseline_variant_batch_256_vs_oracle(baseline_weights):
+    """BASELINE config 3 at its full size: 256 streams of the dilated-dense variant, every output vs oracle B."""
+    w, blob = baseline_weights
+    B, steps = 256, 4
+    mags = synthetic_mags(B, steps, seed=78)
+    eng = NutlsEngine(blob, batch=B, variant="baseline")
+    ref = NutlsRef(w, batch=B, variant="baseline")
+    for s in range(steps):
+        out = eng.step(mags[s])
+        want = ref.step(mags[s]).numpy()
+        assert rms(out, want) < 1e-4 * max(1.0, float(np.abs(want).max())), s
+    for name in ("msfe6_ee_prev1", "ddb_prev3", "msfe4_de_ddb_prev_in", "msfe6_dd_prev6"):
+        a, b = eng.state_get(name).reshape(B, -1), ref.state[name].numpy().reshape(B, -1)
+        assert rms(a, b) < 2e-4 * max(1.0, float(np.abs(b).max())), name
+    eng.close()
+
+
+@pytest.mark.parametrize("B", [1024, 2048])
+def test_config_size_streams_properties(B):
+    """BASELINE config 5 size (B = 1024) and the total of config 4 (B = 2048 = 8 x 256) on one GPU, four / eight
+    streams per CU: size-independent properties -- identical inputs
     give bit-identical outputs wherever the stream sits, silence stays silent-ish and finite, and a handful of
     streams checked against the oracle."""
-    B, steps = 1024, 4
+    steps = 4
     rng = np.random.default_rng(5)
     base = (0.25 * np.abs(rng.standard_normal((steps, 8, 256)))).astype(np.float32)
     idx = rng.integers(0, 8, size=B)
