@@ -2,14 +2,15 @@
 """Headline benchmark: NUNet-TLS-LSTM frame step, frames/s (one frame = one 256-bin magnitude
 vector of one stream = one 256-sample hop of the 512-pt / 50 % STFT).
 
-    python bench.py --gpus 1 --steps 200 --warmup 32
+    python bench.py                       # 1 GPU, 200 steps, 32 warm-up
+    python bench.py --gpus N              # spawns N ranks itself (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # what the driver does
 
-Workload (BASELINE.json configs[1]): NUNet-TLS-LSTM, real (de-quantised) weights, B = 256
-independent streams per GPU, synthetic magnitudes 0.25*|N(0,1)| (default_rng(1234 + rank)),
+Workload (BASELINE.json configs[1]): NUNet-TLS-LSTM, the reference's trained weights, B = 256
+independent streams per GPU, synthetic magnitudes 0.25*|N(0,1)| (default_rng(1234 + first stream of the rank)),
 zero-initialised state, inputs resident in HBM before the timed region.  A "step" is one pass
-of the hot path over the batch (256 frames per GPU).  N > 1 shards streams over ranks (weak
+of the hot path over the batch (256 frames per GPU).  N > 1 shards the N*256 streams over ranks (weak
 scaling, no data-path collective; RCCL only reduces the timing / frame counters).
 
 Prints ONE JSON line (rank 0).
@@ -17,8 +18,12 @@ Prints ONE JSON line (rank 0).
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,9 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOPS_PER_FRAME = 2 * 73_967_252
-PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (2.4 GHz)
 PEAK_HBM_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E spec peak
 HOP_SECONDS = 0.016
+PKG = os.path.join(ROOT, "nested-u-net-based-real-time-speech-enhancement-mobile-app_amd")
 
 
 def synthetic_pool(batch, n, seed):
@@ -38,25 +44,51 @@ def synthetic_pool(batch, n, seed):
     return (0.25 * np.abs(rng.standard_normal((n, batch, 256)))).astype(np.float32)
 
 
-def cpu_baseline(sample_batch=32, budget_s=12.0):
-    """The oracle (torch-CPU restatement) timed on this box's host cores: bounded sample.
-    8 threads: on the 2 x 64-core EPYC host more threads are *slower* for these small GEMMs
-    (measured 606 frames/s at 8 threads, 240 at 32, 75 at 64)."""
+def kernel_source_sha16(mode):
+    """Identity of the kernel a PMC traffic record belongs to: hash of the sources of the step kernel."""
+    files = {"fused": ["fused_step.hip", "fused_plan.hpp", "fused_plan_lstm.inc"], "persistent": ["megakernel.hip", "ddb_device.hpp"]}.get(mode, [])
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(PKG, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16] if files else None
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=12.0):
+    """the oracle (torch-CPU restatement of the reference's step) on this box's host cores, B = 1 and
+    B = 64, bounded sample.  Threads: min(8, cores) -- on the 2 x 64-core EPYC host of the GPU boxes more threads
+    are *slower* for these small GEMMs (measured 606 frames/s at 8 threads, 240 at 32, 75 at 64)."""
     import torch
     from oracle.nutls_ref import NutlsRef
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
-    ref = NutlsRef(batch=sample_batch)
-    x = synthetic_pool(sample_batch, 4, 99)
-    ref.step(x[0])                        # warm-up (allocations, thread pool)
-    t0, n = time.time(), 0
-    while True:
-        ref.step(x[n % 4])
-        n += 1
-        if time.time() - t0 > budget_s or n >= 512:
-            break
-    dt = time.time() - t0
-    return {"value": round(sample_batch * n / dt, 1), "unit": "frames/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": "%d steps of %d streams (oracle/nutls_ref.py, torch-CPU fp32), %.1f s" % (n, sample_batch, dt)}
+    threads = min(8, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    res = {}
+    for sb, share in ((1, 0.35), (64, 0.65)):
+        ref = NutlsRef(batch=sb)
+        x = synthetic_pool(sb, 4, 99)
+        ref.step(x[0])                        # warm-up (allocations, thread pool)
+        t0, n = time.time(), 0
+        while True:
+            ref.step(x[n % 4])
+            n += 1
+            if time.time() - t0 > budget_s * share or n >= 512:
+                break
+        dt = time.time() - t0
+        res[sb] = (sb * n / dt, n, dt)
+    return {"value": round(res[64][0], 1), "unit": "frames/s", "cores": threads, "kind": "port",
+            "value_b1": round(res[1][0], 1), "host_cores": os.cpu_count(), "cpu": cpu_model_name(),
+            "sample": "oracle/nutls_ref.py (torch-CPU fp32): %d steps of 64 streams in %.1f s (value), %d steps of 1 stream in %.1f s (value_b1), %d threads"
+                      % (res[64][1], res[64][2], res[1][1], res[1][2], threads)}
 
 
 def bench_offline(args, rank, world, local_rank):
@@ -101,13 +133,41 @@ def parity_check(eng_cls, pool, n_streams=4, steps=6):
     return float(np.sqrt(se / steps))
 
 
+class _LauncherSelfTestEngine:
+    """CPU stand-in used ONLY by `--selftest-launcher` (tests/test_sharding.py): exercises this file's rank plumbing
+    (self-launch, stream sharding, barrier, counter reduction, the JSON line) without a GPU.  It computes nothing of the
+    model -- it is not a fallback of the product path."""
+
+    def __init__(self, batch):
+        self.batch = batch
+
+    def step(self, x):
+        return x * 0.5
+
+    def close(self):
+        pass
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
-    ap.add_argument("--mode", default="persistent", choices=["persistent", "graph", "launches"])
+    ap.add_argument("--mode", default=None, choices=["fused", "persistent", "graph", "launches"],
+                    help="default: fused (LSTM variant) / persistent (baseline variant)")
     ap.add_argument("--variant", default="lstm", choices=["lstm", "baseline"],
                     help="baseline = dilated-dense bottleneck with synthetic weights, seed 4321 (BASELINE configs[2])")
     ap.add_argument("--host-io", action="store_true",
@@ -117,8 +177,12 @@ def main():
     ap.add_argument("--offline", type=int, default=0, metavar="T",
                     help="offline / block mode: ONE utterance, a step = one block of T consecutive frames (frames/s of that utterance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-json", default="", help="write the per-launch HIP-event timeline here")
+    ap.add_argument("--profile-json", default="", help="write the per-op timeline here")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -127,42 +191,62 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N ranks with torch.distributed.run" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    selftest = args.selftest_launcher
+    if not selftest:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("rank %d has no GPU: %d visible" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if selftest:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
-    import nunet_amd
-    from nunet_amd.sharding import reduce_throughput
+    from nunet_amd.sharding import reduce_throughput, stream_range
 
     if args.offline:
         return bench_offline(args, rank, world, local_rank)
-    B = args.batch
-    weights = None
-    if args.variant == "baseline":
-        from nunet_amd.weights import synthetic_weights, write_blob
-        weights = write_blob(synthetic_weights("baseline", seed=4321))
-    eng = nunet_amd.NutlsEngine(weights, batch=B, device=local_rank, mode=args.mode, variant=args.variant)
-    pool_host = synthetic_pool(B, 8, 1234 + rank)
-    pool = torch.from_numpy(pool_host).cuda()            # inputs resident in HBM
-    out = torch.empty(B, 256, device="cuda")
-    stream = torch.cuda.current_stream()
+    # the job is world * batch independent streams; this rank owns a contiguous slice of them
+    lo, hi = stream_range(world * args.batch, rank, world)
+    B = hi - lo
+    device = torch.device("cpu") if selftest else torch.device("cuda", local_rank)
+    mode = args.mode or ("fused" if args.variant == "lstm" else "persistent")
+    if selftest:
+        eng = _LauncherSelfTestEngine(B)
+    else:
+        import nunet_amd
+        weights = None
+        if args.variant == "baseline":
+            from nunet_amd.weights import synthetic_weights, write_blob
+            weights = write_blob(synthetic_weights("baseline", seed=4321))
+        eng = nunet_amd.NutlsEngine(weights, batch=B, device=local_rank, mode=mode, variant=args.variant)
+    pool_host = synthetic_pool(B, 8, 1234 + lo)
+    pool = torch.from_numpy(pool_host).to(device)            # inputs resident in HBM
+    out = torch.empty(B, 256, device=device)
+
+    def sync():
+        if not selftest:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     pcm = pcm_out = None
     if args.frontend:        # PCM hops resident in HBM: white noise at speech level
-        pcm = (0.05 * torch.randn(8, B, 256, generator=torch.Generator().manual_seed(1234 + rank))).cuda()
+        pcm = (0.05 * torch.randn(8, B, 256, generator=torch.Generator().manual_seed(1234 + lo))).cuda()
         pcm_out = torch.empty(B, 256, device="cuda")
 
     def one_step(s):
+        if selftest:
+            out.copy_(eng.step(pool[s % 8]))
+            return out
         if args.frontend:
             return eng.enhance_hop(pcm[s % 8], "edge", pcm_out)
         if args.host_io:
@@ -175,109 +259,39 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(s)
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     barrier()
     frames = B * args.steps
-    total_frames, max_elapsed = reduce_throughput(frames, elapsed, dist if world > 1 else None,
-                                                  torch.device("cuda", local_rank))
+    total_frames, max_elapsed = reduce_throughput(frames, elapsed, dist if world > 1 else None, device)
     assert args.host_io or bool(torch.isfinite(pcm_out if args.frontend else out).all())
 
     if rank == 0:
-        import re
-        plan = eng.launch_plan()
-        step_flops = sum(p["flops"] for p in plan)
-
-        def is_enc_conv(p):   # the 26 encoder (2,3) stride-2 convs = the north-star's "encoder conv stack"
-            return re.search(r"_en\d?_conv\d$", p["layer"]) is not None
-
-        if args.mode == "persistent":
-            # The whole step is ONE kernel (nutls_stream_step_kernel).  Its average duration over the
-            # timed region comes from HIP events recorded on the stream it is launched on.
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            ev[0].record(stream)
-            for s in range(args.steps):
-                eng.step(pool[s % 8], out)
-            ev[1].record(stream)
-            torch.cuda.synchronize()
-            avg_ms = ev[0].elapsed_time(ev[1]) / args.steps
-            achieved = step_flops / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):           # HBM bytes per launch from the committed rocprofv3 PMC passes
-                t = json.load(open(tpath))
-                if t.get("batch") == B and t.get("mode") == args.mode:
-                    traffic = t["traffic_bytes"]
-            roofline = {"kernel": "nutls_stream_step_kernel", "bound": "mfma", "achieved": round(achieved, 2),
-                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": traffic, "launches_per_step": 1, "avg_launch_ms": round(avg_ms, 5),
-                        "flops_per_launch": step_flops}
-            # in-kernel timeline of workgroup 0 (wall clock stamps at every layer boundary)
-            reps = 10
-            for _ in range(2):
-                eng.profile_persistent()
-            us = np.zeros(len(plan))
-            for _ in range(reps):
-                us += eng.profile_persistent()
-            ms = us / reps / 1e3
-        else:
-            # one kernel per layer: per-launch HIP events on the library stream
-            eng.set_mode("launches")
-            reps = 10
-            ms = np.zeros(len(plan))
-            for _ in range(2):
-                eng.profile_step()
-            for _ in range(reps):
-                ms += eng.profile_step()
-            ms /= reps
-        fam = {}
-        for p, t in zip(plan, ms):
-            f = fam.setdefault(p["family"], {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
-            f["ms"] += t; f["n"] += 1; f["flops"] += p["flops"]; f["bytes"] += p["bytes"]
-        if args.mode != "persistent":
-            dom = max(fam, key=lambda k: fam[k]["ms"])
-            d = fam[dom]
-            avg_ms = d["ms"] / d["n"]
-            achieved = d["flops"] / d["n"] / (avg_ms * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                        "launches_per_step": d["n"], "avg_launch_ms": round(avg_ms, 5),
-                        "share_of_step": round(d["ms"] / ms.sum(), 3)}
-        enc = [(p, t) for p, t in zip(plan, ms) if is_enc_conv(p)]
-        enc_ms = sum(t for _, t in enc)
-        enc_bytes = sum(p["bytes"] for p, _ in enc)
-        enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
-        encoder_stack = {"layers": len(enc), "ms_per_step": round(enc_ms, 4), "achieved": round(enc_gbs, 1),
-                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(enc_gbs / PEAK_HBM_GBS, 4),
-                         "tflops": round(sum(p["flops"] for p, _ in enc) / (enc_ms * 1e-3) / 1e12, 2)}
-        if args.profile_json:
-            with open(args.profile_json, "w") as f:
-                json.dump({"batch": B, "mode": args.mode, "launches": [dict(p, ms=float(t)) for p, t in zip(plan, ms)],
-                           "families": fam, "timeline_step_ms": float(ms.sum())}, f, indent=1)
         value = total_frames / max_elapsed
         line = {
             "metric": "STFT frames/sec (512-pt, 50% hop) through the NUNet-TLS frame step",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * max_elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic magnitudes 0.25*|N(0,1)|, " + ("trained weights de-quantised from the reference's nutls_lstm.tflite"
+            "data": "synthetic magnitudes 0.25*|N(0,1)|, " + ("trained weights of the reference's nutls_lstm.tflite (int8 conv kernels kept int8 on the device, scale applied in fp32)"
                                                                  if args.variant == "lstm" else "synthetic weights (no trained baseline weights exist)"),
-            "config": {"workload": ("NUNet-TLS-LSTM (proposed) frame step, batch=%d streams per GPU, 256-bin frames (BASELINE configs[1])" % B)
+            "config": {"workload": ("NUNet-TLS-LSTM (proposed) frame step, batch=%d streams per GPU, 256-bin frames (BASELINE configs[1])" % args.batch)
                        if args.variant == "lstm" else
-                       ("NUNet-TLS dilated-dense baseline frame step, synthetic weights seed 4321, batch=%d streams per GPU (BASELINE configs[2])" % B),
+                       ("NUNet-TLS dilated-dense baseline frame step, synthetic weights seed 4321, batch=%d streams per GPU (BASELINE configs[2])" % args.batch),
                        "variant": args.variant, "host_io": bool(args.host_io), "stft_istft_on_gpu": bool(args.frontend),
-                       "streams_per_gpu": B, "total_streams": B * world, "parallelism": "stream-sharded x%d" % world,
-                       "mode": args.mode, "layers_per_step": len(plan)},
+                       "streams_per_gpu": args.batch, "total_streams": total_frames // args.steps, "parallelism": "stream-sharded x%d" % world,
+                       "mode": mode},
             "rtf_per_stream": round(1e3 * max_elapsed / args.steps / 16.0, 5),
             "tflops": round(value * FLOPS_PER_FRAME / 1e12, 2),
             "frac_f32_peak": round(value * FLOPS_PER_FRAME / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4),
-            "roofline": roofline,
-            "encoder_conv_stack": encoder_stack,
         }
+        if not selftest:
+            line.update(kernel_report(args, eng, pool, out, B, mode))
         if args.host_io:
             line["step_latency_ms"] = line["ms_per_step"]
             line["real_time_budget_ms"] = 16.0
-        if not args.no_cpu_baseline and args.variant == "lstm":
+        if not selftest and not args.no_cpu_baseline and args.variant == "lstm":
+            import nunet_amd
             line["cpu_baseline"] = cpu_baseline()
             line["parity_rms_vs_oracle"] = parity_check(nunet_amd.NutlsEngine, pool_host)
         print(json.dumps(line))
@@ -285,6 +299,86 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_report(args, eng, pool, out, B, mode):
+    """roofline of the dominant kernel + the encoder conv stack (north-star target) from the in-kernel timeline."""
+    import torch
+    stream = torch.cuda.current_stream()
+    plan = eng.launch_plan()                       # per layer: algorithmic flops / bytes for the handle's batch
+    step_flops = sum(p["flops"] for p in plan)
+    by_layer = {p["layer"].split("#")[0]: {"flops": 0.0, "bytes": 0.0} for p in plan}
+    for p in plan:
+        by_layer[p["layer"].split("#")[0]]["flops"] += p["flops"]
+        by_layer[p["layer"].split("#")[0]]["bytes"] += p["bytes"]
+    rep = {}
+    one_launch = mode in ("fused", "persistent")
+    if one_launch:
+        # The whole step is ONE kernel.  Its average duration over the timed region: HIP events on the launch stream.
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record(stream)
+        for s in range(args.steps):
+            eng.step(pool[s % 8], out)
+        ev[1].record(stream)
+        torch.cuda.synchronize()
+        avg_ms = ev[0].elapsed_time(ev[1]) / args.steps
+        achieved = step_flops / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):     # HBM bytes per launch from rocprofv3 PMC passes -- only if they were taken on THIS kernel
+            t = json.load(open(tpath))
+            if t.get("batch") == B and t.get("mode") == mode and t.get("kernel_source_sha16") == kernel_source_sha16(mode):
+                traffic = t["traffic_bytes"]
+        rep["roofline"] = {"kernel": "nutls_fused_step_kernel" if mode == "fused" else "nutls_stream_step_kernel", "bound": "mfma",
+                           "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "launches_per_step": 1,
+                           "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": step_flops}
+        # in-kernel timeline of workgroup 0 (wall clock stamps at every op boundary)
+        prof = eng.profile_fused if mode == "fused" else eng.profile_persistent
+        names = [p["layer"] for p in (eng.fused_plan() if mode == "fused" else plan)]
+        for _ in range(2):
+            prof()
+        us = np.zeros(len(names))
+        reps = 10
+        for _ in range(reps):
+            us += prof()
+        ms = us / reps / 1e3
+    else:
+        eng.set_mode("launches")
+        names = [p["layer"] for p in plan]
+        ms = np.zeros(len(plan))
+        for _ in range(2):
+            eng.profile_step()
+        for _ in range(10):
+            ms += eng.profile_step()
+        ms /= 10
+        fam = {}
+        for p, t in zip(plan, ms):
+            f = fam.setdefault(p["family"], {"ms": 0.0, "n": 0, "flops": 0.0})
+            f["ms"] += t; f["n"] += 1; f["flops"] += p["flops"]
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        d = fam[dom]
+        avg_ms = d["ms"] / d["n"]
+        achieved = d["flops"] / d["n"] / (avg_ms * 1e-3) / 1e12
+        rep["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": d["n"], "avg_launch_ms": round(avg_ms, 5), "share_of_step": round(d["ms"] / ms.sum(), 3)}
+    # The 26 encoder (2,3) stride-2 convs = the north-star's "encoder conv stack".  In the one-launch modes the stamps are
+    # workgroup 0's, i.e. the time ONE resident stream per CU needs; min(B, #CUs) streams run concurrently.
+    resident = min(B, 256) if one_launch else B
+    enc_ms = sum(t for n, t in zip(names, ms) if re.search(r"_en\d?_conv\d$", n.split("#")[0]))
+    enc = [v for k, v in by_layer.items() if re.search(r"_en\d?_conv\d$", k)]
+    enc_bytes = sum(v["bytes"] for v in enc) / B * resident
+    enc_flops = sum(v["flops"] for v in enc) / B * resident
+    enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
+    rep["encoder_conv_stack"] = {"layers": len(enc), "ms_per_step": round(float(enc_ms), 4), "achieved": round(enc_gbs, 1),
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(enc_gbs / PEAK_HBM_GBS, 4),
+                                 "tflops": round(enc_flops / (enc_ms * 1e-3) / 1e12, 2), "concurrent_streams": resident}
+    if args.profile_json:
+        with open(args.profile_json, "w") as f:
+            json.dump({"batch": B, "mode": mode, "timeline_step_ms": float(ms.sum()),
+                       "ops": [{"layer": n, "ms": float(t), **by_layer.get(n.split("#")[0], {})} for n, t in zip(names, ms)]}, f, indent=1)
+    return rep
 
 
 if __name__ == "__main__":

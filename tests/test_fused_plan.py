@@ -1,0 +1,100 @@
+"""CPU tests of the fused kernel's host side: the committed static schedule is what tools/gen_fused_plan.py writes, and the
+weight blob the library packs (conv kernels int8 in MFMA fragment order) decodes -- with the walk the kernel uses -- back
+to exactly the int8 payload / scales / biases of the container."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_plan_is_current():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_fused_plan.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _perm(o):
+    n = o["N"]
+    if o["kind"] == 2 and n == 64:       # sub-pixel shuffle folded into the channel order
+        return np.array([2 * c + r for r in range(2) for c in range(32)])
+    if o["kind"] == 2 and n == 128:
+        return np.array([r * 64 + (c2 % 32) * 2 + c2 // 32 for r in range(2) for c2 in range(64)])
+    return np.arange(n)
+
+
+def test_blob_packing_round_trips_the_container():
+    import nunet_amd  # noqa: F401
+    from nunet_amd.runner import load_library, _fptr
+    from nunet_amd.weights import DEFAULT_WEIGHTS, parse_blob, read_blob
+    lib = load_library()
+    blob = read_blob(DEFAULT_WEIGHTS)
+    n = lib.nutls_fused_blob_floats()
+    out = np.zeros(n, np.float32)
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    assert lib.nutls_fused_pack_blob(buf, len(blob), _fptr(out), n) == 0, lib.nutls_last_error()
+    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_lstm.json")))
+    assert plan["blob_floats"] == n
+    W, Wq = parse_blob(blob), parse_blob(blob, dequantize=False)
+    lane = np.arange(64)
+    n_conv = 0
+    for o in plan["ops"]:
+        if o["type"] != 1:
+            continue
+        n_conv += 1
+        r32, up = o["path"] == 0, o["kind"] == 4
+        cin, N = o["cin"], o["N"]
+        G = cin // (8 if r32 else 16)
+        GW = G // o["KSg"]
+        segw = 3 if up else o["nseg"] // o["KSt"]
+        nf = segw * GW * o["NT"]
+        nsf = (nf + 3) // 4
+        wt = o["CG"] * o["KSt"] * o["KSg"]
+        raw = out[o["w_off"]:o["w_off"] + wt * nsf * 256].view(np.int8).reshape(wt, nsf, 64, 16)
+        q, sc = Wq[o["wkey"] + ".w"]
+        perm = _perm(o)
+        rec = np.full(q.shape, 99, np.int32)
+        for task in range(wt):
+            ct, ks = task % o["CG"], task // o["CG"]
+            ks_g, ks_t = ks % o["KSg"], ks // o["KSg"]
+            for f in range(nf):          # the walk of conv_x16 / conv_r32 (fused_step.hip)
+                if r32:
+                    nt, sgi = f % o["NT"], f // o["NT"]
+                    sg, g, T = sgi // G, sgi % G, ct * o["NT"] + nt
+                    npk, c0 = 32 * T + (lane & 31), 8 * g + 4 * (lane >> 5)
+                else:
+                    sg, g, T = ks_t * segw + f // GW, ks_g * GW + f % GW, ct
+                    npk, c0 = 16 * T + (lane & 15), 16 * g + 4 * (lane >> 4)
+                t, kw = o["seg_tk"][sg] >> 2, o["seg_tk"][sg] & 3
+                for qq in range(4):
+                    rec[perm[npk], t, kw, c0 + qq] = raw[task, f // 4, :, (f % 4) * 4 + qq]
+        assert np.array_equal(rec, q.astype(np.int32)), o["name"]          # every weight covered, every byte right
+        ntot, gc = N * (2 if up else 1), o["gc"]
+        blk = out[o["p_off"]:o["p_off"] + 2 * ntot + 2 * gc + 1]
+        assert np.array_equal(blk[:N], W[o["wkey"] + ".b"][perm]), o["name"]
+        assert np.array_equal(blk[ntot:ntot + N], sc[perm] if sc.size > 1 else np.full(N, sc[0], np.float32)), o["name"]
+        if o["ln"]:
+            assert np.array_equal(blk[2 * ntot:2 * ntot + gc], W[o["wkey"] + ".gamma"].reshape(-1))
+            assert np.array_equal(blk[2 * ntot + gc:2 * ntot + 2 * gc], W[o["wkey"] + ".beta"].reshape(-1))
+            assert blk[2 * ntot + 2 * gc] == W[o["wkey"] + ".alpha"].reshape(-1)[0]
+    assert n_conv == 128
+
+
+def test_plan_images_fit_lds_and_ops_cover_the_network():
+    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_lstm.json")))
+    ops = plan["ops"]
+    assert len(ops) == 154 and sum(o["type"] == 2 for o in ops) == 13 and sum(o["type"] == 3 for o in ops) == 12
+    flops = sum(o["flops"] for o in ops)
+    # 147.9 MFLOP per frame and stream; the plan counts the conv ops only (CTFA 1x1s as lowered by TFLite: 4.2 M, LSTM + Dense 0.3 M)
+    assert 0.96 < flops / (2 * 73_967_252) < 1.0
+    for o in ops:
+        if o["type"] == 1:
+            lim = o["ex_b"] if o["path"] == 1 else 160 * 1024 - 8192
+            assert o["img"]["bytes"] <= lim, o["name"]
+            for p in o["parts"]:
+                assert p["la"] in (1, 2)

@@ -62,3 +62,29 @@ def test_counter_reduction_world2_gloo():
     assert (lo0, hi1) == (0, 2051) and hi0 == lo1
     assert tot0 == tot1 == 2051 * 10          # whole-job frames
     assert mx0 == mx1 == 2.0                  # max over ranks
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_py_rank_plumbing_two_ranks_gloo(launcher):
+    """`python bench.py --gpus 2` with no launcher around it must spawn its two ranks itself (and keep working under
+    torch.distributed.run, which is how the driver starts it): self-launch, rank -> stream slice, barrier, counter
+    reduction and the single JSON line of rank 0 -- on CPU over gloo with a stand-in engine (no model arithmetic)."""
+    import json
+    import subprocess
+    args = ["--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "6", "--selftest-launcher", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if launcher == "self":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # ONE line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["warmup"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["streams_per_gpu"] == 6 and j["config"]["total_streams"] == 12
+    assert j["unit"] == "frames/s" and j["value"] > 0
+    assert abs(j["value"] - 12 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-3      # whole-job frames / max-over-ranks time
