@@ -123,6 +123,10 @@ int nutls_use_graph(nutls_handle* h, int enable);
 int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
 int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, size_t n_floats);
 
+/* Every state tensor of ONE stream, concatenated in nutls_state_info order (n_floats = sum of the per-stream sizes):
+ * what the signature runner hands back per frame, with a single device-to-host copy. */
+int nutls_state_get_all(nutls_handle* h, int stream_idx, float* host_buf, size_t n_floats);
+
 /* Enumerate the state tensors: count, then name + per-stream dims (F, C) or (21, 1). */
 int nutls_state_count(nutls_handle* h);
 int nutls_state_info(nutls_handle* h, int index, const char** name, int* dim0, int* dim1);

@@ -5,6 +5,7 @@
 // optional hipGraph capture of that plan.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <exception>
 #include <cstdio>
@@ -249,8 +250,13 @@ static int prep_conv(Engine* e, const WeightMap& wm, const std::string& layer, c
   const HostTensor* w = find(wm, layer + ".w", &err);
   const HostTensor* b = find(wm, layer + ".b", &err);
   if (!w || !b) return fail(NUTLS_ERR_WEIGHTS, err);
-  if (w->dims.size() != 4 || w->dims[3] != sh.cin || static_cast<int>(perm.size()) != 32 * sh.nt)
-    return fail(NUTLS_ERR_WEIGHTS, "unexpected weight shape for " + layer);
+  int max_kw = 0;
+  for (const auto& tk : taps) max_kw = std::max(max_kw, tk.second);
+  int max_perm = -1;
+  for (int q : perm) max_perm = std::max(max_perm, q);
+  if (w->dims.size() != 4 || w->dims[3] != sh.cin || static_cast<int>(perm.size()) != 32 * sh.nt || w->dims[0] <= max_perm ||
+      w->dims[1] < sh.tt || w->dims[2] <= max_kw || static_cast<int>(b->size()) <= max_perm)
+    return fail(NUTLS_ERR_WEIGHTS, "unexpected weight / bias shape for " + layer);
   ConvLayerW cw{};
   int rc = upload(e, pack_conv_weights(*w, perm, taps, sh.tt, sh.cin, sh.nt), &cw.wpk);
   if (rc) return rc;
@@ -263,7 +269,8 @@ static int prep_conv(Engine* e, const WeightMap& wm, const std::string& layer, c
     const HostTensor* bt = find(wm, layer + ".beta", &err);
     const HostTensor* al = find(wm, layer + ".alpha", &err);
     if (!g || !bt || !al) return fail(NUTLS_ERR_WEIGHTS, err);
-    if (static_cast<int>(g->size()) != 32 * sh.g) return fail(NUTLS_ERR_WEIGHTS, "unexpected LayerNorm width for " + layer);
+    if (static_cast<int>(g->size()) != 32 * sh.g || static_cast<int>(bt->size()) != 32 * sh.g || al->size() < 1)
+      return fail(NUTLS_ERR_WEIGHTS, "unexpected LayerNorm / PReLU size for " + layer);
     if ((rc = upload(e, g->data, &cw.gamma))) return rc;
     if ((rc = upload(e, bt->data, &cw.beta))) return rc;
     cw.alpha = al->data[0];
@@ -316,7 +323,8 @@ static int prep_ddb_weights(Engine* e, const WeightMap& wm) {
       const HostTensor* tw = find(wm, n + ".w", &err);
       const HostTensor* tb = find(wm, n + ".b", &err);
       const HostTensor* ta = find(wm, n + ".alpha", &err);
-      if (!tw || !tb || !ta || tw->dims.size() != 4) return fail(NUTLS_ERR_WEIGHTS, err.empty() ? "bad ddb conv " + n : err);
+      if (!tw || !tb || !ta || tw->dims.size() != 4 || tw->dims[1] != 2 || tw->dims[2] != 3 || static_cast<int>(tb->size()) != tw->dims[0] || ta->size() < 1)
+        return fail(NUTLS_ERR_WEIGHTS, err.empty() ? "bad ddb conv " + n : err);
       int r;
       if ((r = upload(e, ohwi_to_tkio(*tw), w))) return r;
       if ((r = upload(e, tb->data, bias))) return r;
@@ -336,8 +344,11 @@ static int prep_ddb_weights(Engine* e, const WeightMap& wm) {
       const HostTensor* bt = find(wm, n + ".beta", &err);
       const HostTensor* al = find(wm, n + ".alpha", &err);
       if (!wg || !bg || !w1 || !b1 || !gm || !bt || !al) return fail(NUTLS_ERR_WEIGHTS, err);
-      if (wg->dims.size() != 4 || wg->dims[3] != k) return fail(NUTLS_ERR_WEIGHTS, "unexpected grouped-conv shape " + n);
+      if (wg->dims.size() != 4 || wg->dims[3] != k || wg->dims[1] != 2 || wg->dims[2] != 3) return fail(NUTLS_ERR_WEIGHTS, "unexpected grouped-conv shape " + n);
       const int G = wg->dims[0];
+      if (w1->size() != static_cast<size_t>(G) * G || static_cast<int>(bg->size()) != G || static_cast<int>(b1->size()) != G ||
+          static_cast<int>(gm->size()) != G || static_cast<int>(bt->size()) != G || al->size() < 1)
+        return fail(NUTLS_ERR_WEIGHTS, "unexpected 1x1 / LayerNorm size in " + n);
       if ((rc = upload(e, ohwi_to_tkio(*wg), &W.wg[k - 1]))) return rc;
       if ((rc = upload(e, bg->data, &W.bg[k - 1]))) return rc;
       if ((rc = upload(e, transpose2d(*w1, G, G), &W.w1[k - 1]))) return rc;
@@ -394,7 +405,7 @@ static int prep_weights(Engine* e, const WeightMap& wm) {
         const HostTensor* w2 = find(wm, P + br + ".w2", &err);
         const HostTensor* b2 = find(wm, P + br + ".b2", &err);
         if (!w1 || !b1 || !w2 || !b2) return fail(NUTLS_ERR_WEIGHTS, err);
-        if (w1->size() != 16 * 64 || w2->size() != 64 * 16) return fail(NUTLS_ERR_WEIGHTS, "unexpected CTFA shape " + P + br);
+        if (w1->size() != 16 * 64 || w2->size() != 64 * 16 || b1->size() != 16u || b2->size() != 64u) return fail(NUTLS_ERR_WEIGHTS, "unexpected CTFA shape " + P + br);
         CtfaW cw{};
         if ((rc = upload(e, transpose2d(*w1, 16, 64), &cw.w1T))) return rc;
         if ((rc = upload(e, b1->data, &cw.b1))) return rc;
@@ -421,10 +432,11 @@ static int prep_weights(Engine* e, const WeightMap& wm) {
     const HostTensor* bd = find(wm, ld.second + ".b", &err);
     if (!wx || !wh || !b || !wd || !bd) return fail(NUTLS_ERR_WEIGHTS, err);
     LstmW lw{};
+    if (wx->dims.size() != 2 || wh->dims.size() != 2 || wd->dims.size() != 2 || wx->dims[0] != 84 || wh->dims[0] != 84 || wh->dims[1] != 21 ||
+        wd->dims[1] != 21 || b->size() != 84u || static_cast<int>(bd->size()) != wd->dims[0])
+      return fail(NUTLS_ERR_WEIGHTS, "unexpected LSTM shape " + ld.first);
     lw.din = wx->dims[1];
     lw.dout = wd->dims[0];
-    if (wx->dims[0] != 84 || wh->dims[0] != 84 || wh->dims[1] != 21 || wd->dims[1] != 21)
-      return fail(NUTLS_ERR_WEIGHTS, "unexpected LSTM shape " + ld.first);
     if ((rc = upload(e, transpose2d(*wx, 84, lw.din), &lw.wxT))) return rc;
     if ((rc = upload(e, transpose2d(*wh, 84, 21), &lw.whT))) return rc;
     if ((rc = upload(e, b->data, &lw.bias))) return rc;
@@ -441,6 +453,8 @@ static int prep_weights(Engine* e, const WeightMap& wm) {
   const HostTensor* ow = find(wm, "out_conv.w", &err);
   const HostTensor* ob = find(wm, "out_conv.b", &err);
   if (!iw || !ib || !ig || !ibt || !ia || !ow || !ob) return fail(NUTLS_ERR_WEIGHTS, err);
+  if (iw->size() != 64u || ib->size() != 64u || ig->size() != 64u || ibt->size() != 64u || ia->size() < 1 || ow->size() != 64u || ob->size() < 1)
+    return fail(NUTLS_ERR_WEIGHTS, "unexpected input layer / output conv shape");
   if ((rc = upload(e, iw->data, &e->in_w))) return rc;
   if ((rc = upload(e, ib->data, &e->in_b))) return rc;
   if ((rc = upload(e, ig->data, &e->in_g))) return rc;
@@ -1003,7 +1017,20 @@ const char* nutls_version(void) { return "nutls-hip 0.1 (gfx950, fp32 MFMA)"; }
 
 static int build_offline_plan(Engine* e);
 
+static int create_body(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out);
+
+// (nothing may be thrown through the C ABI: a malformed container or an allocation failure is an error code)
 static int create_common(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out) {
+  try {
+    return create_body(weights, n_bytes, variant, batch, device, offline_frames, out);
+  } catch (const std::bad_alloc&) {
+    return fail(NUTLS_ERR_WEIGHTS, "nutls_create: out of host memory (malformed weight container?)");
+  } catch (const std::exception& ex) {
+    return fail(NUTLS_ERR_WEIGHTS, std::string("nutls_create: ") + ex.what());
+  }
+}
+
+static int create_body(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out) {
   if (!weights || !out || batch < 1) return fail(NUTLS_ERR_ARG, "nutls_create: null pointer or batch < 1");
   if (variant != NUTLS_VARIANT_LSTM && variant != NUTLS_VARIANT_BASELINE) return fail(NUTLS_ERR_ARG, "nutls_create: unknown variant");
   int ndev = 0;
@@ -1062,6 +1089,7 @@ static int create_common(const void* weights, size_t n_bytes, int variant, int b
     if (rc) return rc;
     if (e->fz_blob) e->mode = 3;          // the default for streaming handles of the LSTM variant
   }
+  HIP_TRY(stream_step_set_attributes());      // dynamic-LDS limit of the one-launch kernels, on THIS handle's device
   e->n_cu = prop.multiProcessorCount;
   e->debug["input_layer"] = {e->t_inlayer, 256 * 64};
   e->debug["msfe6_de.y"] = {e->t_y, 256 * 64};
@@ -1127,6 +1155,7 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
   Engine* e = &h->eng;
   if (!e->offline) return fail(NUTLS_ERR_ARG, "nutls_process_block: not an offline handle (nutls_create_offline)");
   if (n_frames < 1 || n_frames > e->offline) return fail(NUTLS_ERR_ARG, "nutls_process_block: n_frames out of range");
+  HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = static_cast<size_t>(n_frames) * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
@@ -1207,6 +1236,7 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_step: null pointer");
   Engine* e = &h->eng;
   if (e->offline) return fail(NUTLS_ERR_ARG, "nutls_step: offline handle, use nutls_process_block");
+  HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = static_cast<size_t>(e->B) * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
@@ -1245,6 +1275,7 @@ int nutls_step_host(nutls_handle* h, const float* mag_in, float* mag_out) {
 int nutls_stft_hop(nutls_handle* h, const float* pcm_in, void* stream) {
   if (!h || !pcm_in) return fail(NUTLS_ERR_ARG, "nutls_stft_hop: null pointer");
   Engine* e = &h->eng;
+  HIP_TRY(hipSetDevice(e->device));
   int rc = frontend_init(e);
   if (rc) return rc;
   HIP_TRY(launch_stft_hop(pcm_in, e->fe_tail, e->fe_win, e->fe_tw, e->io_in, e->fe_ph, e->B, static_cast<hipStream_t>(stream)));
@@ -1255,6 +1286,7 @@ int nutls_istft_hop(nutls_handle* h, float* pcm_out, int dc_mode, void* stream) 
   if (!h || !pcm_out) return fail(NUTLS_ERR_ARG, "nutls_istft_hop: null pointer");
   if (dc_mode != NUTLS_DC_EDGE && dc_mode != NUTLS_DC_ZERO) return fail(NUTLS_ERR_ARG, "dc_mode must be NUTLS_DC_EDGE or NUTLS_DC_ZERO");
   Engine* e = &h->eng;
+  HIP_TRY(hipSetDevice(e->device));
   int rc = frontend_init(e);
   if (rc) return rc;
   HIP_TRY(launch_istft_hop(e->io_out, e->fe_ph, e->fe_inv, e->fe_tw, e->fe_ola, pcm_out, dc_mode == NUTLS_DC_EDGE ? 1 : 0, e->B,
@@ -1319,8 +1351,9 @@ static int state_lookup(Engine* e, const char* name, size_t n_floats, StateTenso
   auto it = e->state_index.find(name);
   if (it == e->state_index.end()) return fail(NUTLS_ERR_ARG, std::string("unknown state tensor: ") + name);
   StateTensor* st = &e->states[it->second];
-  if (n_floats != st->per_stream() * e->B)
-    return fail(NUTLS_ERR_ARG, std::string("size mismatch for ") + name + ": expected " + std::to_string(st->per_stream() * e->B) +
+  const size_t nb = e->offline ? 1 : static_cast<size_t>(e->B);      // an offline handle is ONE utterance (arena slot 0 = carried state)
+  if (n_floats != st->per_stream() * nb)
+    return fail(NUTLS_ERR_ARG, std::string("size mismatch for ") + name + ": expected " + std::to_string(st->per_stream() * nb) +
                                    " floats, got " + std::to_string(n_floats));
   *out = st;
   return NUTLS_OK;
@@ -1334,6 +1367,7 @@ int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), host_buf, true, 0);
   rc = copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), host_buf, true);
   if (rc == NUTLS_OK && st->ring_d > 1) rotate_ring(e, *st, host_buf, true);
   return rc;
@@ -1347,12 +1381,45 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), const_cast<float*>(host_buf), false, 0);
   if (st->ring_d > 1) {
     std::vector<float> tmp(host_buf, host_buf + n_floats);
     rotate_ring(e, *st, tmp.data(), false);
     return copy_stream_tensor(e, st->buf[0], st->per_stream(), tmp.data(), false);
   }
   return copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), const_cast<float*>(host_buf), false);
+}
+
+/* All state tensors of ONE stream in signature order, concatenated (what the compat runner returns per frame): one
+ * device-to-host copy of the stream's `prev`-side state block instead of one copy per tensor. */
+int nutls_state_get_all(nutls_handle* h, int stream_idx, float* host_buf, size_t n_floats) {
+  if (!h || !host_buf) return fail(NUTLS_ERR_ARG, "nutls_state_get_all: null pointer");
+  Engine* e = &h->eng;
+  if (e->offline) stream_idx = 0;
+  if (stream_idx < 0 || stream_idx >= e->B) return fail(NUTLS_ERR_ARG, "nutls_state_get_all: stream index out of range");
+  size_t total = 0;
+  for (const StateTensor& st : e->states) total += st.per_stream();
+  if (n_floats != total) return fail(NUTLS_ERR_ARG, "nutls_state_get_all: expected " + std::to_string(total) + " floats");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  // the stream's slice of the arena up to the end of the state slots (both parities + rings), then pick the tensors out of it
+  size_t span = 0;
+  for (const StateTensor& st : e->states)
+    for (int b = 0; b < 2; ++b) span = std::max(span, static_cast<size_t>(st.buf[b] - e->arena) + st.per_stream());
+  std::vector<float> slice(span);
+  HIP_TRY(hipMemcpy(slice.data(), e->arena + e->sstride * stream_idx, span * sizeof(float), hipMemcpyDeviceToHost));
+  size_t o = 0;
+  for (const StateTensor& st : e->states) {
+    const float* src = slice.data() + ((e->offline ? st.buf[0] : st.buf[1 - e->next_parity]) - e->arena);
+    std::memcpy(host_buf + o, src, st.per_stream() * sizeof(float));
+    if (st.ring_d > 1) {      // physical ring order -> the reference's oldest-first order
+      const size_t frame = st.per_stream() / st.ring_d;
+      for (int j = 0; j < st.ring_d; ++j)
+        std::memcpy(host_buf + o + j * frame, src + ((e->steps + j) % st.ring_d) * frame, frame * sizeof(float));
+    }
+    o += st.per_stream();
+  }
+  return NUTLS_OK;
 }
 
 int nutls_reset(nutls_handle* h, int stream_idx) {

@@ -988,19 +988,21 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
   }
 }
 
-hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s) {
-  static bool attr_set = false;
+// Dynamic-LDS limit of the four builds, on the CURRENT device (function attributes are per device: every handle sets them
+// for its own device when it is created).
+hipError_t stream_step_set_attributes() {
   const void* fns[4] = {reinterpret_cast<const void*>(nutls_stream_step_kernel<false, false>),
                         reinterpret_cast<const void*>(nutls_stream_step_kernel<true, false>),
                         reinterpret_cast<const void*>(nutls_stream_step_kernel<false, true>),
                         reinterpret_cast<const void*>(nutls_stream_step_kernel<true, true>)};
-  if (!attr_set) {
-    for (const void* f : fns) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MK_LDS_BYTES));
-      if (e != hipSuccess) return e;
-    }
-    attr_set = true;
+  for (const void* f : fns) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(MK_LDS_BYTES));
+    if (e != hipSuccess) return e;
   }
+  return hipSuccess;
+}
+
+hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s) {
   const bool prof = a.prof != nullptr, ddb = a.ddb != nullptr;
   if (!prof && !ddb) hipLaunchKernelGGL((nutls_stream_step_kernel<false, false>), dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);
   else if (prof && !ddb) hipLaunchKernelGGL((nutls_stream_step_kernel<true, false>), dim3(grid), dim3(MK_THREADS), MK_LDS_BYTES, s, a);

@@ -225,6 +225,7 @@ struct StepArgs {            // kernel arguments of the persistent kernel
 };
 CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase);
 hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s);
+hipError_t stream_step_set_attributes();
 
 // grid = number of workgroups (each loops over streams blockIdx.x, +grid, ...); prof (nullable)
 // receives wall_clock64() at every layer boundary of workgroup 0 (n_ops + 1 entries).

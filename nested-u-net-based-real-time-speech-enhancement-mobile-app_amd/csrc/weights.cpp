@@ -39,13 +39,17 @@ bool parse_weight_blob(const void* blob, size_t n, WeightMap* out, std::string* 
     for (int d = 0; d < ndim; ++d) {
       uint32_t v = 0;
       if (!c.take(&v, 4)) { *err = "truncated dims: " + name; return false; }
+      // every dim positive, and the element count can never exceed the bytes that are left (no overflow, no huge resize)
+      if (v == 0 || v > n || cnt > n / v) { *err = "bad dims: " + name; return false; }
       t.dims.push_back(static_cast<int>(v));
       cnt *= v;
     }
     uint32_t ns = 0;
     if (!c.take(&ns, 4)) { *err = "truncated scales: " + name; return false; }
+    if (static_cast<size_t>(ns) > (n - c.off) / 4) { *err = "truncated scales: " + name; return false; }
     std::vector<float> scales(ns);
     if (ns && !c.take(scales.data(), 4ull * ns)) { *err = "truncated scales: " + name; return false; }
+    if (cnt > (n - c.off) / (dtype == 0 ? 4 : 1)) { *err = "truncated payload: " + name; return false; }
     t.data.resize(cnt);
     if (dtype == 0) {
       if (!c.take(t.data.data(), 4 * cnt)) { *err = "truncated payload: " + name; return false; }

@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
     "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
-    "nutls_fused_blob_floats", "nutls_fused_pack_blob",
+    "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all",
 )
 
 
@@ -64,6 +64,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_set_mode.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_state_get.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
     lib.nutls_state_set.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
+    lib.nutls_state_get_all.argtypes = [c.c_void_p, c.c_int, fp, c.c_size_t]
     lib.nutls_state_count.argtypes = [c.c_void_p]
     lib.nutls_state_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_int), c.POINTER(c.c_int)]
     lib.nutls_reset.argtypes = [c.c_void_p, c.c_int]
@@ -189,6 +190,8 @@ class NutlsEngine:
             raise ValueError("mag must be [%d,%d], got %s" % (self.batch, T.N_BINS, tuple(mag.shape)))
         if out is None:
             out = torch.empty_like(mag)
+        if mag.device.index != self.device or out.device != mag.device:
+            raise ValueError("mag / out live on %s / %s, this engine on cuda:%d" % (mag.device, out.device, self.device))
         stream = torch.cuda.current_stream(mag.device).cuda_stream
         _check(self._lib, self._lib.nutls_step(self._h, mag.data_ptr(), out.data_ptr(), stream))
         return out
@@ -265,6 +268,14 @@ class NutlsEngine:
         _check(self._lib, self._lib.nutls_state_get(self._h, name.encode(), _fptr(a), a.size))
         return a.reshape(self.batch, d0) if d1 == 1 and d0 == T.LSTM_UNITS else a
 
+    def state_get_all(self, stream_idx: int = 0) -> np.ndarray:
+        """Every state tensor of one stream, concatenated in ``state_specs()`` order: ONE device-to-host copy."""
+        if not hasattr(self, "_state_total"):
+            self._state_total = sum(d0 * d1 for _, (d0, d1) in self.state_specs())
+        a = np.empty(self._state_total, np.float32)
+        _check(self._lib, self._lib.nutls_state_get_all(self._h, int(stream_idx), _fptr(a), a.size))
+        return a
+
     def state_set(self, name: str, value) -> None:
         d0, d1 = self._state_shape(name)
         a = np.ascontiguousarray(value, dtype=np.float32)
@@ -329,7 +340,9 @@ class NutlsRunner:
 
     The caller owns the state arrays, as in the reference.  When it echoes back the very
     arrays this runner returned last frame (what the reference loop does) the upload is
-    skipped, because the device already holds them."""
+    skipped, because the device already holds them; the returned arrays are READ-ONLY views of one
+    buffer, so a caller that wants to patch a state (zero h/c to reset a stream, ...) has to make a
+    copy -- a new object -- which is uploaded like any foreign array."""
 
     signature_key = "nutls_lstm_sm"
 
@@ -373,10 +386,13 @@ class NutlsRunner:
                 eng.state_set(k_in, a)
         out = eng.step(x.reshape(1, T.N_BINS))
         res = {"model_out": out.reshape(1, 1, T.N_BINS, 1)}
+        flat = eng.state_get_all(0)                 # one D2H copy for the 130 / 208 tensors
+        flat.flags.writeable = False                # in-place edits of an echoed array would go unnoticed: forbid them
+        o = 0
         for base, shp in self._specs:
-            k_in, k_out = base.format("prev"), base.format("cur")
-            a = eng.state_get(k_in)
-            res[k_out] = a.reshape(self._io_shape(shp))
+            n = int(np.prod(shp))
+            res[base.format("cur")] = flat[o:o + n].reshape(self._io_shape(shp))
+            o += n
         self._last = res
         return res
 

@@ -49,11 +49,12 @@ def inverse_window() -> np.ndarray:
     return (w / den).astype(np.float32)
 
 
-def zero_state() -> Dict[str, np.ndarray]:
-    """The all-zero ``tflite_out`` seed of interpreter_proposed.py:36-198 (keys are the
-    *output* names: ``*_cur{i}``, ``*_h``, ``*_c``, ``model_out``)."""
+def zero_state(variant: str = "lstm") -> Dict[str, np.ndarray]:
+    """The all-zero ``tflite_out`` seed of interpreter_proposed.py:36-198 / interpreter_nunet_tls.py:36-370 (keys are
+    the *output* names: ``*_cur{i}``, ``*_h``, ``*_c``, ``model_out``; the baseline's dilated-dense histories are
+    ``[1, d, F, C]``)."""
     st = {"model_out": np.zeros((1, 1, T.N_BINS, 1), np.float32)}
-    for base, shp in T.state_specs():
+    for base, shp in T.state_specs(variant):
         if len(shp) == 1:
             st[base] = np.zeros((1, shp[0]), np.float32)
         else:
@@ -61,10 +62,11 @@ def zero_state() -> Dict[str, np.ndarray]:
     return st
 
 
-def feeds_from_outputs(prev_out: Dict[str, np.ndarray], sliced_mag: np.ndarray) -> Dict[str, np.ndarray]:
-    """cur -> prev echo the caller performs every frame (interpreter_proposed.py:215-350)."""
+def feeds_from_outputs(prev_out: Dict[str, np.ndarray], sliced_mag: np.ndarray, variant: str = "lstm") -> Dict[str, np.ndarray]:
+    """cur -> prev echo the caller performs every frame (interpreter_proposed.py:215-350,
+    interpreter_nunet_tls.py:372-540 for the 'nutls' signature)."""
     feeds = {"input": sliced_mag}
-    for base, shp in T.state_specs():
+    for base, shp in T.state_specs(variant):
         if len(shp) == 1:
             feeds[base] = prev_out[base]
         else:
@@ -90,8 +92,11 @@ def frame_magnitudes(noisy_speech: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
 
 
 def real_time_speech_enhancer(noisy_speech: np.ndarray, runner: Callable[..., Dict[str, np.ndarray]],
-                              dc_mode: str = "edge") -> Tuple[np.ndarray, List[float]]:
+                              dc_mode: str = "edge", variant: str = None) -> Tuple[np.ndarray, List[float]]:
     """Frame-by-frame enhancement of one utterance; returns (waveform, per-frame seconds).
+
+    ``variant``: which signature the runner implements -- ``"lstm"`` ('nutls_lstm_sm', interpreter_proposed.py:380)
+    or ``"baseline"`` ('nutls', interpreter_nunet_tls.py:549); default: what the runner says (``signature_key``).
 
     ``dc_mode``: how bin 0 is re-created after the 256-bin model: ``"edge"`` (the PC loop,
     interpreter_proposed.py:352-353) or ``"zero"`` (the phone,
@@ -103,7 +108,9 @@ def real_time_speech_enhancer(noisy_speech: np.ndarray, runner: Callable[..., Di
     num_blocks = (audio.shape[0] - (FRAME_LEN - FRAME_STEP)) // FRAME_STEP
     out_file = np.zeros((len(audio) + (FRAME_LEN - FRAME_STEP)))
     time_array: List[float] = []
-    model_out = zero_state()
+    if variant is None:
+        variant = "baseline" if getattr(runner, "signature_key", "nutls_lstm_sm") == "nutls" else "lstm"
+    model_out = zero_state(variant)
     for idx in range(num_blocks):
         t0 = time.time()
         in_buffer[:-FRAME_STEP] = in_buffer[FRAME_STEP:]
@@ -111,7 +118,7 @@ def real_time_speech_enhancer(noisy_speech: np.ndarray, runner: Callable[..., Di
         spec = np.fft.rfft(in_buffer * win)
         in_mag, in_phase = np.abs(spec), np.angle(spec)
         sliced_mag = np.reshape(in_mag, (1, 1, -1, 1)).astype(np.float32)[:, :, 1:]
-        model_out = runner(**feeds_from_outputs(model_out, sliced_mag))
+        model_out = runner(**feeds_from_outputs(model_out, sliced_mag, variant))
         est = model_out["model_out"]
         if dc_mode == "edge":
             est_mag = np.pad(est, ((0, 0), (0, 0), (1, 0), (0, 0)), mode="edge")

@@ -98,3 +98,38 @@ def test_plan_images_fit_lds_and_ops_cover_the_network():
             assert o["img"]["bytes"] <= lim, o["name"]
             for p in o["parts"]:
                 assert p["la"] in (1, 2)
+
+
+def test_malformed_containers_are_error_codes_not_crashes():
+    """The container parser never trusts header fields (huge / zero dims, truncated payloads, wrapping products):
+    every malformed blob comes back as NUTLS_ERR_WEIGHTS through the C ABI (host-only entry point, no GPU needed)."""
+    import struct
+    import nunet_amd  # noqa: F401
+    from nunet_amd.runner import load_library, _fptr
+    from nunet_amd.weights import DEFAULT_WEIGHTS, read_blob
+    lib = load_library()
+    n = lib.nutls_fused_blob_floats()
+    out = np.zeros(n, np.float32)
+    good = read_blob(DEFAULT_WEIGHTS)
+
+    def rc_of(b):
+        buf = ctypes.create_string_buffer(bytes(b), len(b))
+        return lib.nutls_fused_pack_blob(buf, len(b), _fptr(out), n)
+
+    def tensor(name, dtype, dims, ns=0, payload=b""):
+        nb = name.encode()
+        return struct.pack("<H", len(nb)) + nb + struct.pack("<BB", dtype, len(dims)) + struct.pack("<%dI" % len(dims), *dims) + struct.pack("<I", ns) + payload
+
+    head = b"NUTLSW01" + struct.pack("<I", 1)
+    bad = [
+        good[:1000],                                                        # truncated
+        b"XXXXXXXX" + good[8:],                                             # wrong magic
+        head + tensor("a.w", 0, (0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)),      # product overflows / huge resize
+        head + tensor("a.w", 1, (0, 4)),                                    # zero dim (division by dims[0])
+        head + tensor("a.w", 0, (1 << 30,)),                                # 4 GiB of payload that is not there
+        head + tensor("a.w", 1, (4, 4), ns=0x40000000),                     # scale count beyond the file
+        good + b"\0",                                                       # trailing bytes
+    ]
+    for b in bad:
+        assert rc_of(b) == -2, lib.nutls_last_error()                      # NUTLS_ERR_WEIGHTS
+    assert rc_of(good) == 0

@@ -60,3 +60,31 @@ def test_streaming_entry_points_reject_offline_handles_and_vice_versa(clip):
     y = np.zeros((2, 256), np.float32)
     assert eng._lib.nutls_process_block_host(eng._h, _fptr(y), _fptr(y.copy()), 2) != 0
     eng.close()
+
+
+def test_offline_handle_state_get_set_addresses_the_carried_state():
+    """state_get / state_set on an offline handle read / write the state carried from block to block (one utterance)."""
+    import numpy as np
+    import nunet_amd
+    from conftest import GOLDEN
+    import os
+    clip = np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+    off = nunet_amd.NutlsOffline(max_frames=16)
+    eng = nunet_amd.NutlsEngine(batch=1)
+    off.process(clip["mags_in"][:16])
+    for i in range(16):
+        eng.step(clip["mags_in"][i:i + 1])
+    lib, h = off._lib, off._h
+    import ctypes
+    for name, n in (("state_h", 21), ("msfe6_ee_prev1", 256 * 64), ("msfe3_dd_prev2", 2 * 64)):
+        a = np.zeros(n, np.float32)
+        assert lib.nutls_state_get(h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), n) == 0, lib.nutls_last_error()
+        np.testing.assert_allclose(a, eng.state_get(name).reshape(-1), rtol=1e-4, atol=1e-5, err_msg=name)
+    # zero one state on both and continue: still the same function
+    z = np.zeros(21, np.float32)
+    assert lib.nutls_state_set(h, b"state_h", z.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 21) == 0
+    eng.state_set("state_h", z.reshape(1, 21))
+    o1 = off.process(clip["mags_in"][16:24])
+    o2 = np.concatenate([eng.step(clip["mags_in"][i:i + 1]) for i in range(16, 24)])
+    assert float(np.sqrt(np.mean((o1 - o2) ** 2))) < 2e-5
+    off.close(); eng.close()

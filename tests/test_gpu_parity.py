@@ -347,3 +347,54 @@ def test_extreme_inputs_stay_finite_and_match_oracle():
         scale = max(1.0, float(np.abs(want).max()))
         assert rms(out, want) < 1e-4 * scale
     eng.close()
+
+
+def test_runner_outputs_are_read_only_and_patched_copies_are_uploaded(clip):
+    """The signature runner hands back read-only arrays (one batched device-to-host copy): an in-place edit of an echoed
+    state raises instead of being silently ignored; an edited COPY (a new object) is uploaded like any foreign array."""
+    run = NutlsRunner()
+    feeds = {k: np.zeros(v, np.float32) for k, v in run.get_input_details().items()}
+    for i in range(3):
+        feeds["input"] = clip["mags_in"][i].reshape(1, 1, 256, 1)
+        out = run(**feeds)
+        feeds = {k.replace("_cur", "_prev"): v for k, v in out.items() if k != "model_out"}
+    with pytest.raises(ValueError):
+        out["state_h"][0, 0] = 0.0
+    # batched read == per-tensor reads
+    for base, shp in T.state_specs():
+        name = base if len(shp) == 1 else base.format("cur")
+        np.testing.assert_array_equal(out[name].reshape(-1), run.engine.state_get(name.replace("_cur", "_prev")).reshape(-1), err_msg=name)
+    # reset the LSTM states of the stream through the feeds: same as an engine whose h / c were zeroed
+    ref = NutlsEngine(batch=1)
+    for i in range(3):
+        ref.step(clip["mags_in"][i:i + 1])
+    for n in ("state_h", "state_c", "msfe6_en_h", "msfe6_en_c"):
+        feeds[n] = np.zeros_like(feeds[n])
+        ref.state_set(n, np.zeros((1, 21), np.float32))
+    feeds["input"] = clip["mags_in"][3].reshape(1, 1, 256, 1)
+    got = run(**feeds)["model_out"].reshape(1, 256)
+    assert rms(got, ref.step(clip["mags_in"][3:4])) < 1e-7
+    ref.close()
+
+
+def test_baseline_runner_through_the_host_loop(baseline_weights, clip):
+    """The reference's baseline loop (interpreter_nunet_tls.py:372-549: 'nutls' signature, 208 states echoed every
+    frame) driven by the HIP runner == the same loop driven by oracle B."""
+    w, blob = baseline_weights
+    audio = clip["noisy"][:256 * 42] if "noisy" in clip.files else None
+    if audio is None:
+        rng = np.random.default_rng(3)
+        audio = (0.05 * rng.standard_normal(256 * 42)).astype(np.float32)
+    run = NutlsRunner(blob, variant="baseline")
+    enh, _ = SE.real_time_speech_enhancer(audio, run)
+    ref = NutlsRef(w, batch=1, variant="baseline")
+    zeros = {k: v for k, v in SE.zero_state("baseline").items() if k != "model_out"}
+
+    def oracle_runner(**feeds):      # the echo is exact, so the oracle may keep the state to itself
+        out = ref.step(np.asarray(feeds["input"], np.float32).reshape(1, 256)).numpy()
+        return dict(zeros, model_out=out.reshape(1, 1, 256, 1))
+
+    oracle_runner.signature_key = "nutls"
+    want, _ = SE.real_time_speech_enhancer(audio, oracle_runner)
+    assert enh.shape == want.shape and np.isfinite(enh).all()
+    assert rms(enh, want) < 1e-4 * max(1.0, float(np.abs(want).max()))
