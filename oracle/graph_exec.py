@@ -115,11 +115,54 @@ def _strided_slice(x, begin, end, strides, o):
     return x[tuple(idx)]
 
 
+# ---- third-party arithmetic for the heavy operators (cross-check of the hand-written numpy forms above) ----------
+def _conv2d_torch(x, w, b, stride_h, stride_w, padding, dil_h=1, dil_w=1):
+    """CONV_2D through torch.nn.functional.conv2d (NHWC / OHWI in and out, explicit TF-style SAME padding)."""
+    import torch
+    import torch.nn.functional as Fn
+    n, h, wd, c = x.shape
+    o, kh, kw, ci = w.shape
+    xt = torch.from_numpy(np.ascontiguousarray(x, dtype=F32)).permute(0, 3, 1, 2)
+    if padding == 0:
+        _, pt, pb = _same_pad(h, kh, stride_h, dil_h)
+        _, pl, pr = _same_pad(wd, kw, stride_w, dil_w)
+        xt = Fn.pad(xt, (pl, pr, pt, pb))
+    wt = torch.from_numpy(np.ascontiguousarray(w, dtype=F32)).permute(0, 3, 1, 2).contiguous()
+    bt = None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=F32))
+    y = Fn.conv2d(xt, wt, bt, stride=(stride_h, stride_w), dilation=(dil_h, dil_w))
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def _transpose_conv_torch(out_shape, w, x, b, stride_h, stride_w, padding):
+    """TRANSPOSE_CONV through torch.nn.functional.conv_transpose2d (weights OHWI -> torch's [in, out, kh, kw])."""
+    import torch
+    import torch.nn.functional as Fn
+    oh, ow = int(out_shape[1]), int(out_shape[2])
+    xt = torch.from_numpy(np.ascontiguousarray(x, dtype=F32)).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(np.ascontiguousarray(w, dtype=F32)).permute(3, 0, 1, 2).contiguous()
+    full = Fn.conv_transpose2d(xt, wt, None, stride=(stride_h, stride_w))
+    fh, fw = full.shape[2], full.shape[3]
+    pt = max(fh - oh, 0) // 2 if padding == 0 else 0
+    pl = max(fw - ow, 0) // 2 if padding == 0 else 0
+    y = full[:, :, pt:pt + oh, pl:pl + ow].permute(0, 2, 3, 1)
+    if b is not None:
+        y = y + torch.from_numpy(np.ascontiguousarray(b, dtype=F32))
+    return y.contiguous().numpy()
+
+
 class GraphOracle:
     """Callable with the same surface as the reference's TFLite signature runner
-    (``/root/reference/dnn_model/interpreter_proposed.py:380, 215-350``)."""
+    (``/root/reference/dnn_model/interpreter_proposed.py:380, 215-350``).
 
-    def __init__(self, path: str):
+    ``backend="numpy"``: every operator hand-written in numpy (the generator of the goldens).
+    ``backend="torch"``: CONV_2D / TRANSPOSE_CONV / FULLY_CONNECTED / AVERAGE_POOL_2D / LOGISTIC / TANH / PRELU through
+    ``torch.nn.functional`` -- third-party arithmetic for everything that carries FLOPs, so the goldens are not pinned to
+    hand-written numpy alone (tests/test_oracle.py::test_oracle_a_numpy_ops_agree_with_torch_functional)."""
+
+    def __init__(self, path: str, backend: str = "numpy"):
+        if backend not in ("numpy", "torch"):
+            raise ValueError("backend must be 'numpy' or 'torch'")
+        self.backend = backend
         self.model = TFLiteModel(path)
         sig = self.model.signatures[0]
         self.key = sig.key
@@ -162,10 +205,39 @@ class GraphOracle:
                 return self._w(i) if t.dtype == np.int8 else self.consts[i]
             raise KeyError("tensor %d (%s) not computed" % (i, tensors[i].name))
 
+        tb = self.backend == "torch"
+        if tb:
+            import torch
+            import torch.nn.functional as Fn
         for op in self.model.ops:
             ins, o, n = op.inputs, op.options, op.name
             if n == "DEQUANTIZE":
                 r = self._w(ins[0])
+            elif tb and n == "CONV_2D":
+                b = get(ins[2]) if len(ins) > 2 and ins[2] >= 0 else None
+                r = _act(_conv2d_torch(get(ins[0]), get(ins[1]), b, o["stride_h"], o["stride_w"], o["padding"], o["dil_h"], o["dil_w"]), o["act"])
+            elif tb and n == "TRANSPOSE_CONV":
+                b = get(ins[3]) if len(ins) > 3 and ins[3] >= 0 else None
+                r = _transpose_conv_torch(get(ins[0]), get(ins[1]), get(ins[2]), b, o["stride_h"], o["stride_w"], o["padding"])
+            elif tb and n == "FULLY_CONNECTED":
+                x, w = get(ins[0]), get(ins[1])
+                b = get(ins[2]) if len(ins) > 2 and ins[2] >= 0 else None
+                y = Fn.linear(torch.from_numpy(np.ascontiguousarray(x, dtype=F32)).reshape(-1, w.shape[1]), torch.from_numpy(np.ascontiguousarray(w, dtype=F32)),
+                              None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=F32))).numpy()
+                if o["keep_num_dims"]:
+                    y = y.reshape(x.shape[:-1] + (w.shape[0],))
+                r = _act(y.astype(F32), o["act"])
+            elif tb and n == "AVERAGE_POOL_2D":
+                assert o["padding"] == 1 and o["act"] == 0
+                xt = torch.from_numpy(np.ascontiguousarray(get(ins[0]), dtype=F32)).permute(0, 3, 1, 2)
+                r = Fn.avg_pool2d(xt, (o["filter_h"], o["filter_w"]), (o["stride_h"], o["stride_w"])).permute(0, 2, 3, 1).contiguous().numpy()
+            elif tb and n == "LOGISTIC":
+                r = torch.sigmoid(torch.from_numpy(np.ascontiguousarray(get(ins[0]), dtype=F32))).numpy()
+            elif tb and n == "TANH":
+                r = torch.tanh(torch.from_numpy(np.ascontiguousarray(get(ins[0]), dtype=F32))).numpy()
+            elif tb and n == "PRELU":
+                x, a = get(ins[0]), get(ins[1])
+                r = Fn.prelu(torch.from_numpy(np.ascontiguousarray(x, dtype=F32)), torch.from_numpy(np.ascontiguousarray(a, dtype=F32)).reshape(-1)[:1]).numpy()
             elif n == "CONV_2D":
                 b = get(ins[2]) if len(ins) > 2 and ins[2] >= 0 else None
                 r = _act(_conv2d(get(ins[0]), get(ins[1]), b, o["stride_h"], o["stride_w"],

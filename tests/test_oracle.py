@@ -158,12 +158,16 @@ def _offline_ddb(w, tag, x_seq):
 
 
 def test_baseline_streaming_ddb_equals_offline_dilated_conv():
+    """Every one of the 13 bottlenecks, WHOLE (in conv + six grouped dilated blocks + out conv, nunet_tls.py:190-272):
+    oracle B's streaming form (rings, converter_nunet_tls.py:374-411) against the offline Keras formulation evaluated
+    with torch.nn.functional.conv2d(groups=G, dilation=d) over a 70-frame sequence."""
     import torch
     from nunet_amd.weights import synthetic_weights
     w = synthetic_weights("baseline", seed=7, bias_std=0.2, affine_jitter=0.2)
     ref = NutlsRef(w, batch=1, variant="baseline")
     rng = np.random.default_rng(3)
-    for tag, F, C in (("msfe6_en_ddb", 4, 32), ("msfe3_de_ddb", 1, 32), ("ddb", 4, 64)):
+    for prefix, F, C in T.bottlenecks():
+        tag = (prefix + "_ddb") if prefix else "ddb"
         T_ = 70                                                  # > 2 * 32 frames: every ring wraps
         xs = rng.standard_normal((T_, F, C)).astype(np.float32)
         want = _offline_ddb(w, tag, xs)
@@ -182,3 +186,63 @@ def test_baseline_topology_matches_reference_signature():
     shapes = {b.format("prev"): s for b, s in specs}
     assert shapes["msfe6_en_ddb_prev4"] == (8, 4, 64) and shapes["ddb_prev6"] == (32, 4, 192)
     assert shapes["ddb_prev_in"] == (1, 4, 64) and shapes["msfe3_de_ddb_prev_out"] == (1, 1, 16)
+
+
+def test_oracle_b_lstm_cell_equals_torch_lstmcell():
+    """Oracle B's hand-written Keras LSTM cell (gates i, f, g, o; proposed.py:70-119) against torch.nn.LSTMCell loaded
+    with the same weights (torch's gate order is i, f, g, o as well), for all 13 LSTMs, 5 steps of carried state."""
+    import torch
+    w = load_weights()
+    ref = NutlsRef(batch=2)
+    rng = np.random.default_rng(11)
+    for prefix, F, C in T.bottlenecks():
+        lstm = (prefix + "_lstm") if prefix else "lstm"
+        dense = (prefix + "_dense") if prefix else "dense"
+        hn, cn = ((prefix + "_h", prefix + "_c") if prefix else ("state_h", "state_c"))
+        din = w[lstm + ".wx"].shape[1]
+        cell = torch.nn.LSTMCell(din, T.LSTM_UNITS)
+        with torch.no_grad():
+            cell.weight_ih.copy_(torch.from_numpy(w[lstm + ".wx"]))
+            cell.weight_hh.copy_(torch.from_numpy(w[lstm + ".wh"]))
+            cell.bias_ih.copy_(torch.from_numpy(w[lstm + ".b"]))
+            cell.bias_hh.zero_()
+        h = torch.zeros(2, T.LSTM_UNITS)
+        c = torch.zeros(2, T.LSTM_UNITS)
+        ref.state[hn], ref.state[cn] = h.clone(), c.clone()
+        for _ in range(5):
+            v = torch.from_numpy(rng.standard_normal((2, din)).astype(np.float32))
+            ref._new = {}
+            got = ref._lstm_dense(v, lstm, dense, hn, cn)
+            ref.state.update(ref._new)
+            with torch.no_grad():
+                h, c = cell(v, (h, c))
+                want = torch.nn.functional.linear(h, torch.from_numpy(w[dense + ".w"]), torch.from_numpy(w[dense + ".b"]))
+            assert rms(got.numpy(), want.numpy()) < 1e-6, lstm
+            assert rms(ref.state[cn].numpy(), c.numpy()) < 1e-6, lstm
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_TFLITE), reason="needs /root/reference (build container only)")
+def test_oracle_a_numpy_ops_agree_with_torch_functional():
+    """The goldens come from oracle A's hand-written numpy operators.  Here the same flatbuffer runs with every
+    FLOP-carrying operator (CONV_2D, TRANSPOSE_CONV, FULLY_CONNECTED, AVERAGE_POOL_2D, LOGISTIC, TANH, PRELU) evaluated
+    by torch.nn.functional instead: third-party arithmetic must reproduce the committed goldens too.  (Still not the
+    TF-Lite runtime -- that stays unpinned, SURVEY F6 -- but no longer pinned to hand-written numpy alone.)"""
+    from oracle.graph_exec import GraphOracle
+    clip = np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+    a, b = GraphOracle(REFERENCE_TFLITE), GraphOracle(REFERENCE_TFLITE, backend="torch")
+    fa, fb = a.zero_feeds(), b.zero_feeds()
+    for i in range(4):
+        x = clip["mags_in"][i].reshape(1, 1, 256, 1)
+        fa["input"], fb["input"] = x, x
+        oa, ob = a(**fa), b(**fb)
+        assert rms(ob["model_out"].reshape(-1), clip["mags_out"][i]) < 1e-6
+        for k in oa:
+            # (saturated LSTM cell states accumulate the last-bit difference between the two sigmoid / tanh implementations)
+            assert rms(oa[k], ob[k]) < 5e-6 * max(1.0, float(np.abs(oa[k]).max())), k
+        if i == 2:
+            fb_prev3 = dict(ob)
+        fa = {k.replace("_cur", "_prev"): v for k, v in oa.items() if k != "model_out"}
+        fb = {k.replace("_cur", "_prev"): v for k, v in ob.items() if k != "model_out"}
+    st = np.load(os.path.join(GOLDEN, "state_f3.npz"))         # the committed state goldens after frame 3 = feeds of frame 4
+    for k in ("msfe6_ee_cur1", "msfe4_dd3_cur2", "msfe3_de_cur1", "msfe6_dd_cur6"):
+        np.testing.assert_allclose(fb_prev3[k].reshape(-1), st[k].reshape(-1), rtol=1e-4, atol=1e-5, err_msg=k)
