@@ -75,6 +75,30 @@ bool fused_pack_blob(const WeightMap& wm, std::vector<float>* out, std::string* 
       }
       const int th = w->dims[1], kw = w->dims[2];
       const std::vector<int> perm = channel_perm(d);
+      if (d.path == fz::P_X4) {
+        // 4x4x1 tiles: wave `wv` = (64-channel tile ct, K slices kw * VH + hv); lane = (block b, row i) holds channel
+        // 64 ct + 4 (b mod 16/VH) + i; fragment f = 4 consecutive input channels of one K segment
+        const int VH = d.N < 64 ? 2 : 1, KSc = d.KSg, cps = d.cin / KSc, fps = cps / 4, segw = d.nseg / d.KSt;
+        const int nf = segw * fps, nsf = (nf + 3) / 4;
+        if (8 * nsf * 256 != bi.floats) { *err = "fragment count mismatch for " + key; return false; }
+        int8_t* dst8 = reinterpret_cast<int8_t*>(dst);
+        for (int wv = 0; wv < 8; ++wv) {
+          const int ct = wv % d.CG, kwv = wv / d.CG;
+          for (int f = 0; f < nf; ++f)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int b = lane >> 2, i = lane & 3, hv = VH == 2 ? (b >> 3) : 0;
+              const int v = kwv * VH + hv, ks_t = v / KSc, ks_c = v % KSc;
+              const int sg = ks_t * segw + f / fps, c0 = ks_c * cps + 4 * (f % fps);
+              const int np = 64 * ct + 4 * (VH == 2 ? (b & 7) : b) + i;
+              const int t = fz::kSegTk[bi.op][sg] >> 2, k = fz::kSegTk[bi.op][sg] & 3;
+              if (sg >= d.nseg || t >= th || k >= kw || np >= d.N) { *err = "segment / channel outside the kernel of " + key; return false; }
+              for (int q = 0; q < 4; ++q)
+                dst8[((static_cast<size_t>(wv) * nsf + f / 4) * 64 + lane) * 16 + (f % 4) * 4 + q] =
+                    w->q[((static_cast<size_t>(perm[np]) * th + t) * kw + k) * d.cin + c0 + q];
+            }
+        }
+        continue;
+      }
       const bool r32 = d.path == fz::P_R32;
       const int G = d.cin / (r32 ? 8 : 16), GW = G / d.KSg;
       const int segw = d.kind == fz::K_UP ? 3 : d.nseg / d.KSt;

@@ -12,7 +12,7 @@ namespace fz {
 
 enum OpType : int { T_INPUT = 0, T_CONV = 1, T_LSTM = 2, T_CTFA = 3 };
 enum CKind : int { K_IN = 0, K_EL = 1, K_DL = 2, K_DOWN = 3, K_UP = 4 };
-enum Path : int { P_R32 = 0, P_X16 = 1 };
+enum Path : int { P_R32 = 0, P_X16 = 1, P_X4 = 2 };
 enum Src : int { S_PREV = 0, S_CUR = 1, S_SCRATCH = 2 };   // HBM base a float offset is relative to
 
 constexpr int LDS_BYTES = 160 * 1024;
@@ -51,7 +51,7 @@ struct OpD {
   int ln, R, gc;                           // LayerNorm+PReLU?, output rows per position, channels per output row
   int rounds;                              // 2: the two time taps use the same LDS region one after the other
   int nseg, seg_b[MAX_SEG];                // (tap, frequency tap) segments of K: byte offset of each inside the image
-  int ex_b;                                // exchange buffer (X16 path)
+  int ex_b;                                // exchange buffer (X16 / X4 paths)
   int w_off, p_off;                        // weight blob (floats): MFMA fragments; bias | gamma | beta | alpha
   int d0_on, d0_src, d0_off, d0_ld, d1_on, d1_src, d1_off, d1_ld;   // HBM destinations (row 0, first channel)
   int row_mul, row_add;                    // output row of position p, sub-row r:  p * row_mul + row_add + r

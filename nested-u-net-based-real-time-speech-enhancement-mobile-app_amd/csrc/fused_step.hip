@@ -112,8 +112,10 @@ constexpr int kgroups(const OpD& d) { return d.cin / (d.path == P_R32 ? 8 : 16);
 constexpr int gw(const OpD& d) { return kgroups(d) / d.KSg; }                                     // ... per wave
 constexpr int segw(const OpD& d) { return is_up(d) ? 3 : d.nseg / d.KSt; }                       // segments per wave
 constexpr int tn(const OpD& d) { return d.N / (d.path == P_R32 ? 32 : 16); }                     // channel tiles per segment row of the blob
-constexpr int conv_nf(const OpD& d) { return segw(d) * gw(d) * d.NT; }                            // weight fragments per wave
-constexpr int ntask(const OpD& d) { return d.PG * d.CG * d.KSt * d.KSg; }
+constexpr int conv_nf(const OpD& d) {                                                              // weight fragments per wave
+  return d.path == P_X4 ? (d.nseg / d.KSt) * (d.cin / d.KSg / 4) : segw(d) * gw(d) * d.NT;
+}
+constexpr int ntask(const OpD& d) { return d.path == P_X4 ? 8 : d.PG * d.CG * d.KSt * d.KSg; }
 constexpr int nparams(const OpD& d) { return 2 * ntot(d) + 2 * d.gc + 1; }      // bias | weight scale | gamma | beta | alpha
 constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 3) / 4; }             // "super-fragments": 4 int8 fragments = one dwordx4 per lane
 constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), RING_SF); }
@@ -230,7 +232,10 @@ __device__ __forceinline__ Task conv_task(int wave) {
   constexpr OpD d = kOps[I];
   Task t;
   t.active = wave < ntask(d);
-  if constexpr (d.path == P_R32) {
+  if constexpr (d.path == P_X4) {
+    t.a = wave & (d.CG - 1); t.b = wave >> clog2(d.CG); t.ks = 0;
+    t.wbase_f = wave * (conv_nsf(d) * 256);
+  } else if constexpr (d.path == P_R32) {
     t.a = wave & (d.PG - 1);           // position group
     t.b = (wave >> clog2(d.PG)) & (d.CG - 1);   // channel group
     t.ks = 0;
@@ -412,6 +417,63 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
         if (UP) lds4(eb + d.N * 4) = acco[pt];
       }
     }
+  }
+  if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
+  FZ_STAMP(I, 1);
+  lds_barrier();
+  FZ_STAMP(I, 2);
+  x_epilogue<I>(cx, tid);
+  FZ_STAMP(I, 3);
+  build_next<I>(tid, p1, c.p);
+  FZ_STAMP(I, 4);
+}
+
+// ---- conv op, tiny layers (<= 8 positions): 4x4x1 tiles -- one MFMA = 16 blocks of (4 channels x 4 positions), one K step ----
+// Lane (block b, j): A = weight of channel 4 b + (lane & 3), B = activation of position j (the same for every block),
+// D = channels 4 b .. 4 b + 3 of position j.  All 8 waves split K (time tap x channel range of every frequency-tap
+// segment); a 32-channel layer runs two K slices in the two halves of the 16 blocks.  Exchange + row-wise epilogue as X16.
+template <int I, int N1, int N3>
+__device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
+  constexpr OpD d = kOps[I];
+  constexpr int PT = d.PT, VH = d.N < 64 ? 2 : 1, KSc = d.KSg, CPS = d.cin / KSc, FPS = CPS / 4, SEGW = d.nseg / d.KSt;
+  constexpr int NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d), OPB = (NTOT + 4) * 4;
+  static_assert(d.rounds == 1 && !is_up(d), "X4 path: single-round, not the up-sampling layer");
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Task t = conv_task<I>(wave);
+  const int b = lane >> 2, j = lane & 3, hv = VH == 2 ? (b >> 3) : 0;
+  const int v = t.b * VH + hv, ks_t = v / KSc, ks_c = v % KSc;
+  int lane_b[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    int pos = 4 * pt + j;
+    if (pos > d.P - 1) pos = d.P - 1;
+    lane_b[pt] = pos * d.img.pitch_b + ks_t * d.img.tap_b + ks_c * (CPS * 4);
+  }
+  f32x4 acc[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
+  const unsigned lane16 = static_cast<unsigned>(lane * 16);
+  pin_regs(c.w);
+  sfor<NF>([&](auto ff) {
+    constexpr int f = decltype(ff)::value;
+    constexpr int s = f / FPS, g = f % FPS, sf = f / 4;
+    const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const f32x4 bq = lds4(lane_b[pt] + d.seg_b[s] + g * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[pt] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[q], bq[q], acc[pt], 0, 0, 0);
+    }
+    if constexpr ((f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
+      c.w[sf % CW] = ldb(wbase + static_cast<unsigned long long>((sf + CW) * 1024), lane16);
+      sched_pin();
+    }
+  });
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int pos = 4 * pt + j;
+    if (pos < d.P) lds4(d.ex_b + (v * d.P + pos) * OPB + (64 * t.a + 4 * (VH == 2 ? (b & 7) : b)) * 4) = acc[pt];
   }
   if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
   FZ_STAMP(I, 1);
@@ -769,6 +831,7 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
     build_next<I>(tid, p1, c.p);
   } else if constexpr (d.type == T_CONV) {
     if constexpr (d.path == P_X16) conv_x16<I>(cx, tid, c, p1, p3);
+    else if constexpr (d.path == P_X4) conv_x4<I>(cx, tid, c, p1, p3);
     else conv_r32<I>(cx, tid, c, p1, p3);
   } else if constexpr (d.type == T_LSTM) {
     lstm_op<I>(cx, tid, c);

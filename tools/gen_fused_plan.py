@@ -44,7 +44,7 @@ DEC = [("msfe3_de", 3, 8, "msfe3_de", "msfe3_dd", "msfe3_upsampling"),
 
 T_INPUT, T_CONV, T_LSTM, T_CTFA = 0, 1, 2, 3
 K_IN, K_EL, K_DL, K_DOWN, K_UP = 0, 1, 2, 3, 4
-P_R32, P_X16 = 0, 1
+P_R32, P_X16, P_X4 = 0, 1, 2
 S_PREV, S_CUR, S_SCRATCH = 0, 1, 2
 LDS_BYTES = 160 * 1024
 SCR_BYTES = 8192
@@ -136,6 +136,17 @@ def tiling(kind, N, P, cin, taps, rounds=1):
         PT, NT, PG, CG = R32_TABLE[(kind, N, P)]
         return dict(path=P_R32, PT=PT, NT=NT, PG=PG, CG=CG, KSt=1, KSg=1)
     assert P <= 64, (kind, N, P)
+    if P <= 8 and kind != K_UP and os.environ.get("NUTLS_PLAN_NO_X4") is None:
+        # 4x4x1 MFMA (16 blocks of 4 channels x 4 positions, one K step per instruction): a tile is 64 channels x 4 positions,
+        # so layers with <= 8 positions waste nothing on position padding.  All 8 waves split K; a 32-channel layer uses the
+        # two halves of the 16 blocks as two K slices (VH = 2).
+        CG = max(1, N // 64)
+        VH = 2 if N < 64 else 1
+        KS = (8 // CG) * VH
+        KSt = min(taps, 2)
+        KSc = KS // KSt
+        assert cin % (4 * KSc) == 0, (kind, N, P, cin)
+        return dict(path=P_X4, PT=(P + 3) // 4, NT=1, PG=1, CG=CG, KSt=KSt, KSg=KSc)
     CT = N // 16
     G16 = cin // 16
     KS = max(1, 8 // CT)
@@ -228,9 +239,12 @@ def build():
         segw = 3 if kind == K_UP else len(g["seg_b"]) // o["KSt"]
         nf = segw * (G // o["KSg"]) * o["NT"]
         wtasks = o["CG"] * o["KSt"] * o["KSg"]
+        if o["path"] == P_X4:
+            nf = segw * (cin // o["KSg"] // 4)          # fragments (64 channels x 4 K) per wave
+            wtasks = 8
         o["w_off"] = W.add(wtasks * ((nf + 3) // 4) * 256, "conv_w", wkey)
         o["p_off"] = W.add(2 * ntot + 2 * gc + 1, "conv_p", wkey)      # bias | gamma | beta | alpha | per-channel weight scale
-        if o["path"] == P_X16:
+        if o["path"] in (P_X16, P_X4):
             ks = o["KSt"] * o["KSg"]
             ex = ks * P * (ntot + 4) * 4
             o["ex_b"] = (SCR_B - ex) // 256 * 256
@@ -377,13 +391,13 @@ def build():
         if o["type"] != T_CONV:
             continue
         g = o["img"]
-        lim = o["ex_b"] if o["path"] == P_X16 else SCR_B
+        lim = o["ex_b"] if o["path"] in (P_X16, P_X4) else SCR_B
         assert g["bytes"] <= lim, (o["name"], g["bytes"], lim)
         if o["nxt"] >= 0:
             assert ops[o["nxt"]]["img"]["bytes"] <= lim, (o["name"], "next image over the exchange buffer")
         assert len(o["parts"]) <= MAX_PARTS and len(g["zero"]) <= MAX_ZERO and o["nseg"] <= MAX_SEG
         tasks = o["PG"] * o["CG"] * o["KSt"] * o["KSg"]
-        assert tasks in (1, 2, 4, 8), (o["name"], tasks)
+        assert tasks in (1, 2, 4, 8) or o["path"] == P_X4, (o["name"], tasks)
         if o["path"] == P_R32:
             assert o["P"] % (32 * o["PT"] * o["PG"]) == 0 and (not o["ln"] or o["NT"] * 32 == o["gc"])
     # Same-frame HBM hand-offs (skip connections): the loads of a staged part may only be issued after a
