@@ -165,15 +165,20 @@ bool fused_pack_blob(const WeightMap& wm, std::vector<float>* out, std::string* 
         *err = "unexpected LSTM / Dense shape for " + ln;
         return false;
       }
+      // [x ; h ; 3 zero rows] x 84 gate columns, column 4 u + g = gate g (i, f, g, o) of unit u; bias in the same order;
+      // Dense as one row of 24 per output: 21 weights, bias, 2 x 0
+      auto col = [](int n) { return 4 * (n % 21) + n / 21; };       // Keras column gate * 21 + unit -> interleaved
       for (int k = 0; k < din; ++k)
-        for (int n = 0; n < 84; ++n) dst[k * 84 + n] = wx->data[static_cast<size_t>(n) * din + k];
+        for (int n = 0; n < 84; ++n) dst[k * 84 + col(n)] = wx->data[static_cast<size_t>(n) * din + k];
       for (int u = 0; u < 21; ++u)
-        for (int n = 0; n < 84; ++n) dst[(din + u) * 84 + n] = wh->data[static_cast<size_t>(n) * 21 + u];
-      for (int n = 0; n < 84; ++n) dst[(din + 21) * 84 + n] = b->data[n];
-      float* wdT = dst + (din + 22) * 84;
-      for (int u = 0; u < 21; ++u)
-        for (int n = 0; n < dout; ++n) wdT[u * dout + n] = wd->data[static_cast<size_t>(n) * 21 + u];
-      for (int n = 0; n < dout; ++n) wdT[21 * dout + n] = bd->data[n];
+        for (int n = 0; n < 84; ++n) dst[(din + u) * 84 + col(n)] = wh->data[static_cast<size_t>(n) * 21 + u];
+      float* bp = dst + (din + 24) * 84;
+      for (int n = 0; n < 84; ++n) bp[col(n)] = b->data[n];
+      float* wdr = bp + 84;
+      for (int n = 0; n < dout; ++n) {
+        for (int u = 0; u < 21; ++u) wdr[n * 24 + u] = wd->data[static_cast<size_t>(n) * 21 + u];
+        wdr[n * 24 + 21] = bd->data[n];
+      }
     } else if (bi.what == 3) {
       int o = 0;
       for (const char* br : {"_ta", "_fa"}) {

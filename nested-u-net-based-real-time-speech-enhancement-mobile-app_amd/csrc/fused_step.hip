@@ -135,12 +135,13 @@ constexpr int nxt_of(int i) { return (i >= 0 && i < kNumOps) ? kOps[i].nxt : -1;
 constexpr int nxt_regs(int i, int cls) { return nxt_of(i) >= 0 ? parts_regs(kOps[nxt_of(i)].img, cls) : 0; }
 constexpr int own_regs(int i, int cls) { return (i < kNumOps && kOps[i].type == T_CONV) ? parts_regs(kOps[i].img, cls) : 0; }
 constexpr int ctfa_ni(const OpD& d) { return (d.F + 31) / 32; }
+constexpr int lstm_s0(const OpD& d) { return cmax(d.din / 16, 6); }      // carry slots of the gate weights (see lstm_op)
 constexpr int carry_w(int i) {
   if (i >= kNumOps) return 0;
   const OpD& d = kOps[i];
   if (d.type == T_CONV) return ring_sf(d);
-  if (d.type == T_LSTM) return d.din / 16;
-  if (d.type == T_CTFA) return ctfa_ni(d);
+  if (d.type == T_LSTM) return lstm_s0(d) + 10;
+  if (d.type == T_CTFA) return ctfa_ni(d) + 2;
   return 0;
 }
 
@@ -267,13 +268,31 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
       }
       if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>(tid * 16));
     } else if constexpr (d.type == T_LSTM) {
-      constexpr int KN = d.din / 16;
+      // everything lstm_op needs from memory (slot map there), one op ahead
+      constexpr int KN = d.din / 16, S0 = lstm_s0(d), WB = d.lw_off, BIAS = WB + (d.din + 24) * 84, WD = BIAS + 84;
+      const int u = tid % 21, sl = tid / 21;
       if (tid < 336) {
-        const int n4 = tid % 21, sl = tid / 21;
         sfor<KN>([&](auto jj) {
           constexpr int j = decltype(jj)::value;
-          w[j] = ldb(cx.wb, static_cast<unsigned>((d.lw_off + (sl * KN + j) * 84 + 4 * n4) * 4));
+          w[j] = ldb(cx.wb, static_cast<unsigned>((WB + (sl * KN + j) * 84 + 4 * u) * 4));
         });
+      } else if (tid < 420) {
+        const int hs = sl - 16;
+        sfor<6>([&](auto jj) {
+          constexpr int j = decltype(jj)::value;
+          w[j] = ldb(cx.wb, static_cast<unsigned>((WB + (d.din + 6 * hs + j) * 84 + 4 * u) * 4));
+          w[S0 + j / 4][j % 4] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + 6 * hs + j) * 4));      // (h[21..23]: slot padding, zero)
+        });
+      }
+      if (tid < d.dout) {
+        sfor<6>([&](auto jj) {
+          constexpr int j = decltype(jj)::value;
+          w[S0 + 2 + j] = ldb(cx.wb, static_cast<unsigned>((WD + tid * 24 + 4 * j) * 4));
+        });
+      }
+      if (tid < 21) {
+        w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((BIAS + 4 * tid) * 4));
+        w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + tid) * 4));
       }
     } else if constexpr (d.type == T_CTFA) {
       constexpr int NI = ctfa_ni(d);
@@ -284,6 +303,10 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
         if (f > d.F - 1) f = d.F - 1;
         w[i] = ldb(cx.sbc, static_cast<unsigned>((d.e0_off + f * d.e0_ld + 4 * c4) * 4));
       });
+      if constexpr (d.last) {
+        w[NI] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 4256 + 4 * c4) * 4));                     // output conv weights
+        w[NI + 1][0] = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 4320) * 4));
+      }
     }
   }
 }
@@ -449,9 +472,11 @@ __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, con
     if (pos > d.P - 1) pos = d.P - 1;
     lane_b[pt] = pos * d.img.pitch_b + ks_t * d.img.tap_b + ks_c * (CPS * 4);
   }
-  f32x4 acc[PT];
+  f32x4 acc4[PT][4];           // one accumulator per K step of a fragment: four independent MFMA chains
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc4[pt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   pin_regs(c.w);
@@ -463,7 +488,7 @@ __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, con
     for (int pt = 0; pt < PT; ++pt) {
       const f32x4 bq = lds4(lane_b[pt] + d.seg_b[s] + g * 16);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[pt] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[q], bq[q], acc[pt], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) acc4[pt][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[q], bq[q], acc4[pt][q], 0, 0, 0);
     }
     if constexpr ((f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
       c.w[sf % CW] = ldb(wbase + static_cast<unsigned long long>((sf + CW) * 1024), lane16);
@@ -473,7 +498,7 @@ __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, con
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int pos = 4 * pt + j;
-    if (pos < d.P) lds4(d.ex_b + (v * d.P + pos) * OPB + (64 * t.a + 4 * (VH == 2 ? (b & 7) : b)) * 4) = acc[pt];
+    if (pos < d.P) lds4(d.ex_b + (v * d.P + pos) * OPB + (64 * t.a + 4 * (VH == 2 ? (b & 7) : b)) * 4) = (acc4[pt][0] + acc4[pt][1]) + (acc4[pt][2] + acc4[pt][3]);
   }
   if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
   FZ_STAMP(I, 1);
@@ -654,50 +679,39 @@ __device__ __forceinline__ void input_op(const Ctx& cx, int tid) {
 // ---- LSTM cell + Dense (proposed.py:70-119; converter_proposed.py:234-237), in place on the next conv's image ------------
 template <int I>
 __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
+  // z = [x ; h] . [Wx ; Wh] + b with the gate columns interleaved (column 4 u + g: gate g of unit u), so that one float4
+  // is (i, f, g, o) of a unit.  K is cut into 16 slices of x (threads (u, slice), tid < 336) and 4 slices of h
+  // (tid 336..419); every operand arrived in the carry (slot map: [0, S0) weight rows of the thread's slice,
+  // [S0, S0+2) its h values, [S0+2, S0+8) the Dense row of output tid, S0+8 the unit's bias, S0+9 its cell state).
   constexpr OpD d = kOps[I];
-  constexpr int KN = d.din / 16, XS = clog2(d.x_cols);
-  constexpr int PART = SCR_B, Z = SCR_B + 16 * 84 * 4, HN = Z + 96 * 4;
-  // recurrent product, bias, cell state, dense weights: requested now, used after the first barrier
-  float wh[21], hprev[21], wd[21];
-  float bias = 0.f, c_old = 0.f, bd = 0.f;
-  if (tid < 84) {
-#pragma unroll
-    for (int u = 0; u < 21; ++u) {
-      wh[u] = ldb1(cx.wb, static_cast<unsigned>((d.lw_off + (d.din + u) * 84 + tid) * 4));
-      hprev[u] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + u) * 4));
-    }
-    bias = ldb1(cx.wb, static_cast<unsigned>((d.lw_off + (d.din + 21) * 84 + tid) * 4));
-  }
-  if (tid < 21) c_old = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + tid) * 4));
-  if (tid < d.dout) {
-#pragma unroll
-    for (int u = 0; u < 21; ++u) wd[u] = ldb1(cx.wb, static_cast<unsigned>((d.lw_off + (d.din + 22) * 84 + u * d.dout + tid) * 4));
-    bd = ldb1(cx.wb, static_cast<unsigned>((d.lw_off + (d.din + 22) * 84 + 21 * d.dout + tid) * 4));
-  }
+  constexpr int KN = d.din / 16, XS = clog2(d.x_cols), S0 = lstm_s0(d);
+  constexpr int PART = SCR_B, HN = SCR_B + 20 * 21 * 16;
+  const int u = tid % 21, sl = tid / 21;
+  pin_regs(c.w);
   if (tid < 336) {
-    const int n4 = tid % 21, sl = tid / 21;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < KN; ++j) {
       const int k = sl * KN + j;
       a += c.w[j] * lds1(d.x_b + (k >> XS) * d.x_pitch_b + (k & (d.x_cols - 1)) * 4);
     }
-    lds4(PART + (sl * 84 + 4 * n4) * 4) = a;
-  }
-  lds_barrier();
-  if (tid < 84) {
-    float a = bias;
+    lds4(PART + (sl * 21 + u) * 16) = a;
+  } else if (tid < 420) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) a += lds1(PART + (s2 * 84 + tid) * 4);
-    float r = 0.f;
-#pragma unroll
-    for (int u = 0; u < 21; ++u) r = fmaf(wh[u], hprev[u], r);
-    lds1(Z + tid * 4) = a + r;
+    for (int j = 0; j < 6; ++j) {
+      const float hv = c.w[S0 + j / 4][j % 4];
+      a += c.w[j] * hv;
+    }
+    lds4(PART + (sl * 21 + u) * 16) = a;
   }
   lds_barrier();
   if (tid < 21) {
-    const float gi = fast_sigmoid(lds1(Z + tid * 4)), gf = fast_sigmoid(lds1(Z + (21 + tid) * 4));
-    const float gg = fast_tanh(lds1(Z + (42 + tid) * 4)), go = fast_sigmoid(lds1(Z + (63 + tid) * 4));
+    f32x4 z = c.w[S0 + 8];
+#pragma unroll
+    for (int s2 = 0; s2 < 20; ++s2) z += lds4(PART + (s2 * 21 + tid) * 16);
+    const float c_old = c.w[S0 + 9][0];
+    const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
     const float c_new = gf * c_old + gi * gg;
     const float h_new = go * fast_tanh(c_new);
     stb1(cx.sbc, static_cast<unsigned>((d.c_off + tid) * 4), c_new);
@@ -706,9 +720,13 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
   }
   lds_barrier();
   if (tid < d.dout) {
-    float a = bd;
+    float a = c.w[S0 + 2 + 5][1];          // bd
 #pragma unroll
-    for (int u = 0; u < 21; ++u) a = fmaf(wd[u], lds1(HN + u * 4), a);
+    for (int q = 0; q < 5; ++q) {
+      const f32x4 h4 = lds4(HN + 16 * q), w4 = c.w[S0 + 2 + q];
+      a += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
+    }
+    a = fmaf(c.w[S0 + 2 + 5][0], lds1(HN + 80), a);
     const int f = tid >> XS, cc = tid & (d.x_cols - 1);
     lds1(d.y_b + f * d.x_pitch_b + cc * 4) = a;
     if constexpr (d.ldst_on) stb1(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4), a);
@@ -749,10 +767,10 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
   constexpr int NI = ctfa_ni(d);
   constexpr int PART = SCR_B, GATE = SCR_B + 512 * 4, MSCR = GATE + 64 * 4;
   const int c4 = tid & 15, rg = tid >> 4, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // gate perceptrons (wave 0: lane c holds its 16 input / output weights of each of the four matrices): requested now,
+  // used after the column sums.  (In the carry they would cost every wave of the preceding sub-pixel conv 64 registers.)
   float b1t = 0.f, b1f = 0.f, b2t = 0.f, b2f = 0.f;
-  f32x4 ow = {0.f, 0.f, 0.f, 0.f};
-  float ob = 0.f;
-  f32x4 w1t[4], w2t[4], w1f[4], w2f[4];       // gate perceptrons: lane c holds its 16 input / output weights of each matrix
+  f32x4 w1t[4], w2t[4], w1f[4], w2f[4];
   if (wave == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -766,10 +784,8 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
     b1f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 1024 + (lane & 15)) * 4));
     b2f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 2064 + lane) * 4));
   }
-  if constexpr (d.last) {
-    ow = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 4256 + 4 * c4) * 4));
-    ob = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 4320) * 4));
-  }
+  const f32x4 ow = c.w[NI];
+  const float ob = c.w[NI + 1][0];
   f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -865,20 +881,23 @@ struct FzArgs {
 #endif
 __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   constexpr bool PROF = FZ_PROF != 0;
-  for (int stream = blockIdx.x; stream < a.B; stream += gridDim.x) {
-    const float* slice = a.arena + static_cast<size_t>(stream) * a.sstride;
-    Ctx cx;
-    cx.sbs = (gcb_t)(unsigned long long)slice;
-    cx.sbc = (gcb_t)(unsigned long long)(slice + (a.par ? kParityStride : 0));
-    cx.sbp = (gcb_t)(unsigned long long)(slice + (a.par ? 0 : kParityStride));
-    cx.wb = (gcb_t)(unsigned long long)a.blob;
-    cx.io_in = (gcf_t)(unsigned long long)(a.io_in + static_cast<size_t>(stream) * 256);
-    cx.io_out = (gf_t)(unsigned long long)(a.io_out + static_cast<size_t>(stream) * 256);
-    cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
-    Carry<0> c0;
-    run_from<0, PROF>(cx, c0);
-    if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();
-  }
+  // One workgroup per stream, grid = B (the hardware queues the workgroups that do not fit).  No loop over streams here:
+  // everything that depends only on kernel arguments (hundreds of `blob + offset` bases) would be hoisted out of such a
+  // loop to the kernel entry, spilled, and re-loaded from scratch in the op prologues -- behind a full vmcnt(0) drain.
+  const int stream = blockIdx.x;
+  if (stream >= a.B) return;
+  const float* slice = a.arena + static_cast<size_t>(stream) * a.sstride;
+  Ctx cx;
+  cx.sbs = (gcb_t)(unsigned long long)slice;
+  cx.sbc = (gcb_t)(unsigned long long)(slice + (a.par ? kParityStride : 0));
+  cx.sbp = (gcb_t)(unsigned long long)(slice + (a.par ? 0 : kParityStride));
+  cx.wb = (gcb_t)(unsigned long long)a.blob;
+  cx.io_in = (gcf_t)(unsigned long long)(a.io_in + static_cast<size_t>(stream) * 256);
+  cx.io_out = (gf_t)(unsigned long long)(a.io_out + static_cast<size_t>(stream) * 256);
+  cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
+  Carry<0> c0;
+  run_from<0, PROF>(cx, c0);
+  if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();
 }
 
 }  // namespace fz

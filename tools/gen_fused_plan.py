@@ -275,7 +275,7 @@ def build():
             lst.append(conv_op("%s_conv%d" % (p, i), "%s_conv%d" % (p, i), K_EL, side, i, D, f0 >> i, d0=d0, d1=d1))
         l = new_op(type=T_LSTM, name=p + "_lstm", wkey=p, din=fd * 32, dout=fd * 32, x_cols=32,
                    h_off=A.off[p + "_h"], c_off=A.off[p + "_c"], ldst=(S_CUR, st_off(stg, 1), 64), drain=1)
-        l["lw_off"] = W.add((l["din"] + 21 + 1) * 84 + 21 * l["dout"] + l["dout"], "lstm", p)
+        l["lw_off"] = W.add((l["din"] + 24) * 84 + 84 + 24 * l["dout"], "lstm", p)
         lst.append(l)
         for j in range(1, D + 1):
             P = fd << (j - 1)
@@ -298,7 +298,7 @@ def build():
         p, D, f0, ct, stg, rs = ENC[s]
         downs[s] = conv_op(rs, rs, K_DOWN, 0, 0, D, f0 // 2, d0=(S_SCRATCH, A.scratch["upcat%d" % (5 - s)] + 64, 128))
     cl = new_op(type=T_LSTM, name="lstm", wkey="", din=256, dout=256, x_cols=64, h_off=A.off["state_h"], c_off=A.off["state_c"], ldst=None, drain=1)
-    cl["lw_off"] = W.add((256 + 21 + 1) * 84 + 21 * 256 + 256, "lstm", "")
+    cl["lw_off"] = W.add((256 + 24) * 84 + 84 + 24 * 256, "lstm", "")
     ups = {}
     for s in range(6):
         p, D, f0, ct, stg, rs = DEC[s]
