@@ -1613,11 +1613,14 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n) {
     if (FILE* f = fopen(dump, "w")) {
       for (int i = 0; i < n; ++i) {
         fprintf(f, "%-24s total %6.2f |", fused_op_name(i), us[i]);
-        const char* nm[5] = {"issue", "mfma", "bar1", "epi", "build"};
+        // stamp slots in chronological order: 0 loads issued, 5 carried weights arrived, 6 MFMA loop done (4x4 path),
+        // 1 partials / parameters written, 2 past barrier 1, 3 epilogue done, 4 next image built
+        const int order[7] = {0, 5, 6, 1, 2, 3, 4};
+        const char* nm[7] = {"issue", "wwait", "mloop", "mfma", "bar1", "epi", "build"};
         unsigned long long prev = t[i];
-        for (int k = 0; k < 5; ++k) {
-          const unsigned long long v = sub[8 * i + k];
-          if (v >= t[i] && v <= t[i + 1]) { fprintf(f, " %s %5.2f", nm[k], static_cast<double>(v - prev) * 1000.0 / khz); prev = v; }
+        for (int k = 0; k < 7; ++k) {
+          const unsigned long long v = sub[8 * i + order[k]];
+          if (v >= prev && v <= t[i + 1]) { fprintf(f, " %s %5.2f", nm[k], static_cast<double>(v - prev) * 1000.0 / khz); prev = v; }
         }
         fprintf(f, " bar2 %5.2f\n", static_cast<double>(t[i + 1] - prev) * 1000.0 / khz);
       }

@@ -151,7 +151,11 @@ template <int I>
 struct Carry {
   f32x4 w[cmax(1, carry_w(I))];
   f32x4 p[cmax(1, nxt_regs(I, 2))];
-  f32x4 prm;                   // conv ops: this thread's float4 of the epilogue parameter block (bias | gamma | beta | alpha)
+  f32x4 prm;                   // conv ops: this thread's float4 of the epilogue parameter block (bias | scale | gamma | beta | alpha)
+  // the same for op I+1, already requested by op I-1: weights are fetched TWO ops ahead (a fetch that misses L2 -- the
+  // state tensors stream through it all the time -- takes longer than one small op)
+  f32x4 w2[cmax(1, carry_w(I + 1))];
+  f32x4 prm2;
 };
 
 // ---- staging: HBM tensor blocks -> registers -> LDS image -------------------------------------------------
@@ -397,6 +401,7 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   if (t.active) pin_regs(c.w);
+  FZ_STAMP(I, 5);
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
     if (t.active) {
@@ -480,6 +485,7 @@ __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, con
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   pin_regs(c.w);
+  FZ_STAMP(I, 5);
   sfor<NF>([&](auto ff) {
     constexpr int f = decltype(ff)::value;
     constexpr int s = f / FPS, g = f % FPS, sf = f / 4;
@@ -495,6 +501,7 @@ __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, con
       sched_pin();
     }
   });
+  FZ_STAMP(I, 6);
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     const int pos = 4 * pt + j;
@@ -535,6 +542,7 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   if (t.active) pin_regs(c.w);
+  FZ_STAMP(I, 5);
   f32x4 b[PT];
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
@@ -837,8 +845,11 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
   f32x4 p3[cmax(1, own_regs(I, 3))];
   stage_load<nxt_of(I), 1>(cx, tid, p1);
   stage_load<I, 3>(cx, tid, p3);
-  prefetch_w<I + 1>(cx, tid, n.w, n.prm);
   stage_load<nxt_of(I + 1), 2>(cx, tid, n.p);
+#pragma unroll
+  for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
+  n.prm = c.prm2;
+  prefetch_w<I + 2>(cx, tid, n.w2, n.prm2);
   sched_pin();
   FZ_STAMP(I, 0);
 
@@ -896,6 +907,10 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.io_out = (gf_t)(unsigned long long)(a.io_out + static_cast<size_t>(stream) * 256);
   cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
   Carry<0> c0;
+  {
+    int tid = threadIdx.x;
+    prefetch_w<1>(cx, tid, c0.w2, c0.prm2);
+  }
   run_from<0, PROF>(cx, c0);
   if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();
 }
