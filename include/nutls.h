@@ -97,6 +97,15 @@ int nutls_istft_hop(nutls_handle* h, float* pcm_out, int dc_mode, void* stream);
  * and is zeroed by nutls_reset(h, -1).  mag_in / mag_out: DEVICE pointers to [n_frames, 256] float32. */
 int nutls_create_offline(const void* weights, size_t n_bytes, int max_frames, int device, nutls_handle** out);
 int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames, void* stream);
+/* The frequency-attention branch of CTFA in offline handles:
+ *   NUTLS_CTFA_FRAME     (default) what the frame-wise graph computes: the branch sees TA/32 (ctfa_rt with T = 1,
+ *                        proposed.py:162-196) -- offline results equal the streaming ones;
+ *   NUTLS_CTFA_CAUSAL32  the offline / training model (`ctfa`, proposed.py:125-160, :143-147): the mean of the time
+ *                        attention over the last 32 real frames (zeros before the utterance starts).  The 31-frame
+ *                        history carries from block to block; switching modes or nutls_reset clears it. */
+#define NUTLS_CTFA_FRAME 0
+#define NUTLS_CTFA_CAUSAL32 1
+int nutls_offline_set_ctfa_mode(nutls_handle* h, int mode);
 /* Same with HOST buffers (synchronises). */
 int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames);
 

@@ -127,6 +127,8 @@ struct Engine {
   int offline = 0;       // > 0: offline / block handle for up to this many frames per call (arena slot 0 = carried state)
   std::vector<Launch> plan_off;   // plan[0] with 'previous frame' = one arena slot earlier
   float* zx = nullptr;   // [offline][84] LSTM input products of a block
+  int ctfa_causal = 0;   // offline handles: 1 = true 32-frame causal average in the CTFA frequency branch (proposed.py:143-147)
+  float* ta_hist = nullptr;   // [12 stages][31 + offline][64] time-attention history (causal mode)
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
   int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel (plan interpreter),
                          // 3 fused kernel (statically scheduled, LSTM variant only)
@@ -1147,7 +1149,20 @@ static int build_offline_plan(Engine* e) {
       case Launch::DDB: return fail(NUTLS_ERR_ARG, "offline mode: LSTM variant only");
     }
   }
-  return dev_alloc(e, static_cast<size_t>(e->offline) * 84, &e->zx, true);
+  int rc = dev_alloc(e, static_cast<size_t>(e->offline) * 84, &e->zx, true);
+  if (rc) return rc;
+  return dev_alloc(e, static_cast<size_t>(12) * (31 + e->offline) * 64, &e->ta_hist, true);
+}
+
+int nutls_offline_set_ctfa_mode(nutls_handle* h, int mode) {
+  if (!h || !h->eng.offline) return fail(NUTLS_ERR_ARG, "nutls_offline_set_ctfa_mode: not an offline handle");
+  if (mode != NUTLS_CTFA_FRAME && mode != NUTLS_CTFA_CAUSAL32) return fail(NUTLS_ERR_ARG, "nutls_offline_set_ctfa_mode: unknown mode");
+  Engine* e = &h->eng;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(e->ta_hist, 0, static_cast<size_t>(12) * (31 + e->offline) * 64 * sizeof(float)));      // a mode switch starts a new history
+  e->ctfa_causal = mode == NUTLS_CTFA_CAUSAL32;
+  return NUTLS_OK;
 }
 
 int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames, void* stream) {
@@ -1159,13 +1174,19 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = static_cast<size_t>(n_frames) * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
+  int n_ctfa = 0;
   for (const Launch& L0 : e->plan_off) {
     Launch L = L0;
     hipError_t err = hipSuccess;
     switch (L.kind) {
       case Launch::CONV: L.conv.B = n_frames; err = launch_conv(L.ck, L.conv, s); break;
       case Launch::LSTM: L.lstm.B = n_frames; err = launch_lstm_block(L.lstm, e->zx, n_frames, s); break;
-      case Launch::CTFA: L.ctfa.B = n_frames; err = launch_ctfa(L.ctfa, s); break;
+      case Launch::CTFA:
+        L.ctfa.B = n_frames;
+        if (e->ctfa_causal) err = launch_ctfa_causal(L.ctfa, e->ta_hist + static_cast<size_t>(n_ctfa) * (31 + e->offline) * 64, s);
+        else err = launch_ctfa(L.ctfa, s);
+        ++n_ctfa;
+        break;
       case Launch::INLAYER: L.inl.n_pos = n_frames * NUTLS_BINS; err = launch_input_layer(L.inl, s); break;
       case Launch::OUTCONV: L.outc.n_pos = n_frames * NUTLS_BINS; err = launch_out_conv(L.outc, s); break;
       default: err = hipErrorInvalidValue;
@@ -1432,6 +1453,7 @@ int nutls_reset(nutls_handle* h, int stream_idx) {
   // a stream's whole slice of the arena (state of both parities + scratch) is contiguous
   if (stream_idx < 0) HIP_TRY(hipMemset(e->arena, 0, e->sstride * sizeof(float) * e->B));
   else HIP_TRY(hipMemset(e->arena + e->sstride * stream_idx, 0, e->sstride * sizeof(float)));
+  if (e->ta_hist) HIP_TRY(hipMemset(e->ta_hist, 0, static_cast<size_t>(12) * (31 + e->offline) * 64 * sizeof(float)));
   if (e->fe_tail) {   // STFT front / back end: previous hop and overlap tail
     const size_t hop = NUTLS_FRAME_STEP * sizeof(float);
     if (stream_idx < 0) {

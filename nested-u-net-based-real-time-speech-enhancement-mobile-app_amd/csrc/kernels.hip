@@ -384,6 +384,104 @@ __global__ __launch_bounds__(256) void ctfa_kernel(const CtfaParams p) {
   }
 }
 
+// ---- CTFA with the TRUE 32-frame causal average of the offline model (models/proposed.py:125-160 `ctfa`:
+// ZeroPadding2D((31,0)) + AveragePooling1D(32, strides=1) over the time-attention vectors of real frames), offline / block
+// mode only.  hist [31 + frames][64]: rows 0..30 = TA of the 31 frames before this block (zeros at the start of an
+// utterance), row 31 + t = TA of block frame t.  Pass 1 (parallel over frames): TA.  Pass 2: FA from the mean of the last
+// 32 TA rows, gate, residual.  Pass 3: the last 31 rows move to the front for the next block.
+__global__ __launch_bounds__(256) void ctfa_ta_kernel(const CtfaParams p, float* __restrict__ hist) {
+  __shared__ __attribute__((aligned(16))) float part[16][64];
+  __shared__ float m[64];
+  __shared__ float hid[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c4 = tid & 15, rg = tid >> 4;
+  const float* xb = p.x + static_cast<size_t>(b) * p.sstride;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int f = rg; f < p.F; f += 16) s += *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
+  *reinterpret_cast<f32x4*>(&part[rg][4 * c4]) = s;
+  __syncthreads();
+  if (tid < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += part[r][tid];
+    m[tid] = a / static_cast<float>(p.F);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float a = p.ta_b1[tid];
+    for (int c = 0; c < 64; ++c) a = fmaf(p.ta_w1T[c * 16 + tid], m[c], a);
+    hid[tid] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float a = p.ta_b2[tid];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a = fmaf(p.ta_w2T[u * 64 + tid], hid[u], a);
+    hist[static_cast<size_t>(31 + b) * 64 + tid] = sigmoid_f(a);
+  }
+}
+
+__global__ __launch_bounds__(256) void ctfa_apply_causal_kernel(const CtfaParams p, const float* __restrict__ hist) {
+  __shared__ float avg[64];
+  __shared__ float hid[16];
+  __shared__ __attribute__((aligned(16))) float gate[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c4 = tid & 15, rg = tid >> 4;
+  float ta = 0.f;
+  if (tid < 64) {
+    float a = 0.f;
+    for (int k = 0; k < 32; ++k) a += hist[static_cast<size_t>(31 + b - k) * 64 + tid];      // oldest rows are zeros before the utterance starts
+    avg[tid] = a * (1.0f / 32.0f);
+    ta = hist[static_cast<size_t>(31 + b) * 64 + tid];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float a = p.fa_b1[tid];
+    for (int c = 0; c < 64; ++c) a = fmaf(p.fa_w1T[c * 16 + tid], avg[c], a);
+    hid[tid] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float a = p.fa_b2[tid];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a = fmaf(p.fa_w2T[u * 64 + tid], hid[u], a);
+    gate[tid] = sigmoid_f(a) * ta;
+  }
+  __syncthreads();
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(&gate[4 * c4]);
+  const float* xb = p.x + static_cast<size_t>(b) * p.sstride;
+  const float* eb = p.e0 + static_cast<size_t>(b) * p.sstride;
+  float* yb = p.y + static_cast<size_t>(b) * p.sstride;
+  for (int f = rg; f < p.F; f += 16) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
+    const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
+    *reinterpret_cast<f32x4*>(yb + static_cast<size_t>(f) * p.y_ld + 4 * c4) = xv * g4 + ev;
+  }
+}
+
+__global__ __launch_bounds__(1024) void ctfa_hist_roll_kernel(float* __restrict__ hist, int frames) {
+  const int tid = threadIdx.x;          // 31 x 64 = 1984 values, two per thread: read everything, then write (the ranges overlap when frames < 31)
+  float v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 1024 * i;
+    v[i] = e < 31 * 64 ? hist[static_cast<size_t>(frames) * 64 + e] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 1024 * i;
+    if (e < 31 * 64) hist[e] = v[i];
+  }
+}
+
+hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, hipStream_t s) {
+  hipLaunchKernelGGL(ctfa_ta_kernel, dim3(p.B), dim3(256), 0, s, p, hist);
+  hipLaunchKernelGGL(ctfa_apply_causal_kernel, dim3(p.B), dim3(256), 0, s, p, hist);
+  hipLaunchKernelGGL(ctfa_hist_roll_kernel, dim3(1), dim3(1024), 0, s, hist, p.B);
+  return hipGetLastError();
+}
+
 hipError_t launch_ctfa(const CtfaParams& p, hipStream_t s) {
   hipLaunchKernelGGL(ctfa_kernel, dim3(p.B), dim3(256), 0, s, p);
   return hipGetLastError();

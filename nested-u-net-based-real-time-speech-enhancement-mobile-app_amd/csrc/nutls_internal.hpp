@@ -123,6 +123,8 @@ struct CtfaParams {
   long long sstride;
 };
 hipError_t launch_ctfa(const CtfaParams& p, hipStream_t s);
+// offline / block mode, true 32-frame causal average of the time attention (models/proposed.py:143-147); hist [31 + p.B][64]
+hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, hipStream_t s);
 
 struct InLayerParams {   // input_layer: 1x1 conv 1->64 + LN + PReLU
   const float* x;        // [B,256]

@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
     "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
-    "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all",
+    "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all", "nutls_offline_set_ctfa_mode",
 )
 
 
@@ -82,6 +82,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_create_offline.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
     lib.nutls_process_block.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_process_block_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
+    lib.nutls_offline_set_ctfa_mode.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_fused_num_ops.argtypes = []
     lib.nutls_fused_op_info.argtypes = [c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
     lib.nutls_profile_fused.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
@@ -403,12 +404,21 @@ class NutlsOffline:
     the stream index), only the LSTM recurrences are scanned.  Same function as a batch-1 streaming engine
     fed frame by frame; the state carries over between calls until :meth:`reset`."""
 
-    def __init__(self, weights=None, max_frames: int = 256, device: int = 0):
+    CTFA_MODES = {"frame": 0, "causal32": 1}
+
+    def __init__(self, weights=None, max_frames: int = 256, device: int = 0, ctfa_mode: str = "frame"):
+        """``ctfa_mode``: "frame" (default; the frame-wise graph's TA/32, equal to the streaming result) or "causal32"
+        (the offline model's true 32-frame causal average of the time attention, models/proposed.py:143-147)."""
+        if ctfa_mode not in self.CTFA_MODES:
+            raise ValueError("ctfa_mode must be one of %s" % sorted(self.CTFA_MODES))
         self._lib = load_library()
         blob = read_blob(weights if weights is not None else DEFAULT_WEIGHTS)
         self._h = ctypes.c_void_p()
         self.max_frames = int(max_frames)
         _check(self._lib, self._lib.nutls_create_offline(blob, len(blob), self.max_frames, int(device), ctypes.byref(self._h)))
+        if ctfa_mode != "frame":
+            _check(self._lib, self._lib.nutls_offline_set_ctfa_mode(self._h, self.CTFA_MODES[ctfa_mode]))
+        self.ctfa_mode = ctfa_mode
 
     def process(self, mags) -> np.ndarray:
         """``mags [N,256]`` float32 (any N) -> enhanced magnitudes ``[N,256]``; blocks of ``max_frames``."""

@@ -58,6 +58,7 @@ class NutlsRef:
     # ---------------------------------------------------------------- state -------------
     def reset(self):
         """All-zero state, as the reference seeds it (interpreter_proposed.py:36-198)."""
+        self.ta_hist = {}
         for base, shp in T.state_specs(self.variant):
             if len(shp) == 1:
                 self.state[base] = torch.zeros(self.batch, shp[0])
@@ -198,7 +199,16 @@ class NutlsRef:
         With T = 1 the frequency-attention branch average-pools 31 zero frames and the
         current TA, i.e. sees TA/32 every frame."""
         ta = self._mlp_gate(x.mean(dim=1), prefix + "_ta")          # [B,64]
-        fa = self._mlp_gate(ta / 32.0, prefix + "_fa")
+        if self.ctfa_mode == "causal32":
+            # the offline / training model (`ctfa`, proposed.py:125-160): ZeroPadding2D((31,0)) + AveragePooling1D(32,
+            # strides=1) over the time-attention vectors of REAL frames = mean of the last 32 TA (zeros before the start)
+            hist = self.ta_hist.setdefault(prefix, torch.zeros(self.batch, 31, 64))
+            fa = self._mlp_gate((hist.sum(dim=1) + ta) / 32.0, prefix + "_fa")
+            self.ta_hist[prefix] = torch.cat([hist[:, 1:], ta.unsqueeze(1)], dim=1)
+        elif self.ctfa_mode == "frame":
+            fa = self._mlp_gate(ta / 32.0, prefix + "_fa")
+        else:
+            raise ValueError("ctfa_mode must be 'frame' or 'causal32'")
         return x * (ta * fa).unsqueeze(1) + e0
 
     # ---------------------------------------------------------------- stage -------------

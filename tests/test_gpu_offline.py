@@ -88,3 +88,24 @@ def test_offline_handle_state_get_set_addresses_the_carried_state():
     o2 = np.concatenate([eng.step(clip["mags_in"][i:i + 1]) for i in range(16, 24)])
     assert float(np.sqrt(np.mean((o1 - o2) ** 2))) < 2e-5
     off.close(); eng.close()
+
+
+def test_offline_causal32_ctfa_matches_oracle_across_block_boundaries(clip):
+    """The non-default CTFA option of the offline mode (true 32-frame causal average of the time attention,
+    models/proposed.py:143-147) against oracle B in the same mode, in blocks that do and do not divide 31."""
+    from oracle.nutls_ref import NutlsRef
+    n = 80
+    ref = NutlsRef(batch=1, ctfa_mode="causal32")
+    want = np.concatenate([ref.step(clip["mags_in"][i:i + 1]).numpy() for i in range(n)])
+    for T_ in (32, 7):
+        off = NutlsOffline(max_frames=T_, ctfa_mode="causal32")
+        got = off.process(clip["mags_in"][:n])
+        assert rms(got, want) < 2e-5, T_
+        off.reset()                                   # a reset clears the history: same result again
+        assert rms(off.process(clip["mags_in"][:n]), want) < 2e-5
+        off.close()
+    frame = NutlsOffline(max_frames=32)
+    streaming_form = frame.process(clip["mags_in"][:n])
+    assert rms(streaming_form[0], want[0]) < 2e-5      # frame 0: both see TA/32
+    assert rms(streaming_form[40:], want[40:]) > 1e-4  # later frames: a different function
+    frame.close()

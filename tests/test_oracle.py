@@ -246,3 +246,25 @@ def test_oracle_a_numpy_ops_agree_with_torch_functional():
     st = np.load(os.path.join(GOLDEN, "state_f3.npz"))         # the committed state goldens after frame 3 = feeds of frame 4
     for k in ("msfe6_ee_cur1", "msfe4_dd3_cur2", "msfe3_de_cur1", "msfe6_dd_cur6"):
         np.testing.assert_allclose(fb_prev3[k].reshape(-1), st[k].reshape(-1), rtol=1e-4, atol=1e-4, err_msg=k)   # same tolerance as the GPU golden test
+
+
+def test_oracle_b_causal32_ctfa_equals_the_offline_pooling_formulation():
+    """ctfa_mode="causal32": oracle B's frame-by-frame history against the offline model's layers evaluated on a whole
+    sequence (models/proposed.py:143-147: ZeroPadding2D((31,0)) + AveragePooling1D(32, strides=1) over time)."""
+    import torch
+    import torch.nn.functional as Fn
+    ref = NutlsRef(batch=1, ctfa_mode="causal32")
+    rng = np.random.default_rng(5)
+    T_, F = 75, 8
+    xs = torch.from_numpy(rng.standard_normal((T_, F, 64)).astype(np.float32))
+    e0 = torch.from_numpy(rng.standard_normal((T_, F, 64)).astype(np.float32))
+    prefix = "msfe3_en"
+    got = torch.stack([ref._ctfa(xs[t:t + 1], e0[t:t + 1], prefix)[0] for t in range(T_)])
+    ta = ref._mlp_gate(xs.mean(dim=1), prefix + "_ta")                                   # [T,64]
+    pooled = Fn.avg_pool1d(Fn.pad(ta.t().unsqueeze(0), (31, 0)), 32, stride=1)[0].t()     # [T,64] causal mean of 32
+    fa = ref._mlp_gate(pooled, prefix + "_fa")
+    want = xs * (ta * fa).unsqueeze(1) + e0
+    assert rms(got.numpy(), want.numpy()) < 1e-6
+    frame = NutlsRef(batch=1)                       # the streaming form differs from it after the first frame only
+    f0 = frame._ctfa(xs[0:1], e0[0:1], prefix)[0]
+    assert rms(f0.numpy(), want[0].numpy()) < 1e-7
