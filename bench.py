@@ -46,12 +46,17 @@ def synthetic_pool(batch, n, seed):
 
 def kernel_source_sha16(mode):
     """Identity of the kernel a PMC traffic record belongs to: hash of the sources of the step kernel."""
-    files = {"fused": ["fused_step.hip", "fused_plan.hpp", "fused_plan_lstm.inc"], "persistent": ["megakernel.hip", "ddb_device.hpp"]}.get(mode, [])
+    files = {"fused": ["fused_step.hip", "fused_plan.hpp", "fused_plan_lstm.inc", "fused_plan_base.inc", "ddb_device.hpp"],
+             "persistent": ["megakernel.hip", "ddb_device.hpp"]}.get(mode, [])
     h = hashlib.sha256()
     for f in files:
         with open(os.path.join(PKG, "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16] if files else None
+
+
+def fused_kernel_name(variant):
+    return "nutls_fused_base_step_kernel" if variant == "baseline" else "nutls_fused_step_kernel"
 
 
 def cpu_model_name():
@@ -167,7 +172,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
     ap.add_argument("--mode", default=None, choices=["fused", "persistent", "graph", "launches"],
-                    help="default: fused (LSTM variant) / persistent (baseline variant)")
+                    help="default: fused")
     ap.add_argument("--variant", default="lstm", choices=["lstm", "baseline"],
                     help="baseline = dilated-dense bottleneck with synthetic weights, seed 4321 (BASELINE configs[2])")
     ap.add_argument("--host-io", action="store_true",
@@ -214,7 +219,7 @@ def main():
     lo, hi = stream_range(world * args.batch, rank, world)
     B = hi - lo
     device = torch.device("cpu") if selftest else torch.device("cuda", local_rank)
-    mode = args.mode or ("fused" if args.variant == "lstm" else "persistent")
+    mode = args.mode or "fused"
     if selftest:
         eng = _LauncherSelfTestEngine(B)
     else:
@@ -222,7 +227,8 @@ def main():
         weights = None
         if args.variant == "baseline":
             from nunet_amd.weights import synthetic_weights, write_blob
-            weights = write_blob(synthetic_weights("baseline", seed=4321))
+            # random-init weights (none are trained), stored as the reference's export stores them: conv kernels int8
+            weights = write_blob(synthetic_weights("baseline", seed=4321), int8_convs=True)
         eng = nunet_amd.NutlsEngine(weights, batch=B, device=local_rank, mode=mode, variant=args.variant)
     pool_host = synthetic_pool(B, 8, 1234 + lo)
     pool = torch.from_numpy(pool_host).to(device)            # inputs resident in HBM
@@ -327,9 +333,10 @@ def kernel_report(args, eng, pool, out, B, mode):
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):     # HBM bytes per launch from rocprofv3 PMC passes -- only if they were taken on THIS kernel
             t = json.load(open(tpath))
-            if t.get("batch") == B and t.get("mode") == mode and t.get("kernel_source_sha16") == kernel_source_sha16(mode):
+            if (t.get("batch") == B and t.get("mode") == mode and t.get("variant", "lstm") == args.variant
+                    and t.get("kernel_source_sha16") == kernel_source_sha16(mode)):
                 traffic = t["traffic_bytes"]
-        rep["roofline"] = {"kernel": "nutls_fused_step_kernel" if mode == "fused" else "nutls_stream_step_kernel", "bound": "mfma",
+        rep["roofline"] = {"kernel": fused_kernel_name(args.variant) if mode == "fused" else "nutls_stream_step_kernel", "bound": "mfma",
                            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "launches_per_step": 1,
                            "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": step_flops}

@@ -114,8 +114,10 @@ int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_ou
 int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out);
 
 /* Execution mode of nutls_step:
- *   3            fused kernel (LSTM variant): ONE launch per frame, one 512-thread workgroup per stream; every
- *                op of the step is its own specialised instruction stream (static schedule, no plan decoding);
+ *   3            fused kernel: ONE launch per frame, one 512-thread workgroup per stream; every op of the step
+ *                is its own specialised instruction stream (static schedule, no plan decoding).  Both variants
+ *                have one; it keeps the conv kernels int8 on the device, so it exists for handles made from a
+ *                container with int8 conv kernels (what the reference's .tflite stores) and is their default;
  *   2            persistent kernel: ONE launch per frame, one 512-thread workgroup per stream interprets
  *                the device-resident plan (layer boundary = workgroup barrier, not a kernel boundary);
  *   1            one kernel per layer, the ~160 launches captured in a hipGraph (one per state parity);
@@ -169,15 +171,16 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n);
  * wall_clock64() at every layer boundary; writes microseconds per layer to us[0..n). */
 int nutls_profile_persistent(nutls_handle* h, double* us, int n);
 
-/* Fused-mode twin: op count / names / algorithmic flops per stream of the static schedule, and one profiled
- * step (workgroup 0 stamps every op boundary); microseconds per op to us[0..nutls_fused_num_ops()). */
-int nutls_fused_num_ops(void);
-int nutls_fused_op_info(int index, const char** name, double* flops);
+/* Fused-mode twin: op count / names / algorithmic flops per stream of a variant's static schedule, and one profiled
+ * step (workgroup 0 stamps every op boundary); microseconds per op to us[0..nutls_fused_num_ops(variant of h)). */
+int nutls_fused_num_ops(int variant);
+int nutls_fused_op_info(int variant, int index, const char** name, double* flops);
 int nutls_profile_fused(nutls_handle* h, double* us, int n);
 /* Host-only (works without a GPU): the fused kernel's weight blob for a container -- conv kernels int8 in MFMA fragment
- * order, everything else fp32, in the order of the static schedule.  n_floats must equal nutls_fused_blob_floats(). */
-int nutls_fused_blob_floats(void);
-int nutls_fused_pack_blob(const void* weights, size_t n_bytes, float* out, size_t n_floats);
+ * order, everything else fp32, in the order of the variant's static schedule.  n_floats must equal
+ * nutls_fused_blob_floats(variant). */
+int nutls_fused_blob_floats(int variant);
+int nutls_fused_pack_blob(const void* weights, size_t n_bytes, int variant, float* out, size_t n_floats);
 
 const char* nutls_last_error(void);
 const char* nutls_version(void);

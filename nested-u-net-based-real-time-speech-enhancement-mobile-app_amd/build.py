@@ -18,8 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnutls_hip.so")
-SOURCES = ["fused_step.hip", "fused_step_prof.hip", "kernels.hip", "megakernel.hip", "stft.hip", "offline.hip", "weights.cpp", "fused_host.cpp", "engine.cpp"]
-HEADERS = ["nutls_internal.hpp", "ddb_device.hpp", "fused_plan.hpp", "fused_plan_lstm.inc", os.path.join("..", "..", "include", "nutls.h")]
+SOURCES = ["fused_step.hip", "fused_step_prof.hip", "fused_base.hip", "fused_base_prof.hip", "kernels.hip", "megakernel.hip", "stft.hip", "offline.hip", "weights.cpp", "fused_host.cpp", "engine.cpp"]
+HEADERS = ["nutls_internal.hpp", "ddb_device.hpp", "fused_plan.hpp", "fused_plan_lstm.inc", "fused_plan_base.inc", "fused_host_impl.inc", os.path.join("..", "..", "include", "nutls.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -44,7 +44,7 @@ def _stale_sources(force: bool):
     for s in SOURCES:
         o = _obj(s)
         dep = max(os.path.getmtime(os.path.join(CSRC, s)), hdr)
-        if s == "fused_step_prof.hip":
+        if s in ("fused_step_prof.hip", "fused_base.hip", "fused_base_prof.hip"):
             dep = max(dep, os.path.getmtime(os.path.join(CSRC, "fused_step.hip")))
         if force or not os.path.exists(o) or os.path.getmtime(o) < dep:
             out.append(s)

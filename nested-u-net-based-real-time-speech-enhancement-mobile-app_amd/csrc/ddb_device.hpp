@@ -211,8 +211,9 @@ __device__ __forceinline__ ddb_f4 ddb_dense23(const float* X0, const float* X1, 
 }
 
 // lds: >= 17.5K floats.  All nthreads (a multiple of 64, >= 256) call.
+// lds_y (optional): the output rows are also written to LDS at lds_y + f * lds_y_pitch + c (the fused kernel's next image).
 __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, float* lds, int tid, int nthreads,
-                                             unsigned long long* dbg_lds = nullptr) {
+                                             unsigned long long* dbg_lds = nullptr, float* lds_y = nullptr, int lds_y_pitch = 0) {
 #define DDB_T(k) do { if (dbg_lds && (tid & 63) == 0) dbg_lds[(tid >> 6) * 16 + (k)] = clock64(); } while (0)
   DDB_T(0);
   const int F = p.F, C = p.C, G = C >> 1;
@@ -336,6 +337,7 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
 #pragma unroll
       for (int j = 0; j < 4; ++j) r[j] = ddb_prelu(s[j] + p.b_out[4 * cq + j], p.a_out);
       *reinterpret_cast<ddb_f4*>(p.dst + soff + f * p.dst_ld + 4 * cq) = r;
+      if (lds_y) *reinterpret_cast<ddb_f4*>(lds_y + f * lds_y_pitch + 4 * cq) = r;
     }
     for (int q = tid; q < FG; q += nthreads) pst_out[q] = o[6 * FG + q];
   }

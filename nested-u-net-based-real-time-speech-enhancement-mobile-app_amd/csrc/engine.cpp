@@ -905,18 +905,22 @@ static int run_persistent(Engine* e, int par, hipStream_t s, bool prof) {
 
 // ---- fused kernel (mode 3): weight blob in plan order + the check that the arena is laid out as the plan says ----
 static int fused_setup(Engine* e, const WeightMap& wm) {
-  const bool same_count = static_cast<int>(e->states.size()) == fused_num_states();
-  bool ok = same_count && e->sstride >= static_cast<size_t>(fused_arena_floats());
-  for (int i = 0; ok && i < fused_num_states(); ++i) {
+  const int v = e->variant;
+  const bool same_count = static_cast<int>(e->states.size()) == fused_num_states(v);
+  bool ok = same_count && e->sstride >= static_cast<size_t>(fused_arena_floats(v));
+  for (int i = 0; ok && i < fused_num_states(v); ++i) {
     const StateTensor& st = e->states[i];
-    ok = st.name_prev == fused_state_name(i) && st.buf[0] - e->arena == fused_state_off(i) && st.buf[1] - st.buf[0] == fused_parity_stride();
+    const bool ring = i >= fused_num_pingpong(v);        // baseline: the dilated-dense history rings are updated in place
+    ok = st.name_prev == fused_state_name(v, i) && st.buf[0] - e->arena == fused_state_off(v, i) &&
+         st.buf[1] - st.buf[0] == (ring ? 0 : fused_parity_stride(v));
   }
   const float* scratch[10] = {e->t_inlayer, e->t_y, e->t_d, e->t_up, e->upcat[0], e->upcat[1], e->upcat[2], e->upcat[3], e->upcat[4], e->upcat[5]};
-  for (int i = 0; ok && i < fused_num_scratch() && i < 10; ++i) ok = scratch[i] - e->arena == fused_scratch_off(i);
+  for (int i = 0; ok && i < fused_num_scratch(v) && i < 10; ++i) ok = scratch[i] - e->arena == fused_scratch_off(v, i);
+  if (ok && v == NUTLS_VARIANT_BASELINE) ok = e->d_ddb != nullptr && e->ddbs.size() == 26;
   if (!ok) return fail(NUTLS_ERR_ARG, "fused plan (tools/gen_fused_plan.py) does not match the engine's arena layout");
   std::vector<float> blob;
   std::string err;
-  if (!fused_pack_blob(wm, &blob, &err)) {
+  if (!fused_pack_blob(v, wm, &blob, &err)) {
     // a container with float conv kernels (no int8 payload): fine, it runs on the plan-interpreter kernel (mode 2)
     if (err.find("not an int8 tensor") != std::string::npos) return NUTLS_OK;
     return fail(NUTLS_ERR_WEIGHTS, err);
@@ -927,19 +931,22 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   HIP_TRY(hipMemcpy(p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
   e->fz_blob = static_cast<float*>(p);
   void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, (fused_num_ops() * 9 + 1) * sizeof(unsigned long long)));     // op starts + 8 phase stamps per op
+  HIP_TRY(hipMalloc(&q, (fused_num_ops(v) * 9 + 1) * sizeof(unsigned long long)));     // op starts + 8 phase stamps per op
   e->allocs.push_back(q);
-  HIP_TRY(hipMemset(q, 0, (fused_num_ops() * 9 + 1) * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(q, 0, (fused_num_ops(v) * 9 + 1) * sizeof(unsigned long long)));
   e->fz_prof = static_cast<unsigned long long*>(q);
-  HIP_TRY(fused_step_set_attributes());
+  HIP_TRY(v == NUTLS_VARIANT_BASELINE ? fused_base_step_set_attributes() : fused_step_set_attributes());
   return NUTLS_OK;
 }
 
 static int run_fused(Engine* e, int par, hipStream_t s, bool prof) {
   if (!e->fz_blob) return fail(NUTLS_ERR_ARG, "fused mode is not available for this handle");
-  hipError_t err = launch_fused_step(e->arena, static_cast<long long>(e->sstride), e->fz_blob, e->io_in, e->io_out, e->B, par,
-                                     prof ? e->fz_prof : nullptr, e->B, s);
+  const bool base = e->variant == NUTLS_VARIANT_BASELINE;
+  hipError_t err = (base ? launch_fused_base_step : launch_fused_step)(e->arena, static_cast<long long>(e->sstride), e->fz_blob, e->io_in,
+                                                                       e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
+                                                                       base ? e->d_ddb : nullptr, e->B, s);
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("fused step launch: ") + hipGetErrorString(err));
+  if (base) HIP_TRY(launch_incr_step(e->d_step, s));   // ring position of the dilated-dense history
   return NUTLS_OK;
 }
 
@@ -1082,14 +1089,14 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
     return fail(NUTLS_ERR_ARG, std::string("plan: ") + ex.what());
   }
   if (rc) return rc;
-  if (variant == NUTLS_VARIANT_LSTM && offline_frames == 0) {
+  if (offline_frames == 0) {
     try {
       rc = fused_setup(e, wm);
     } catch (const std::exception& ex) {
       return fail(NUTLS_ERR_WEIGHTS, std::string("fused plan weights: ") + ex.what());
     }
     if (rc) return rc;
-    if (e->fz_blob) e->mode = 3;          // the default for streaming handles of the LSTM variant
+    if (e->fz_blob) e->mode = 3;          // the default for streaming handles whose container holds int8 conv kernels
   }
   HIP_TRY(stream_step_set_attributes());      // dynamic-LDS limit of the one-launch kernels, on THIS handle's device
   e->n_cu = prop.multiProcessorCount;
@@ -1246,7 +1253,7 @@ int nutls_use_graph(nutls_handle* h, int enable) {
 
 int nutls_set_mode(nutls_handle* h, int mode) {
   if (!h || mode < 0 || mode > 3) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode must be 0, 1, 2 or 3");
-  if (mode == 3 && !h->eng.fz_blob) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 3 (fused kernel) exists for streaming handles of the LSTM variant only");
+  if (mode == 3 && !h->eng.fz_blob) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 3 (fused kernel) needs a streaming handle made from a container with int8 conv kernels");
   if (h->eng.offline && mode != 0) return fail(NUTLS_ERR_ARG, "nutls_set_mode: offline handles run per-layer launches (mode 0)");
   if (mode == 1) return nutls_use_graph(h, 1);
   h->eng.mode = mode;
@@ -1584,20 +1591,23 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   return NUTLS_OK;
 }
 
-int nutls_fused_num_ops(void) { return fused_num_ops(); }
+static bool known_variant(int variant) { return variant == NUTLS_VARIANT_LSTM || variant == NUTLS_VARIANT_BASELINE; }
 
-int nutls_fused_blob_floats(void) { return fused_blob_floats(); }
+int nutls_fused_num_ops(int variant) { return known_variant(variant) ? fused_num_ops(variant) : 0; }
+
+int nutls_fused_blob_floats(int variant) { return known_variant(variant) ? fused_blob_floats(variant) : 0; }
 
 /* Host-only (no GPU needed): the weight blob of the fused kernel for a container, for tests of the packing. */
-int nutls_fused_pack_blob(const void* weights, size_t n_bytes, float* out, size_t n_floats) {
+int nutls_fused_pack_blob(const void* weights, size_t n_bytes, int variant, float* out, size_t n_floats) {
   if (!weights || !out) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: null pointer");
-  if (n_floats != static_cast<size_t>(fused_blob_floats())) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: n_floats must equal nutls_fused_blob_floats()");
+  if (!known_variant(variant)) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: unknown variant");
+  if (n_floats != static_cast<size_t>(fused_blob_floats(variant))) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: n_floats must equal nutls_fused_blob_floats()");
   WeightMap wm;
   std::string err;
   std::vector<float> blob;
   try {
     if (!parse_weight_blob(weights, n_bytes, &wm, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
-    if (!fused_pack_blob(wm, &blob, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
+    if (!fused_pack_blob(variant, wm, &blob, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
   } catch (const std::exception& ex) {
     return fail(NUTLS_ERR_WEIGHTS, std::string("weight container: ") + ex.what());
   }
@@ -1605,17 +1615,18 @@ int nutls_fused_pack_blob(const void* weights, size_t n_bytes, float* out, size_
   return NUTLS_OK;
 }
 
-int nutls_fused_op_info(int index, const char** name, double* flops) {
-  if (index < 0 || index >= fused_num_ops()) return fail(NUTLS_ERR_ARG, "nutls_fused_op_info: bad index");
-  if (name) *name = fused_op_name(index);
-  if (flops) *flops = fused_op_flops(index);
+int nutls_fused_op_info(int variant, int index, const char** name, double* flops) {
+  if (!known_variant(variant)) return fail(NUTLS_ERR_ARG, "nutls_fused_op_info: unknown variant");
+  if (index < 0 || index >= fused_num_ops(variant)) return fail(NUTLS_ERR_ARG, "nutls_fused_op_info: bad index");
+  if (name) *name = fused_op_name(variant, index);
+  if (flops) *flops = fused_op_flops(variant, index);
   return NUTLS_OK;
 }
 
 int nutls_profile_fused(nutls_handle* h, double* us, int n) {
   if (!h || !us) return fail(NUTLS_ERR_ARG, "nutls_profile_fused: null pointer");
   Engine* e = &h->eng;
-  if (n != fused_num_ops()) return fail(NUTLS_ERR_ARG, "nutls_profile_fused: n must equal nutls_fused_num_ops()");
+  if (n != fused_num_ops(e->variant)) return fail(NUTLS_ERR_ARG, "nutls_profile_fused: n must equal nutls_fused_num_ops(variant)");
   HIP_TRY(hipSetDevice(e->device));
   const int par = e->next_parity;
   int rc = run_fused(e, par, e->stream, true);
@@ -1634,7 +1645,7 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n) {
     HIP_TRY(hipMemcpy(sub.data(), e->fz_prof + n + 1, sub.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (FILE* f = fopen(dump, "w")) {
       for (int i = 0; i < n; ++i) {
-        fprintf(f, "%-24s total %6.2f |", fused_op_name(i), us[i]);
+        fprintf(f, "%-24s total %6.2f |", fused_op_name(e->variant, i), us[i]);
         // stamp slots in chronological order: 0 loads issued, 5 carried weights arrived, 6 MFMA loop done (4x4 path),
         // 1 partials / parameters written, 2 past barrier 1, 3 epilogue done, 4 next image built
         const int order[7] = {0, 5, 6, 1, 2, 3, 4};

@@ -10,7 +10,7 @@
 namespace nutls {
 namespace fz {
 
-enum OpType : int { T_INPUT = 0, T_CONV = 1, T_LSTM = 2, T_CTFA = 3 };
+enum OpType : int { T_INPUT = 0, T_CONV = 1, T_LSTM = 2, T_CTFA = 3, T_DDB = 4 };
 enum CKind : int { K_IN = 0, K_EL = 1, K_DL = 2, K_DOWN = 3, K_UP = 4 };
 enum Path : int { P_R32 = 0, P_X16 = 1, P_X4 = 2 };
 enum Src : int { S_PREV = 0, S_CUR = 1, S_SCRATCH = 2 };   // HBM base a float offset is relative to
@@ -65,7 +65,9 @@ struct OpD {
   int F, e0_off, e0_ld, last, cw_off;      // operates in place on fwd-described rows; cw: ta(w1T,b1,w2,b2) | fa(...)
   // ---- all -------------------------------------------------------------------------------------
   int drain;                               // every wave drains its memory counter before the op's last barrier
+  int bidx;                                // T_DDB (baseline variant): which of the 13 dilated-dense bottlenecks (uses x_cols, y_b, x_pitch_b)
 };
+constexpr int DDB_LDS_B = 64 * 1024;       // LDS scratch of a dilated-dense block op (17 920 floats), above the image it completes
 
 }  // namespace fz
 }  // namespace nutls

@@ -28,15 +28,25 @@
 
 #include "nutls_internal.hpp"
 #include "fused_plan.hpp"
+#include "ddb_device.hpp"
 
 #ifndef FZ_PROF
 #define FZ_PROF 0
+#endif
+// FZ_BASE = 1: the baseline variant's build (fused_base.hip): same ops, the LSTM + Dense bottlenecks replaced by the
+// dilated-dense blocks of models/nunet_tls.py:277-359 (plan fused_plan_base.inc)
+#ifndef FZ_BASE
+#define FZ_BASE 0
 #endif
 
 namespace nutls {
 namespace fz {
 
+#if FZ_BASE
+#include "fused_plan_base.inc"
+#else
 #include "fused_plan_lstm.inc"
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -55,6 +65,8 @@ struct Ctx {
   gcf_t io_in;                 // this stream's 256 input magnitudes
   gf_t io_out;
   unsigned long long* prof;
+  const DdbParams* ddb;        // baseline variant: the 13 dilated-dense blocks of this step's parity
+  int stream;
 };
 
 // profiling build: phase stamps inside an op (wave 0 of workgroup 0), slot k of op I at prof[kNumOps + 1 + 8 I + k]
@@ -741,6 +753,15 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
   }
 }
 
+// ---- dilated-dense bottleneck of the baseline variant (models/nunet_tls.py:277-359, streaming converter_nunet_tls.py:374-411):
+//      ddb_device.hpp's workgroup form -- input rows from the state tensor in HBM (the op before drained its stores), history
+//      rings in HBM, output to HBM and, here, straight into the next conv's image.
+template <int I>
+__device__ __forceinline__ void ddb_op(const Ctx& cx, int tid) {
+  constexpr OpD d = kOps[I];
+  ddb_block_wg(cx.ddb[d.bidx], cx.stream, lds + DDB_LDS_B / 4, tid, THREADS, nullptr, lds + d.y_b / 4, d.x_pitch_b / 4);
+}
+
 // 64 -> 16 (ReLU) -> 64 perceptron of the CTFA gates, evaluated by ONE wave without barriers (lane c = channel c)
 __device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1)[4], float b1_u, const f32x4 (&w2)[4], float b2, int scr_b, int lane) {
 #pragma unroll
@@ -862,6 +883,8 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
     else conv_r32<I>(cx, tid, c, p1, p3);
   } else if constexpr (d.type == T_LSTM) {
     lstm_op<I>(cx, tid, c);
+  } else if constexpr (d.type == T_DDB) {
+    ddb_op<I>(cx, tid);
   } else {
     ctfa_op<I>(cx, tid, c);
   }
@@ -880,15 +903,32 @@ __device__ __forceinline__ void run_from(const Ctx& cx, Carry<I>& c) {
 
 struct FzArgs {
   float* arena; long long sstride; const float* blob; const float* io_in; float* io_out; int B, par; unsigned long long* prof;
+  const DdbParams* ddb;      // baseline variant: table [2 parities][13] (engine.cpp push_ddb), else null
 };
 
 #ifndef FZ_PROF
 #define FZ_PROF 0
 #endif
-#if FZ_PROF
+#if FZ_PROF && FZ_BASE
+#define FZ_KERNEL nutls_fused_base_step_prof_kernel
+#define FZ_LAUNCH launch_fused_base_step_prof
+#define FZ_ATTR fused_base_step_prof_set_attributes
+#elif FZ_PROF
 #define FZ_KERNEL nutls_fused_step_prof_kernel
+#define FZ_LAUNCH launch_fused_step_prof
+#define FZ_ATTR fused_step_prof_set_attributes
+#elif FZ_BASE
+#define FZ_KERNEL nutls_fused_base_step_kernel
+#define FZ_LAUNCH launch_fused_base_step
+#define FZ_ATTR fused_base_step_set_attributes
+#define FZ_LAUNCH_PROF launch_fused_base_step_prof
+#define FZ_ATTR_PROF fused_base_step_prof_set_attributes
 #else
 #define FZ_KERNEL nutls_fused_step_kernel
+#define FZ_LAUNCH launch_fused_step
+#define FZ_ATTR fused_step_set_attributes
+#define FZ_LAUNCH_PROF launch_fused_step_prof
+#define FZ_ATTR_PROF fused_step_prof_set_attributes
 #endif
 __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   constexpr bool PROF = FZ_PROF != 0;
@@ -906,6 +946,8 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.io_in = (gcf_t)(unsigned long long)(a.io_in + static_cast<size_t>(stream) * 256);
   cx.io_out = (gf_t)(unsigned long long)(a.io_out + static_cast<size_t>(stream) * 256);
   cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
+  cx.ddb = a.ddb ? a.ddb + a.par * 13 : nullptr;
+  cx.stream = stream;
   Carry<0> c0;
   {
     int tid = threadIdx.x;
@@ -918,29 +960,29 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
 }  // namespace fz
 
 #if FZ_PROF
-hipError_t launch_fused_step_prof(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                                  unsigned long long* prof, int grid, hipStream_t s) {
-  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, prof};
+hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                     unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s) {
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, prof, ddb};
   hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
   return hipGetLastError();
 }
-hipError_t fused_step_prof_set_attributes() {
+hipError_t FZ_ATTR() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(fz::FZ_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
 }
 #else
-hipError_t launch_fused_step_prof(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                                  unsigned long long* prof, int grid, hipStream_t s);
-hipError_t fused_step_prof_set_attributes();
-hipError_t launch_fused_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                             unsigned long long* prof, int grid, hipStream_t s) {
-  if (prof) return launch_fused_step_prof(arena, sstride, blob, io_in, io_out, B, par, prof, grid, s);
-  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr};
+hipError_t FZ_LAUNCH_PROF(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                          unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s);
+hipError_t FZ_ATTR_PROF();
+hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                     unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s) {
+  if (prof) return FZ_LAUNCH_PROF(arena, sstride, blob, io_in, io_out, B, par, prof, ddb, grid, s);
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr, ddb};
   hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
   return hipGetLastError();
 }
-hipError_t fused_step_set_attributes() {
+hipError_t FZ_ATTR() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fz::FZ_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
-  return e != hipSuccess ? e : fused_step_prof_set_attributes();
+  return e != hipSuccess ? e : FZ_ATTR_PROF();
 }
 #endif
 

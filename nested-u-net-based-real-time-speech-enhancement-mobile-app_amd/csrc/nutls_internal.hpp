@@ -248,22 +248,27 @@ void apply_s16_plan(ConvPlan* c, const ConvParams& p);
 
 
 // ------------------------------------------------------------------ fused (statically scheduled) kernel ----
-// fused_step.hip / fused_host.cpp: the LSTM variant's frame step as one specialised instruction stream per op.
+// fused_step.hip (LSTM variant) / fused_base.hip (baseline variant) / fused_host.cpp: the frame step as one specialised
+// instruction stream per op.  `prof` non-null selects the profiling build; `ddb` is the baseline's block table (else null).
 hipError_t launch_fused_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                             unsigned long long* prof, int grid, hipStream_t s);
+                             unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s);
+hipError_t launch_fused_base_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                                  unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s);
 hipError_t fused_step_set_attributes();
-bool fused_pack_blob(const WeightMap& wm, std::vector<float>* out, std::string* err);
-int fused_blob_floats();
-int fused_num_ops();
-const char* fused_op_name(int i);
-double fused_op_flops(int i);
-int fused_parity_stride();
-int fused_arena_floats();
-int fused_num_states();
-const char* fused_state_name(int i);
-int fused_state_off(int i);
-int fused_num_scratch();
-const char* fused_scratch_name(int i);
-int fused_scratch_off(int i);
+hipError_t fused_base_step_set_attributes();
+bool fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err);
+int fused_blob_floats(int variant);
+int fused_num_ops(int variant);
+const char* fused_op_name(int variant, int i);
+double fused_op_flops(int variant, int i);
+int fused_parity_stride(int variant);
+int fused_arena_floats(int variant);
+int fused_num_states(int variant);
+int fused_num_pingpong(int variant);          // the first so many states are ping-pong pairs, the rest in-place history rings
+const char* fused_state_name(int variant, int i);
+int fused_state_off(int variant, int i);
+int fused_num_scratch(int variant);
+const char* fused_scratch_name(int variant, int i);
+int fused_scratch_off(int variant, int i);
 
 }  // namespace nutls

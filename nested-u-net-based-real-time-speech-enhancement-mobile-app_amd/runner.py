@@ -83,11 +83,11 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_process_block.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_process_block_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
     lib.nutls_offline_set_ctfa_mode.argtypes = [c.c_void_p, c.c_int]
-    lib.nutls_fused_num_ops.argtypes = []
-    lib.nutls_fused_op_info.argtypes = [c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
+    lib.nutls_fused_num_ops.argtypes = [c.c_int]
+    lib.nutls_fused_op_info.argtypes = [c.c_int, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
     lib.nutls_profile_fused.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
-    lib.nutls_fused_blob_floats.argtypes = []
-    lib.nutls_fused_pack_blob.argtypes = [c.c_void_p, c.c_size_t, fp, c.c_size_t]
+    lib.nutls_fused_blob_floats.argtypes = [c.c_int]
+    lib.nutls_fused_pack_blob.argtypes = [c.c_void_p, c.c_size_t, c.c_int, fp, c.c_size_t]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:
@@ -119,13 +119,13 @@ class NutlsEngine:
     VARIANTS = {"lstm": 0, "baseline": 1}
 
     def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: Optional[str] = None, variant: str = "lstm"):
-        """``mode``: "fused" (default for the LSTM variant: one launch per frame, one workgroup per stream, every op its
-        own specialised instruction stream), "persistent" (default for the baseline variant: one launch per frame, one
-        workgroup per stream interprets the device-resident plan), "graph" (one kernel per layer, hipGraph replay) or
-        "launches" (one kernel per layer).
+        """``mode``: "fused" (the default when the container holds int8 conv kernels, as the reference's .tflite does:
+        one launch per frame, one workgroup per stream, every op its own specialised instruction stream), "persistent"
+        (the default for float containers: one launch per frame, one workgroup per stream interprets the
+        device-resident plan), "graph" (one kernel per layer, hipGraph replay) or "launches" (one kernel per layer).
         ``variant``: "lstm" (NUNet-TLS-LSTM, trained weights ship in weights/) or "baseline"
         (dilated-dense bottleneck; no trained weights exist -- pass a container, e.g.
-        ``weights.write_blob(weights.synthetic_weights("baseline"))``)."""
+        ``weights.write_blob(weights.synthetic_weights("baseline"), int8_convs=True)``)."""
         self._lib = load_library()
         if variant not in self.VARIANTS:
             raise ValueError("variant must be one of %s" % sorted(self.VARIANTS))
@@ -144,9 +144,9 @@ class NutlsEngine:
         self.io_in_ptr, self.io_out_ptr = pin.value, pout.value
         if mode is not None:
             self.set_mode(mode)
-        else:       # library default: fused for the LSTM variant when the container holds int8 conv kernels, else persistent
+        else:       # library default: fused when the container holds int8 conv kernels, else persistent
             try:
-                self.set_mode("fused" if variant == "lstm" else "persistent")
+                self.set_mode("fused")
             except ValueError:
                 self.set_mode("persistent")
 
@@ -314,15 +314,16 @@ class NutlsEngine:
     def fused_plan(self) -> List[Dict[str, object]]:
         """The fused kernel's static schedule: op name and algorithmic flops per stream."""
         res = []
-        for i in range(self._lib.nutls_fused_num_ops()):
+        v = self.VARIANTS[self.variant]
+        for i in range(self._lib.nutls_fused_num_ops(v)):
             name, fl = ctypes.c_char_p(), ctypes.c_double()
-            _check(self._lib, self._lib.nutls_fused_op_info(i, ctypes.byref(name), ctypes.byref(fl)))
+            _check(self._lib, self._lib.nutls_fused_op_info(v, i, ctypes.byref(name), ctypes.byref(fl)))
             res.append({"layer": name.value.decode(), "flops": fl.value})
         return res
 
     def profile_fused(self) -> np.ndarray:
         """One fused-mode step with workgroup 0 time-stamping every op boundary; microseconds per op."""
-        us = np.zeros(self._lib.nutls_fused_num_ops(), np.float64)
+        us = np.zeros(self._lib.nutls_fused_num_ops(self.VARIANTS[self.variant]), np.float64)
         _check(self._lib, self._lib.nutls_profile_fused(
             self._h, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), us.size))
         return us

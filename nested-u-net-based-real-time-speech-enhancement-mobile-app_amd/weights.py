@@ -64,13 +64,42 @@ def load_weights(path: str = DEFAULT_WEIGHTS) -> Dict[str, np.ndarray]:
     return parse_blob(read_blob(path))
 
 
-def write_blob(tensors: Dict[str, np.ndarray]) -> bytes:
-    """Serialise float32 tensors into a NUTLSW01 container (no quantisation)."""
+def quantize_conv_kernels(tensors: Dict[str, np.ndarray]) -> Dict[str, object]:
+    """What ``tf.lite.Optimize.DEFAULT`` without a representative dataset (dynamic-range quantisation, the reference's
+    export: converter_proposed.py:901, converter_nunet_tls.py:1552) does to the encoder / decoder Conv2D kernels:
+    symmetric int8 per OUTPUT channel, ``scale = max|w| / 127``, ``q = round(w / scale)``; tensors below 1024
+    elements stay float, as in TF-Lite.  The dilated-dense blocks' kernels are left float (the grouped convs are
+    tiny and the block runs in fp32 on every path).  Returns name -> ndarray or ``(int8 array, scales)``."""
+    out: Dict[str, object] = {}
+    for name, arr in tensors.items():
+        a = np.asarray(arr)
+        if name.endswith(".w") and a.ndim == 4 and a.size >= 1024 and "ddb" not in name:
+            amax = np.abs(a).reshape(a.shape[0], -1).max(axis=1)
+            scale = np.where(amax > 0, amax / 127.0, 1.0).astype(np.float32)
+            q = np.clip(np.rint(a / scale.reshape(-1, 1, 1, 1)), -127, 127).astype(np.int8)
+            out[name] = (q, scale)
+        else:
+            out[name] = arr
+    return out
+
+
+def write_blob(tensors: Dict[str, object], int8_convs: bool = False) -> bytes:
+    """Serialise tensors into a NUTLSW01 container: float32 arrays as they are, ``(int8 array, scales)`` tuples as int8
+    payload + scales.  ``int8_convs``: quantise the conv kernels first (`quantize_conv_kernels`) -- the form the fused
+    kernel takes (conv kernels stay int8 on the device)."""
+    if int8_convs:
+        tensors = quantize_conv_kernels(tensors)
     out = [MAGIC, struct.pack("<I", len(tensors))]
     for name, arr in tensors.items():
+        nb = name.encode()
+        if isinstance(arr, tuple):
+            q = np.ascontiguousarray(arr[0], dtype=np.int8)
+            sc = np.ascontiguousarray(arr[1], dtype=np.float32).reshape(-1)
+            out += [struct.pack("<H", len(nb)), nb, struct.pack("<BB", 1, q.ndim), struct.pack("<%dI" % q.ndim, *q.shape),
+                    struct.pack("<I", sc.size), sc.tobytes(), q.tobytes(), b"\0" * ((-q.size) % 4)]
+            continue
         a = np.ascontiguousarray(arr, dtype=np.float32)
         shape = a.shape if a.ndim else (1,)
-        nb = name.encode()
         out += [struct.pack("<H", len(nb)), nb, struct.pack("<BB", 0, len(shape)),
                 struct.pack("<%dI" % len(shape), *shape), struct.pack("<I", 0), a.tobytes()]
     return b"".join(out)

@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 
@@ -28,17 +29,28 @@ def _perm(o):
     return np.arange(n)
 
 
-def test_blob_packing_round_trips_the_container():
+def _container(variant):
+    """lstm: the shipped container (the reference's trained .tflite, conv kernels int8); baseline: random-init weights
+    (no trained ones exist) written the same way."""
+    from nunet_amd.weights import DEFAULT_WEIGHTS, read_blob, synthetic_weights, write_blob
+    if variant == "lstm":
+        return read_blob(DEFAULT_WEIGHTS)
+    return write_blob(synthetic_weights("baseline", seed=11, bias_std=0.1, affine_jitter=0.1), int8_convs=True)
+
+
+@pytest.mark.parametrize("variant", ["lstm", "baseline"])
+def test_blob_packing_round_trips_the_container(variant):
     import nunet_amd  # noqa: F401
     from nunet_amd.runner import load_library, _fptr
-    from nunet_amd.weights import DEFAULT_WEIGHTS, parse_blob, read_blob
+    from nunet_amd.weights import parse_blob
     lib = load_library()
-    blob = read_blob(DEFAULT_WEIGHTS)
-    n = lib.nutls_fused_blob_floats()
+    blob = _container(variant)
+    v = {"lstm": 0, "baseline": 1}[variant]
+    n = lib.nutls_fused_blob_floats(v)
     out = np.zeros(n, np.float32)
     buf = ctypes.create_string_buffer(blob, len(blob))
-    assert lib.nutls_fused_pack_blob(buf, len(blob), _fptr(out), n) == 0, lib.nutls_last_error()
-    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_lstm.json")))
+    assert lib.nutls_fused_pack_blob(buf, len(blob), v, _fptr(out), n) == 0, lib.nutls_last_error()
+    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_%s.json" % ("lstm" if variant == "lstm" else "base"))))
     assert plan["blob_floats"] == n
     W, Wq = parse_blob(blob), parse_blob(blob, dequantize=False)
     lane = np.arange(64)
@@ -110,10 +122,12 @@ def test_blob_packing_round_trips_the_container():
     assert n_conv == 128
 
 
-def test_plan_images_fit_lds_and_ops_cover_the_network():
-    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_lstm.json")))
+@pytest.mark.parametrize("name,bottleneck", [("lstm", 2), ("base", 4)])
+def test_plan_images_fit_lds_and_ops_cover_the_network(name, bottleneck):
+    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_%s.json" % name)))
     ops = plan["ops"]
-    assert len(ops) == 154 and sum(o["type"] == 2 for o in ops) == 13 and sum(o["type"] == 3 for o in ops) == 12
+    assert len(ops) == 154 and sum(o["type"] == bottleneck for o in ops) == 13 and sum(o["type"] == 3 for o in ops) == 12
+    assert sum(o["type"] in (2, 4) for o in ops) == 13
     flops = sum(o["flops"] for o in ops)
     # 147.9 MFLOP per frame and stream; the plan counts the conv ops only (CTFA 1x1s as lowered by TFLite: 4.2 M, LSTM + Dense 0.3 M)
     assert 0.96 < flops / (2 * 73_967_252) < 1.0
@@ -133,13 +147,13 @@ def test_malformed_containers_are_error_codes_not_crashes():
     from nunet_amd.runner import load_library, _fptr
     from nunet_amd.weights import DEFAULT_WEIGHTS, read_blob
     lib = load_library()
-    n = lib.nutls_fused_blob_floats()
+    n = lib.nutls_fused_blob_floats(0)
     out = np.zeros(n, np.float32)
     good = read_blob(DEFAULT_WEIGHTS)
 
     def rc_of(b):
         buf = ctypes.create_string_buffer(bytes(b), len(b))
-        return lib.nutls_fused_pack_blob(buf, len(b), _fptr(out), n)
+        return lib.nutls_fused_pack_blob(buf, len(b), 0, _fptr(out), n)
 
     def tensor(name, dtype, dims, ns=0, payload=b""):
         nb = name.encode()

@@ -230,17 +230,20 @@ def test_linearity_free_property_scale_silence():
 # ------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def baseline_weights():
-    from nunet_amd.weights import synthetic_weights, write_blob
-    w = synthetic_weights("baseline", seed=4321, bias_std=0.1, affine_jitter=0.1)
-    return w, write_blob(w)
+    """Random-init weights written as the reference's export would store them (conv kernels int8 per output channel,
+    converter_nunet_tls.py:1552 Optimize.DEFAULT); the oracle gets the de-quantised values of the same container."""
+    from nunet_amd.weights import parse_blob, synthetic_weights, write_blob
+    blob = write_blob(synthetic_weights("baseline", seed=4321, bias_std=0.1, affine_jitter=0.1), int8_convs=True)
+    return parse_blob(blob), blob
 
 
-@pytest.mark.parametrize("mode", ["persistent", "launches"])
+@pytest.mark.parametrize("mode", ["fused", "persistent", "launches"])
 def test_baseline_variant_matches_oracle(baseline_weights, mode):
     w, blob = baseline_weights
     B, steps = 3, 40                                       # 40 > 32: the deepest history ring wraps
     mags = synthetic_mags(B, steps, seed=77)
     eng = NutlsEngine(blob, batch=B, variant="baseline", mode=mode)
+    assert eng.mode == mode
     ref = NutlsRef(w, batch=B, variant="baseline")
     for s in range(steps):
         out = eng.step(mags[s])
@@ -298,6 +301,7 @@ def test_baseline_variant_batch_256_vs_oracle(baseline_weights):
     B, steps = 256, 4
     mags = synthetic_mags(B, steps, seed=78)
     eng = NutlsEngine(blob, batch=B, variant="baseline")
+    assert eng.mode == "fused"                             # the default for a container with int8 conv kernels
     ref = NutlsRef(w, batch=B, variant="baseline")
     for s in range(steps):
         out = eng.step(mags[s])

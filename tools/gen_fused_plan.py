@@ -25,8 +25,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "nested-u-net-based-real-time-speech-enhancement-mobile-app_amd")
-INC = os.path.join(PKG, "csrc", "fused_plan_lstm.inc")
-JSN = os.path.join(ROOT, "tests", "golden", "fused_plan_lstm.json")
+def inc_path(variant):
+    return os.path.join(PKG, "csrc", "fused_plan_%s.inc" % ("lstm" if variant == "lstm" else "base"))
+
+
+def json_path(variant):
+    return os.path.join(ROOT, "tests", "golden", "fused_plan_%s.json" % ("lstm" if variant == "lstm" else "base"))
 
 # (prefix, depth, f0, conv state tag, sub-pixel state tag, resample layer)   converter_proposed.py:221-727
 ENC = [("msfe6_en", 6, 256, "msfe6_ee", "msfe6_ed", "msfe6_down_sampling"),
@@ -42,7 +46,8 @@ DEC = [("msfe3_de", 3, 8, "msfe3_de", "msfe3_dd", "msfe3_upsampling"),
        ("msfe5_de", 5, 128, "msfe5_de", "msfe5_dd", "msfe5_upsampling"),
        ("msfe6_de", 6, 256, "msfe6_de", "msfe6_dd", "msfe6_upsampling")]
 
-T_INPUT, T_CONV, T_LSTM, T_CTFA = 0, 1, 2, 3
+T_INPUT, T_CONV, T_LSTM, T_CTFA, T_DDB = 0, 1, 2, 3, 4
+DDB_LDS_B = 64 * 1024        # LDS scratch of a dilated-dense block op (70 KB), above the small image it completes
 K_IN, K_EL, K_DL, K_DOWN, K_UP = 0, 1, 2, 3, 4
 P_R32, P_X16, P_X4 = 0, 1, 2
 S_PREV, S_CUR, S_SCRATCH = 0, 1, 2
@@ -62,7 +67,7 @@ class Arena:
     tensors in signature order, then all second buffers in the same order (so `cur` and `prev` of every
     tensor differ by the constant PS), then the scratch tensors."""
 
-    def __init__(self):
+    def __init__(self, variant="lstm"):
         self.states = []   # (name, rows, cols)
         for side, stages in ((0, ENC), (1, DEC)):
             for (p, D, f0, ct, st, _rs) in stages:
@@ -71,11 +76,23 @@ class Arena:
                     self.states.append(("%s_prev%d" % (ct, i), f0 >> (i - 1), c))
                 for j in range(1, D + 1):
                     self.states.append(("%s_prev%d" % (st, j), (f0 >> D) << (j - 1), 64))
-        for (p, *_r) in ENC:
-            self.states += [(p + "_h", 21, 1), (p + "_c", 21, 1)]
-        self.states += [("state_h", 21, 1), ("state_c", 21, 1)]
-        for (p, *_r) in DEC:
-            self.states += [(p + "_h", 21, 1), (p + "_c", 21, 1)]
+        self.rings = []    # baseline: in-place history rings of the dilated-dense blocks (single buffer, after the ping-pong block)
+        if variant == "lstm":
+            for (p, *_r) in ENC:
+                self.states += [(p + "_h", 21, 1), (p + "_c", 21, 1)]
+            self.states += [("state_h", 21, 1), ("state_c", 21, 1)]
+            for (p, *_r) in DEC:
+                self.states += [(p + "_h", 21, 1), (p + "_c", 21, 1)]
+        else:
+            # converter_nunet_tls.py:173-180 / :228-235: prev_in [1,F,C], prev_k [d,F,k*G] (d = 2^(k-1)), prev_out [1,F,G]
+            bn = [(st[0], st[2] >> st[1], 32) for st in ENC] + [("", 4, 64)] + [(st[0], st[2] >> st[1], 32) for st in DEC]
+            for (p, F, C) in bn:
+                tag = (p + "_ddb") if p else "ddb"
+                G = C // 2
+                self.rings.append((tag + "_prev_in", F, C))
+                for k in range(1, 7):
+                    self.rings.append(("%s_prev%d" % (tag, k), (1 << (k - 1)) * F, k * G))
+                self.rings.append((tag + "_prev_out", F, G))
         self.off = {}
         cur = 0
         for (n, r, c) in self.states:
@@ -83,6 +100,9 @@ class Arena:
             cur += r64(r * c)
         self.PS = cur
         cur *= 2
+        for (n, r, c) in self.rings:
+            self.off[n] = cur
+            cur += r64(r * c)
         self.scratch = {}
         for n, sz in [("t_inlayer", 256 * 64), ("t_y", 256 * 64), ("t_d", 256 * 64), ("t_up", 256 * 128)] + \
                      [("upcat%d" % s, (DEC[s][2] // 2) * 128) for s in range(6)]:
@@ -204,17 +224,25 @@ def make_img(kind, P, cin, rounds=1):
     return g
 
 
-def build():
-    A = Arena()
+def ddb_flops(F, c):
+    """Dilated-dense block (nunet_tls.py:277-359) on F positions of c channels: (2,3) conv c -> c/2, six times
+    [grouped dilated (2,3) conv over k channels per filter + 1x1 conv], (2,3) conv c/2 -> c."""
+    g = c // 2
+    return 2 * F * (6 * c * g + sum(6 * k * g + g * g for k in range(1, 7)) + 6 * g * c)
+
+
+def build(variant="lstm"):
+    A = Arena(variant)
     W = Blob()
     ops = []
+    base = variant != "lstm"
 
     def new_op(**kw):
         d = dict(type=T_CONV, name="", kind=0, P=0, cin=0, N=0, taps=0, kf=0, stride=0, path=0, PT=1, NT=1, PG=1, CG=1, KSt=1, KSg=1,
                  ln=0, R=1, gc=0, rounds=1, nseg=0, seg_b=[], seg_tk=[], ex_b=0, w_off=0, p_off=0,
                  d0=None, d1=None, row_mul=1, row_add=0, fwd=None, img=None, nxt=-1, parts=[],
                  din=0, dout=0, x_b=0, x_pitch_b=0, x_cols=0, y_b=0, h_off=0, c_off=0, ldst=None, lw_off=0,
-                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, wkey="", flops=0)
+                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0)
         d.update(kw)
         ops.append(d)
         return d
@@ -273,9 +301,16 @@ def build():
                 d0 = (S_CUR, st_off(stg, 1) + 32, 64)
                 d1 = None
             lst.append(conv_op("%s_conv%d" % (p, i), "%s_conv%d" % (p, i), K_EL, side, i, D, f0 >> i, d0=d0, d1=d1))
-        l = new_op(type=T_LSTM, name=p + "_lstm", wkey=p, din=fd * 32, dout=fd * 32, x_cols=32,
-                   h_off=A.off[p + "_h"], c_off=A.off[p + "_c"], ldst=(S_CUR, st_off(stg, 1), 64), drain=1)
-        l["lw_off"] = W.add((l["din"] + 24) * 84 + 84 + 24 * l["dout"], "lstm", p)
+        if base:
+            # dilated-dense block (nunet_tls.py:277-359): reads e_D from the state tensor in HBM (the strided conv before it
+            # drains its stores), keeps its history rings in HBM, writes d_0 to HBM and into the next image
+            lst[-1]["drain"] = 1
+            l = new_op(type=T_DDB, name=p + "_ddb", wkey=p, din=fd * 32, dout=fd * 32, x_cols=32, bidx=(7 + s if side else s), drain=1,
+                       flops=ddb_flops(fd, 32))
+        else:
+            l = new_op(type=T_LSTM, name=p + "_lstm", wkey=p, din=fd * 32, dout=fd * 32, x_cols=32,
+                       h_off=A.off[p + "_h"], c_off=A.off[p + "_c"], ldst=(S_CUR, st_off(stg, 1), 64), drain=1)
+            l["lw_off"] = W.add((l["din"] + 24) * 84 + 84 + 24 * l["dout"], "lstm", p)
         lst.append(l)
         for j in range(1, D + 1):
             P = fd << (j - 1)
@@ -297,8 +332,12 @@ def build():
         stage_ops[(0, s)] = stage(0, s)
         p, D, f0, ct, stg, rs = ENC[s]
         downs[s] = conv_op(rs, rs, K_DOWN, 0, 0, D, f0 // 2, d0=(S_SCRATCH, A.scratch["upcat%d" % (5 - s)] + 64, 128))
-    cl = new_op(type=T_LSTM, name="lstm", wkey="", din=256, dout=256, x_cols=64, h_off=A.off["state_h"], c_off=A.off["state_c"], ldst=None, drain=1)
-    cl["lw_off"] = W.add((256 + 24) * 84 + 84 + 24 * 256, "lstm", "")
+    if base:
+        downs[5]["drain"] = 1
+        cl = new_op(type=T_DDB, name="ddb", wkey="", din=256, dout=256, x_cols=64, bidx=6, drain=1, flops=ddb_flops(4, 64))
+    else:
+        cl = new_op(type=T_LSTM, name="lstm", wkey="", din=256, dout=256, x_cols=64, h_off=A.off["state_h"], c_off=A.off["state_c"], ldst=None, drain=1)
+        cl["lw_off"] = W.add((256 + 24) * 84 + 84 + 24 * 256, "lstm", "")
     ups = {}
     for s in range(6):
         p, D, f0, ct, stg, rs = DEC[s]
@@ -334,7 +373,7 @@ def build():
 
     # LSTM / CTFA work in place on the image of the conv op that follows them
     for o in ops:
-        if o["type"] == T_LSTM:
+        if o["type"] in (T_LSTM, T_DDB):
             tgt = ops[o["idx"] + 1]
             g = tgt["img"]
             base = (g["taps"] - 1) * g["tap_b"] + g["row0"] * g["pitch_b"]
@@ -342,6 +381,8 @@ def build():
             o["x_b"] = base + o["x_cols"] * 4
             o["y_b"] = base
             o["x_pitch_b"] = g["pitch_b"]
+            if o["type"] == T_DDB:
+                assert g["bytes"] <= DDB_LDS_B and DDB_LDS_B + 17920 * 4 <= SCR_B
         if o["type"] == T_CTFA:
             o["fwd"] = dict(ops[o["idx"] - 1]["fwd"])
             o["last"] = 1 if o["idx"] == n_ops - 1 else 0
@@ -456,14 +497,14 @@ def emit(A, W, ops):
         seg_b = ",".join(str(x) for x in pad(o["seg_b"], MAX_SEG))
         ldst = o["ldst"]
         row = ("{%d, /*conv*/ %d,%d,%d,%d,%d,%d,%d, %d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, %d,{%s}, %d, %d,%d, %s, %s, %d,%d, %s, %s, %d, "
-               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d},   // %d %s") % (
+               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
             o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
             c_fwd(o["fwd"]), c_img(o), o["nxt"],
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
             1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["lw_off"],
-            o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["idx"], o["name"])
+            o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["idx"], o["name"])
         L.append("  " + row)
     L.append("};")
     # what the host needs to pack the blob / check the arena
@@ -480,9 +521,10 @@ def emit(A, W, ops):
         L.append('  {%d, %d, %d, %d, "%s"},' % (off, n, what_code[what], item_op[off], key))
     L.append("};")
     L.append("struct StateOff { const char* name; int off; };")
-    L.append("constexpr int kNumStateOffs = %d;" % len(A.states))
+    L.append("constexpr int kNumStateOffs = %d;      // ping-pong states first, then (baseline) the in-place history rings" % (len(A.states) + len(A.rings)))
+    L.append("constexpr int kNumPingPong = %d;" % len(A.states))
     L.append("static const StateOff kStateOffs[kNumStateOffs] = {")
-    for (n, r, c) in A.states:
+    for (n, r, c) in A.states + A.rings:
         L.append('  {"%s", %d},' % (n, A.off[n]))
     L.append("};")
     L.append("static const StateOff kScratchOffs[%d] = {" % len(A.scratch))
@@ -500,19 +542,23 @@ def emit(A, W, ops):
 
 
 def main():
-    A, W, ops = build()
-    inc = emit(A, W, ops)
-    js = json.dumps(dict(parity_stride=A.PS, arena_floats=A.floats, blob_floats=W.cur, state_off=A.off, scratch=A.scratch,
-                         blob=[list(x) for x in W.items], ops=ops), indent=1, sort_keys=True)
-    if "--check" in sys.argv:
-        ok = open(INC).read() == inc and open(JSN).read() == js
-        print("fused plan is %s" % ("current" if ok else "STALE"))
-        sys.exit(0 if ok else 1)
-    open(INC, "w").write(inc)
-    open(JSN, "w").write(js)
-    r32 = [o for o in ops if o["type"] == T_CONV and o["path"] == P_R32]
-    print("ops %d (conv %d, of which %d on 32x32 tiles), arena %d floats (parity stride %d), blob %d floats" % (
-        len(ops), sum(o["type"] == T_CONV for o in ops), len(r32), A.floats, A.PS, W.cur))
+    stale = False
+    for variant in ("lstm", "baseline"):
+        A, W, ops = build(variant)
+        inc = emit(A, W, ops)
+        js = json.dumps(dict(variant=variant, parity_stride=A.PS, arena_floats=A.floats, blob_floats=W.cur, state_off=A.off, scratch=A.scratch,
+                             blob=[list(x) for x in W.items], ops=ops), indent=1, sort_keys=True)
+        if "--check" in sys.argv:
+            ok = open(inc_path(variant)).read() == inc and open(json_path(variant)).read() == js
+            print("fused plan (%s) is %s" % (variant, "current" if ok else "STALE"))
+            stale = stale or not ok
+            continue
+        open(inc_path(variant), "w").write(inc)
+        open(json_path(variant), "w").write(js)
+        r32 = [o for o in ops if o["type"] == T_CONV and o["path"] == P_R32]
+        print("%-8s ops %d (conv %d, of which %d on 32x32 tiles), arena %d floats (parity stride %d), blob %d floats" % (
+            variant, len(ops), sum(o["type"] == T_CONV for o in ops), len(r32), A.floats, A.PS, W.cur))
+    sys.exit(1 if stale else 0)
 
 
 if __name__ == "__main__":

@@ -9,13 +9,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nunet_amd  # noqa: E402
 from nunet_amd import NutlsEngine, topology as T  # noqa: E402
-from nunet_amd.weights import synthetic_weights, write_blob  # noqa: E402
+from nunet_amd.weights import parse_blob, synthetic_weights, write_blob  # noqa: E402
 from oracle.nutls_ref import NutlsRef  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "launches"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-w = synthetic_weights("baseline", seed=4321, bias_std=0.1, affine_jitter=0.1)
-eng = NutlsEngine(write_blob(w), batch=2, variant="baseline", mode=mode)
+blob = write_blob(synthetic_weights("baseline", seed=4321, bias_std=0.1, affine_jitter=0.1), int8_convs=True)
+w = parse_blob(blob)
+eng = NutlsEngine(blob, batch=2, variant="baseline", mode=mode)
 ref = NutlsRef(w, batch=2, variant="baseline")
 print("engine created, ops per step:", eng.launches_per_step, flush=True)
 rng = np.random.default_rng(1)

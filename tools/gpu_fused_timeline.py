@@ -9,7 +9,12 @@ import nunet_amd
 B = int(os.environ.get("B", "256"))
 steps = int(os.environ.get("STEPS", "200"))
 mode = os.environ.get("MODE", "fused")
-eng = nunet_amd.NutlsEngine(batch=B, mode=mode)
+variant = os.environ.get("VARIANT", "lstm")
+weights = None
+if variant == "baseline":
+    from nunet_amd.weights import synthetic_weights, write_blob
+    weights = write_blob(synthetic_weights("baseline", seed=4321), int8_convs=True)
+eng = nunet_amd.NutlsEngine(weights, batch=B, mode=mode, variant=variant)
 rng = np.random.default_rng(1234)
 pool = torch.from_numpy((0.25 * np.abs(rng.standard_normal((8, B, 256)))).astype(np.float32)).cuda()
 out = torch.empty(B, 256, device="cuda")
