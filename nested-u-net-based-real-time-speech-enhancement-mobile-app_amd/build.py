@@ -9,6 +9,7 @@ changed; the objects and the .so are git-ignored, the .so travels to the GPU box
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -19,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnutls_hip.so")
 SOURCES = ["fused_step.hip", "fused_step_prof.hip", "fused_base.hip", "fused_base_prof.hip", "kernels.hip", "megakernel.hip", "stft.hip", "offline.hip", "weights.cpp", "fused_host.cpp", "engine.cpp"]
-HEADERS = ["nutls_internal.hpp", "ddb_device.hpp", "fused_plan.hpp", "fused_plan_lstm.inc", "fused_plan_base.inc", "fused_host_impl.inc", os.path.join("..", "..", "include", "nutls.h")]
+# (headers are found by scanning the #include "..." lines of every source: _deps)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -34,18 +35,27 @@ def _obj(src: str) -> str:
     return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
 
 
-def _newest_header() -> float:
-    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps(path: str, seen=None) -> set:
+    """The file and everything it includes with quotes, transitively (paths relative to the including file)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path, "r", errors="replace") as f:
+        for inc in _INC.findall(f.read()):
+            _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
 
 
 def _stale_sources(force: bool):
-    hdr = _newest_header()
     out = []
     for s in SOURCES:
         o = _obj(s)
-        dep = max(os.path.getmtime(os.path.join(CSRC, s)), hdr)
-        if s in ("fused_step_prof.hip", "fused_base.hip", "fused_base_prof.hip"):
-            dep = max(dep, os.path.getmtime(os.path.join(CSRC, "fused_step.hip")))
+        dep = max(os.path.getmtime(d) for d in _deps(os.path.join(CSRC, s)))
         if force or not os.path.exists(o) or os.path.getmtime(o) < dep:
             out.append(s)
     return out

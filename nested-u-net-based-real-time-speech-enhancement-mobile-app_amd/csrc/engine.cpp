@@ -129,6 +129,14 @@ struct Engine {
   float* zx = nullptr;   // [offline][84] LSTM input products of a block
   int ctfa_causal = 0;   // offline handles: 1 = true 32-frame causal average in the CTFA frequency branch (proposed.py:143-147)
   float* ta_hist = nullptr;   // [12 stages][31 + offline][64] time-attention history (causal mode)
+  // block pipeline of an offline handle: the block is cut into chunks of consecutive frames, chunk c runs on its own
+  // HIP stream one bottleneck behind chunk c-1 (every layer is causal in time: frame t needs frames <= t only)
+  static constexpr int kMaxChunks = 16, kGroups = 16;
+  std::vector<hipStream_t> ostream;
+  std::vector<hipEvent_t> oev;          // [chunk][group]: chunk's launches up to and including the group's LSTM are enqueued
+  hipEvent_t oev_fork = nullptr;
+  int ochunks = 0;                      // 0 = chosen from the block length
+  std::vector<int> ogroup;              // launch index of plan_off -> group (a group ends with an LSTM)
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
   int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel (plan interpreter),
                          // 3 fused kernel (statically scheduled, LSTM variant only)
@@ -149,6 +157,9 @@ struct Engine {
     for (int i = 0; i < 2; ++i)
       if (gexec[i]) (void)hipGraphExecDestroy(gexec[i]);
     for (void* p : allocs) (void)hipFree(p);
+    for (hipEvent_t ev : oev) (void)hipEventDestroy(ev);
+    if (oev_fork) (void)hipEventDestroy(oev_fork);
+    for (hipStream_t st : ostream) (void)hipStreamDestroy(st);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -1156,9 +1167,83 @@ static int build_offline_plan(Engine* e) {
       case Launch::DDB: return fail(NUTLS_ERR_ARG, "offline mode: LSTM variant only");
     }
   }
+  int g = 0;
+  for (const Launch& L : e->plan_off) {
+    e->ogroup.push_back(g);
+    if (L.kind == Launch::LSTM) ++g;
+  }
+  if (g + 1 > Engine::kGroups) return fail(NUTLS_ERR_ARG, "offline plan: more bottlenecks than pipeline groups");
+  for (int c = 0; c < Engine::kMaxChunks; ++c) {
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    e->ostream.push_back(st);
+    for (int k = 0; k < Engine::kGroups; ++k) {
+      hipEvent_t ev = nullptr;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      e->oev.push_back(ev);
+    }
+  }
+  HIP_TRY(hipEventCreateWithFlags(&e->oev_fork, hipEventDisableTiming));
   int rc = dev_alloc(e, static_cast<size_t>(e->offline) * 84, &e->zx, true);
   if (rc) return rc;
   return dev_alloc(e, static_cast<size_t>(12) * (31 + e->offline) * 64, &e->ta_hist, true);
+}
+
+int nutls_offline_set_pipeline(nutls_handle* h, int chunks) {
+  if (!h || !h->eng.offline) return fail(NUTLS_ERR_ARG, "nutls_offline_set_pipeline: not an offline handle");
+  if (chunks < 0 || chunks > Engine::kMaxChunks) return fail(NUTLS_ERR_ARG, "nutls_offline_set_pipeline: chunks must be 0 (automatic) .. 16");
+  h->eng.ochunks = chunks;
+  return NUTLS_OK;
+}
+
+// Launches [first, last) of the block plan for frames [t0, t0 + n) on stream s: every per-frame tensor (arena slots,
+// magnitudes in / out, LSTM input products, time-attention history) is addressed from frame t0.
+static int launch_block_range(Engine* e, size_t first, size_t last, int t0, int n, bool roll_hist, hipStream_t s) {
+  const float* a0 = e->arena;
+  const float* a1 = e->arena + (static_cast<size_t>(e->offline) + 1) * e->sstride;
+  const size_t d = static_cast<size_t>(t0) * e->sstride;
+  auto shc = [&](const float*& q) { if (q && q >= a0 && q < a1) q += d; };
+  auto sh = [&](float*& q) { if (q && q >= a0 && q < a1) q += d; };
+  int n_ctfa = 0;
+  for (size_t i = 0; i < first; ++i) n_ctfa += e->plan_off[i].kind == Launch::CTFA;
+  for (size_t i = first; i < last; ++i) {
+    Launch L = e->plan_off[i];
+    hipError_t err = hipSuccess;
+    switch (L.kind) {
+      case Launch::CONV:
+        shc(L.conv.src0); shc(L.conv.src1); sh(L.conv.dst0); sh(L.conv.dst1);
+        L.conv.B = n;
+        err = launch_conv(L.ck, L.conv, s);
+        break;
+      case Launch::LSTM:
+        shc(L.lstm.x); sh(L.lstm.dst); shc(L.lstm.h_in); shc(L.lstm.c_in); sh(L.lstm.h_out); sh(L.lstm.c_out);
+        L.lstm.B = n;
+        err = launch_lstm_block(L.lstm, e->zx + static_cast<size_t>(t0) * 84, n, s);
+        break;
+      case Launch::CTFA: {
+        shc(L.ctfa.x); shc(L.ctfa.e0); sh(L.ctfa.y);
+        L.ctfa.B = n;
+        float* hist = e->ta_hist + static_cast<size_t>(n_ctfa) * (31 + e->offline) * 64 + static_cast<size_t>(t0) * 64;
+        if (e->ctfa_causal) err = launch_ctfa_causal(L.ctfa, hist, roll_hist, s);
+        else err = launch_ctfa(L.ctfa, s);
+        ++n_ctfa;
+        break;
+      }
+      case Launch::INLAYER:
+        L.inl.x += static_cast<size_t>(t0) * NUTLS_BINS; sh(L.inl.y);
+        L.inl.n_pos = n * NUTLS_BINS;
+        err = launch_input_layer(L.inl, s);
+        break;
+      case Launch::OUTCONV:
+        shc(L.outc.x); L.outc.y += static_cast<size_t>(t0) * NUTLS_BINS;
+        L.outc.n_pos = n * NUTLS_BINS;
+        err = launch_out_conv(L.outc, s);
+        break;
+      default: err = hipErrorInvalidValue;
+    }
+    if (err != hipSuccess) return fail(NUTLS_ERR_HIP, "block launch " + L.name + ": " + hipGetErrorString(err));
+  }
+  return NUTLS_OK;
 }
 
 int nutls_offline_set_ctfa_mode(nutls_handle* h, int mode) {
@@ -1181,24 +1266,41 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = static_cast<size_t>(n_frames) * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
-  int n_ctfa = 0;
-  for (const Launch& L0 : e->plan_off) {
-    Launch L = L0;
-    hipError_t err = hipSuccess;
-    switch (L.kind) {
-      case Launch::CONV: L.conv.B = n_frames; err = launch_conv(L.ck, L.conv, s); break;
-      case Launch::LSTM: L.lstm.B = n_frames; err = launch_lstm_block(L.lstm, e->zx, n_frames, s); break;
-      case Launch::CTFA:
-        L.ctfa.B = n_frames;
-        if (e->ctfa_causal) err = launch_ctfa_causal(L.ctfa, e->ta_hist + static_cast<size_t>(n_ctfa) * (31 + e->offline) * 64, s);
-        else err = launch_ctfa(L.ctfa, s);
-        ++n_ctfa;
-        break;
-      case Launch::INLAYER: L.inl.n_pos = n_frames * NUTLS_BINS; err = launch_input_layer(L.inl, s); break;
-      case Launch::OUTCONV: L.outc.n_pos = n_frames * NUTLS_BINS; err = launch_out_conv(L.outc, s); break;
-      default: err = hipErrorInvalidValue;
+  int C = e->ochunks;
+  if (C == 0) C = n_frames >= 256 ? 2 : 1;
+  if (const char* env = getenv("NUTLS_OFFLINE_CHUNKS")) C = atoi(env);          // debugging aid
+  C = std::max(1, std::min({C, static_cast<int>(Engine::kMaxChunks), n_frames}));
+  if (C == 1) {
+    int rc = launch_block_range(e, 0, e->plan_off.size(), 0, n_frames, true, s);
+    if (rc) return rc;
+  } else {
+    // chunk c, group g (= the layers up to and including bottleneck g) starts when chunk c-1 has finished group g: then
+    // the previous-frame taps of all its layers, the LSTM's h / c and the time-attention history of frame t0-1 exist
+    const int per = (n_frames + C - 1) / C;
+    const int n_groups = e->ogroup.back() + 1;
+    HIP_TRY(hipEventRecord(e->oev_fork, s));
+    for (int c = 0; c < C; ++c) HIP_TRY(hipStreamWaitEvent(e->ostream[c], e->oev_fork, 0));
+    size_t first = 0;
+    for (int g = 0; g < n_groups; ++g) {
+      size_t last = first;
+      while (last < e->plan_off.size() && e->ogroup[last] == g) ++last;
+      for (int c = 0; c < C; ++c) {
+        const int t0 = c * per, n = std::min(per, n_frames - t0);
+        if (n <= 0) continue;
+        if (c > 0) HIP_TRY(hipStreamWaitEvent(e->ostream[c], e->oev[(c - 1) * Engine::kGroups + g], 0));
+        int rc = launch_block_range(e, first, last, t0, n, false, e->ostream[c]);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e->oev[c * Engine::kGroups + g], e->ostream[c]));
+      }
+      first = last;
     }
-    if (err != hipSuccess) return fail(NUTLS_ERR_HIP, "block launch " + L.name + ": " + hipGetErrorString(err));
+    for (int c = 0; c < C; ++c)
+      if (c * per < n_frames) HIP_TRY(hipStreamWaitEvent(s, e->oev[c * Engine::kGroups + n_groups - 1], 0));
+    if (e->ctfa_causal)
+      for (int k = 0; k < 12; ++k) {
+        hipError_t err = launch_ctfa_hist_roll(e->ta_hist + static_cast<size_t>(k) * (31 + e->offline) * 64, n_frames, s);
+        if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("time-attention history roll: ") + hipGetErrorString(err));
+      }
   }
   if (mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
   // the last frame's slot becomes the carried state of the next block

@@ -13,6 +13,7 @@
 // registers of lanes l and l+32, so the per-position LayerNorm (over channels) is a register
 // reduction plus ONE cross-lane exchange, and the result leaves as 16-byte channels-last stores.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "nutls_internal.hpp"
 #include "ddb_device.hpp"
@@ -475,10 +476,16 @@ __global__ __launch_bounds__(1024) void ctfa_hist_roll_kernel(float* __restrict_
   }
 }
 
-hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, hipStream_t s) {
+hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, bool roll, hipStream_t s) {
   hipLaunchKernelGGL(ctfa_ta_kernel, dim3(p.B), dim3(256), 0, s, p, hist);
   hipLaunchKernelGGL(ctfa_apply_causal_kernel, dim3(p.B), dim3(256), 0, s, p, hist);
-  hipLaunchKernelGGL(ctfa_hist_roll_kernel, dim3(1), dim3(1024), 0, s, hist, p.B);
+  if (roll) hipLaunchKernelGGL(ctfa_hist_roll_kernel, dim3(1), dim3(1024), 0, s, hist, p.B);
+  return hipGetLastError();
+}
+
+// the last 31 rows of a block of `frames` frames become rows 0..30 of the next block's history
+hipError_t launch_ctfa_hist_roll(float* hist, int frames, hipStream_t s) {
+  hipLaunchKernelGGL(ctfa_hist_roll_kernel, dim3(1), dim3(1024), 0, s, hist, frames);
   return hipGetLastError();
 }
 

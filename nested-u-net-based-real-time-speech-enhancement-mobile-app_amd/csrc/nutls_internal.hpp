@@ -124,7 +124,9 @@ struct CtfaParams {
 };
 hipError_t launch_ctfa(const CtfaParams& p, hipStream_t s);
 // offline / block mode, true 32-frame causal average of the time attention (models/proposed.py:143-147); hist [31 + p.B][64]
-hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, hipStream_t s);
+// `hist` = the history row of the first frame's predecessor-window start; `roll`: the block ends here (see launch_ctfa_hist_roll)
+hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, bool roll, hipStream_t s);
+hipError_t launch_ctfa_hist_roll(float* hist, int frames, hipStream_t s);
 
 struct InLayerParams {   // input_layer: 1x1 conv 1->64 + LN + PReLU
   const float* x;        // [B,256]

@@ -39,6 +39,7 @@ ABI_SYMBOLS = (
     "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
     "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all", "nutls_offline_set_ctfa_mode",
+    "nutls_offline_set_pipeline",
 )
 
 
@@ -83,6 +84,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_process_block.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_process_block_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
     lib.nutls_offline_set_ctfa_mode.argtypes = [c.c_void_p, c.c_int]
+    lib.nutls_offline_set_pipeline.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_fused_num_ops.argtypes = [c.c_int]
     lib.nutls_fused_op_info.argtypes = [c.c_int, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
     lib.nutls_profile_fused.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
@@ -407,9 +409,11 @@ class NutlsOffline:
 
     CTFA_MODES = {"frame": 0, "causal32": 1}
 
-    def __init__(self, weights=None, max_frames: int = 256, device: int = 0, ctfa_mode: str = "frame"):
+    def __init__(self, weights=None, max_frames: int = 256, device: int = 0, ctfa_mode: str = "frame", pipeline: int = 0):
         """``ctfa_mode``: "frame" (default; the frame-wise graph's TA/32, equal to the streaming result) or "causal32"
-        (the offline model's true 32-frame causal average of the time attention, models/proposed.py:143-147)."""
+        (the offline model's true 32-frame causal average of the time attention, models/proposed.py:143-147).
+        ``pipeline``: chunks of consecutive frames a block is cut into, each on its own HIP stream one bottleneck behind
+        the chunk before it (1..16; 0 = chosen from the block length).  The result does not depend on it."""
         if ctfa_mode not in self.CTFA_MODES:
             raise ValueError("ctfa_mode must be one of %s" % sorted(self.CTFA_MODES))
         self._lib = load_library()
@@ -420,6 +424,11 @@ class NutlsOffline:
         if ctfa_mode != "frame":
             _check(self._lib, self._lib.nutls_offline_set_ctfa_mode(self._h, self.CTFA_MODES[ctfa_mode]))
         self.ctfa_mode = ctfa_mode
+        if pipeline:
+            self.set_pipeline(pipeline)
+
+    def set_pipeline(self, chunks: int):
+        _check(self._lib, self._lib.nutls_offline_set_pipeline(self._h, int(chunks)))
 
     def process(self, mags) -> np.ndarray:
         """``mags [N,256]`` float32 (any N) -> enhanced magnitudes ``[N,256]``; blocks of ``max_frames``."""

@@ -109,3 +109,36 @@ def test_offline_causal32_ctfa_matches_oracle_across_block_boundaries(clip):
     assert rms(streaming_form[0], want[0]) < 2e-5      # frame 0: both see TA/32
     assert rms(streaming_form[40:], want[40:]) > 1e-4  # later frames: a different function
     frame.close()
+
+
+@pytest.mark.parametrize("ctfa_mode", ["frame", "causal32"])
+def test_block_pipeline_is_independent_of_the_chunk_count(clip, ctfa_mode):
+    """The block pipeline (chunks of consecutive frames on their own HIP streams, one bottleneck apart) computes what the
+    one-stream block does: 1, 2, 5 (ragged) and 16 chunks, two consecutive blocks so that the carried state and the
+    31-frame time-attention history cross a block boundary too.  (Equal up to the summation order inside the conv
+    kernels, whose tile shape follows the number of positions per launch: 1e-6 RMS.)"""
+    x = clip["mags_in"][:240]
+    want = None
+    for chunks in (1, 2, 5, 16):
+        off = NutlsOffline(max_frames=120, ctfa_mode=ctfa_mode, pipeline=chunks)
+        got = off.process(x)
+        off.close()
+        if want is None:
+            want = got
+            if ctfa_mode == "frame":
+                assert rms(got, clip["mags_out"][:240]) < 2e-5
+        else:
+            assert rms(got, want) < 1e-6 and float(np.abs(got - want).max()) < 5e-5, chunks
+
+
+def test_block_pipeline_default_for_long_blocks(clip):
+    """1024-frame blocks (the section 8(f).2 workload) run with the automatic chunk count; the result equals the
+    frame-by-frame golden outputs of the clip, repeated input and all."""
+    x = np.concatenate([clip["mags_in"]] * 5)[:1024]
+    off = NutlsOffline(max_frames=1024)
+    got = off.process(x)
+    one = NutlsOffline(max_frames=1024, pipeline=1)
+    ref = one.process(x)
+    off.close(); one.close()
+    assert rms(got, ref) < 1e-6
+    assert rms(got[:249], clip["mags_out"]) < 2e-5
