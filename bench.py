@@ -46,7 +46,7 @@ def synthetic_pool(batch, n, seed):
 
 def kernel_source_sha16(mode):
     """Identity of the kernel a PMC traffic record belongs to: hash of the sources of the step kernel."""
-    files = {"fused": ["fused_step.hip", "fused_plan.hpp", "fused_plan_lstm.inc", "fused_plan_base.inc", "ddb_device.hpp"],
+    files = {"fused": ["fused_step.hip", "fused_plan.hpp", "fused_plan_lstm.inc", "fused_plan_base.inc", "ddb_device.hpp", "ddb_fused.hpp"],
              "persistent": ["megakernel.hip", "ddb_device.hpp"]}.get(mode, [])
     h = hashlib.sha256()
     for f in files:

@@ -134,15 +134,22 @@ __device__ __forceinline__ void ddb_block(const DdbParams& p, int stream, float*
 }  // namespace nutls
 
 // -------------------------------------------------------------------------------------------------
-//  The same block for the persistent kernel (512 threads, ~70 KB of LDS scratch): everything that does
-//  not depend on this frame's arithmetic -- the history rings, the previous input / output rows and
-//  the small weights of the six grouped blocks -- is fetched into LDS by all threads up front, and the
-//  two dense (2,3) convs (`in`: C -> G, `out`: G -> C) are split over K across the whole workgroup
-//  (float4 weight loads, coalesced over the output channel) instead of running on F*G threads.
+//  The same block for the one-launch kernels (512 threads, ~70 KB of LDS scratch), built around the latency of
+//  the chain in -> six blocks -> out (the arithmetic is tiny):
+//    * every load that does not depend on this frame's arithmetic -- history rings, previous input / output rows,
+//      the small weights of the six blocks, the K slice of the `in` conv's kernel -- is issued up front by all
+//      threads (one memory latency for all of it); the `out` conv's slice is requested before the chain starts;
+//    * the two dense (2,3) convs (`in`: C -> G, `out`: G -> C) are split over K across the whole workgroup;
+//    * the six blocks run on the F*G threads that own an output (one wavefront when F*G = 64: no workgroup
+//      barrier inside the chain, LDS is in order within a wave); a thread's grouped-conv kernel (6k floats) and
+//      its row of the 1x1 kernel are contiguous in LDS; the current frame's o_6 .. o_0 sit in one row per
+//      frequency bin, newest first, so in_k is simply its last k*G channels;
+//    * the ring slots are rewritten once, after the chain.
 // -------------------------------------------------------------------------------------------------
 namespace nutls {
 
 typedef float ddb_f4 __attribute__((ext_vector_type(4)));
+typedef const ddb_f4 __attribute__((address_space(1)))* ddb_gf4;
 
 // sum over G = 16 or 32 consecutive lanes (aligned), result in all of them: DPP quad / row exchanges, one
 // LDS-crossbar step only for the 32-lane case
@@ -159,77 +166,93 @@ __device__ __forceinline__ float ddb_row_sum(float s, int G) {
   return s;
 }
 
-// K-split dense (2,3) conv:  out[f][co] = sum_{t,kw,ci} W[t][kw][ci][co] * X_t[f+kw-1][ci]
-//   X0 / X1: LDS rows [F][CI] of the previous / current frame; W: global [2][3][CI][CO]
-//   part: LDS [nks][F*CO/4] float4 partial sums.  All nthreads call; the result is left in part[0..] summed
-//   by the first F*CO/4 threads (returned in `acc` for those threads, valid when tid < F*CO/4).
-__device__ __forceinline__ ddb_f4 ddb_dense23(const float* X0, const float* X1, const float* W, int F, int CI, int CO, float* part,
-                                              int tid, int nthreads) {
-  const int nq = (F * CO) >> 2;                 // float4 outputs (a power of two)
-  const int entries = 6 * CI;                   // (t, kw, ci); CI is a power of two
-  // (F, CI, CO are powers of two: no integer divisions anywhere in this block -- a division by a run-time value
-  //  is ~40 instructions)
-  int lci = 0, lnq = 0, lcq = 0, lth = 0;
-  while ((1 << lci) < CI) ++lci;
-  while ((1 << lnq) < nq) ++lnq;
+// K-split dense (2,3) conv:  out[f][co] = sum_{t,kw,ci} W[t][kw][ci][co] * X_t[f+kw-1][ci],  W global [2][3][CI][CO].
+// Thread (K slice ks, output float4 q): its <= 24 weight float4s are loaded ahead of use (ddb_dense_load), the products
+// follow when the inputs are in LDS (ddb_dense_run: partial sums through `part`, one barrier, summed by the first F*CO/4
+// threads).  F, CI, CO are powers of two: no integer divisions.
+struct DdbDense { int lci, lnq, nks, epk, nq, q, ks, f, cq; };
+__device__ __forceinline__ DdbDense ddb_dense_geom(int F, int CI, int CO, int tid, int nthreads) {
+  DdbDense g;
+  g.nq = (F * CO) >> 2;                         // float4 outputs
+  int lcq = 0, lth = 0;
+  g.lci = 0; g.lnq = 0;
+  while ((1 << g.lci) < CI) ++g.lci;
+  while ((1 << g.lnq) < g.nq) ++g.lnq;
   while ((4 << lcq) < CO) ++lcq;
   while ((2 << lth) <= nthreads) ++lth;         // floor(log2(nthreads))
-  // K slices: a power of two that divides 6*CI = 3 * 2^(lci+1), i.e. at most 2*CI, and fits the workgroup
-  int lks = lth - lnq;
-  if (lks > lci + 1) lks = lci + 1;
-  const int nks = 1 << lks;
-  const int epk = entries >> lks;               // <= 24
-  const int q = tid & (nq - 1), ks = tid >> lnq;
-  const int f = q >> lcq, cq = q & ((CO >> 2) - 1);
-  ddb_f4 a = {0.f, 0.f, 0.f, 0.f};
-  if (ks < nks) {
-    // all weight loads of the slice first (independent, one L2 latency), then the products
-    ddb_f4 w[24];
-    float xv[24];
-#pragma unroll
-    for (int j = 0; j < 24; ++j) {
-      if (j < epk) {
-        const int e = ks * epk + j;
-        const int t = e >= 3 * CI ? 1 : 0, r = e - t * 3 * CI;
-        const int kw = r >> lci, ci = r & (CI - 1);
-        const int fr = f + kw - 1;
-        const bool ok = fr >= 0 && fr < F;
-        w[j] = *reinterpret_cast<const ddb_f4 __attribute__((address_space(1)))*>((unsigned long long)(W + static_cast<size_t>(e) * CO + 4 * cq));
-        xv[j] = ok ? (t ? X1 : X0)[fr * CI + ci] : 0.f;
-      }
-    }
+  int lks = lth - g.lnq;                        // K slices: a power of two dividing 6*CI = 3 * 2^(lci+1), that fits the workgroup
+  if (lks > g.lci + 1) lks = g.lci + 1;
+  g.nks = 1 << lks;
+  g.epk = (6 * CI) >> lks;                      // <= 24
+  g.q = tid & (g.nq - 1);
+  g.ks = tid >> g.lnq;
+  g.f = g.q >> lcq;
+  g.cq = g.q & ((CO >> 2) - 1);
+  return g;
+}
+__device__ __forceinline__ void ddb_dense_load(const DdbDense& g, const float* W, int CO, ddb_f4 (&w)[24]) {
+  if (g.ks < g.nks) {
 #pragma unroll
     for (int j = 0; j < 24; ++j)
-      if (j < epk) a += w[j] * xv[j];
-    *reinterpret_cast<ddb_f4*>(part + (static_cast<size_t>(ks) * nq + q) * 4) = a;
+      if (j < g.epk) w[j] = *(ddb_gf4)(unsigned long long)(W + static_cast<size_t>(g.ks * g.epk + j) * CO + 4 * g.cq);
+  }
+}
+// X0 / X1: LDS rows of the previous / current frame with pitches p0 / p1.  All threads call (one barrier inside).
+__device__ __forceinline__ ddb_f4 ddb_dense_run(const DdbDense& g, const float* X0, int p0, const float* X1, int p1, int F, int CI,
+                                                const ddb_f4 (&w)[24], float* part, int tid) {
+  if (g.ks < g.nks) {
+    ddb_f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+      if (j < g.epk) {
+        const int e = g.ks * g.epk + j;
+        const int t = e >= 3 * CI ? 1 : 0, r = e - t * 3 * CI;
+        const int kw = r >> g.lci, ci = r & (CI - 1);
+        const int fr = g.f + kw - 1;
+        const float xv = (fr >= 0 && fr < F) ? (t ? X1[fr * p1 + ci] : X0[fr * p0 + ci]) : 0.f;
+        a += w[j] * xv;
+      }
+    }
+    *reinterpret_cast<ddb_f4*>(part + (static_cast<size_t>(g.ks) * g.nq + g.q) * 4) = a;
   }
   __syncthreads();
   ddb_f4 s = {0.f, 0.f, 0.f, 0.f};
-  if (tid < nq)
-    for (int k2 = 0; k2 < nks; ++k2) s += *reinterpret_cast<const ddb_f4*>(part + (static_cast<size_t>(k2) * nq + tid) * 4);
+  if (tid < g.nq)
+    for (int k2 = 0; k2 < g.nks; ++k2) s += *reinterpret_cast<const ddb_f4*>(part + (static_cast<size_t>(k2) * g.nq + tid) * 4);
   return s;
 }
 
-// lds: >= 17.5K floats.  All nthreads (a multiple of 64, >= 256) call.
+// first float4 of block k's ring / in_k rows in the flat [block][F][k*G] order: FG/4 * k(k-1)/2
+__device__ __forceinline__ int ddb_blk_of(int q, int fg4) {
+  return q < fg4 ? 1 : (q < 3 * fg4 ? 2 : (q < 6 * fg4 ? 3 : (q < 10 * fg4 ? 4 : (q < 15 * fg4 ? 5 : 6))));
+}
+
+// floats of the packed small-weight blob (engine.cpp prep_ddb_weights), in LDS order:
+//   wg: block k [G][2][3][k] | w1: block k [G out][G in] | per block bg, b1, gamma, beta [4][G] | b_in [G] | b_out [2G]
+__host__ __device__ constexpr int ddb_wsmall_floats(int G) { return 126 * G + 6 * G * G + 27 * G; }
+
+// lds: >= 17.5K floats.  All NT threads (a multiple of 64, >= 512) call.
 // lds_y (optional): the output rows are also written to LDS at lds_y + f * lds_y_pitch + c (the fused kernel's next image).
-__device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, float* lds, int tid, int nthreads,
+template <int NT>
+__device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, float* lds, int tid,
                                              unsigned long long* dbg_lds = nullptr, float* lds_y = nullptr, int lds_y_pitch = 0) {
-#define DDB_T(k) do { if (dbg_lds && (tid & 63) == 0) dbg_lds[(tid >> 6) * 16 + (k)] = clock64(); } while (0)
+#define DDB_T(k) do { if (dbg_lds && (tid & 63) == 0) dbg_lds[(tid >> 6) * 16 + (k)] = wall_clock64(); } while (0)
+  static_assert(NT >= 512 && NT % 64 == 0, "staging below is sized for >= 512 threads");
   DDB_T(0);
   const int F = p.F, C = p.C, G = C >> 1;
-  const int FG = F * G, FC = F * C;
+  const int FG = F * G, FC = F * C, G7 = 7 * G;
   int lg = 0;
-  while ((1 << lg) < G) ++lg;                // G = 16 or 32, C = 2G
-  float* xs = lds;                    // [F][C]   current input
-  float* pin = xs + FC;               // [F][C]   previous input
-  float* o = pin + FC;                // [7][F][G] o_0 .. o_6
-  float* yv = o + 7 * FG;             // [F][G]
-  float* pout = yv + FG;              // [F][G]   previous o_6
-  float* rings = pout + FG;           // block k at rings + F*G*k(k-1)/2 : [F][k*G] (frame t-d)
-  float* wgs = rings + 21 * FG;       // block k at wgs + 6*G*k(k-1)/2 : [2][3][k][G]
-  float* w1s = wgs + 126 * G;         // [6][G][G]
-  float* sm = w1s + 6 * G * G;        // [6][4][G] bg, b1, gamma, beta
-  float* part = sm + 24 * G;          // K-split partial sums (<= 2048 floats)
+  while ((1 << lg) < G) ++lg;                // G = 16 or 32, C = 2G, F = 4
+  float* xs = lds;                    // [F][C]    current input
+  float* pin = xs + FC;               // [F][C]    previous input
+  float* pout = pin + FC;             // [F][G]    previous o_6
+  float* R = pout + FG;               // [F][7G]   this frame's o_6 | o_5 | ... | o_0  (in_k = the last k*G channels of a row)
+  float* yv = R + 7 * FG;             // [F][G]
+  float* rings = yv + FG;             // block k at rings + F*G*k(k-1)/2 : [F][k*G] (frame t-d)
+  float* wgs = rings + 21 * FG;       // block k at wgs + 6*G*k(k-1)/2 : [G][2][3][k]
+  float* w1s = wgs + 126 * G;         // [6][G out][G in]
+  float* sm = w1s + 6 * G * G;        // [6][4][G] bg, b1, gamma, beta | b_in [G] | b_out [C]
+  float* part = sm + 27 * G;          // K-split partial sums (<= 2048 floats)
   const size_t soff = static_cast<size_t>(stream) * p.sstride;
   const int step = *p.step;
   // (`p` lives in global memory and the block stores to global memory: every p.field the loops below touched
@@ -237,109 +260,145 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
   const float* const px = p.x + soff;
   float* const pst_in = p.st_in + soff;
   float* const pst_out = p.st_out + soff;
-  const int x_ld = p.x_ld;
+  float* const pdst = p.dst + soff;
+  const int x_ld = p.x_ld, dst_ld = p.dst_ld;
+  const float a_in = p.a_in, a_out = p.a_out;
+  float alpha[6];
   float* rp[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) rp[k] = p.st_blk[k] + soff + static_cast<size_t>(step & ((1 << k) - 1)) * F * (k + 1) * G;
-  // ---- phase A: everything that is already known
-  for (int q = tid; q < FC; q += nthreads) {
-    const int f = q >> (lg + 1), c = q & (C - 1);
-    xs[q] = px[f * x_ld + c];
-    pin[q] = pst_in[q];
+  for (int k = 0; k < 6; ++k) {
+    rp[k] = p.st_blk[k] + soff + static_cast<size_t>(step & ((1 << k) - 1)) * F * (k + 1) * G;
+    alpha[k] = p.alpha[k];
   }
-  for (int q = tid; q < FG; q += nthreads) pout[q] = pst_out[q];
+  const int fg4 = FG >> 2;
+  // ---- phase A: every load that is already known, all in flight together
   {
-    // small weights: one packed blob in exactly this LDS order (wgs | w1s | sm), float4 copies, all independent
-    const int n4 = (126 * G + 6 * G * G + 24 * G) / 4;
-    const ddb_f4 __attribute__((address_space(1)))* src = (const ddb_f4 __attribute__((address_space(1)))*)(unsigned long long)p.wsmall;
-    for (int q = tid; q < n4; q += nthreads) reinterpret_cast<ddb_f4*>(wgs)[q] = src[q];
-    // history rings of the six blocks as one flat index space (block k starts at FG * k(k-1)/2)
-    for (int q = tid; q < 21 * FG; q += nthreads) {
-      // block k starts at FG * k(k-1)/2: q < FG -> 1, < 3FG -> 2, < 6FG -> 3, < 10FG -> 4, < 15FG -> 5, else 6
-      const int k = q < FG ? 1 : (q < 3 * FG ? 2 : (q < 6 * FG ? 3 : (q < 10 * FG ? 4 : (q < 15 * FG ? 5 : 6))));
-      const int base = FG * (k * (k - 1) / 2);
-      const float* r = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
-      rings[q] = r[q - base];
+    const DdbDense gi = ddb_dense_geom(F, C, G, tid, NT);
+    ddb_f4 w[24];
+    ddb_dense_load(gi, p.w_in, G, w);
+    float vx = 0.f, vp = 0.f, vo = 0.f;
+    if (tid < FC) {
+      const int f = tid >> (lg + 1), c = tid & (C - 1);
+      vx = px[f * x_ld + c];
+      vp = pst_in[tid];
     }
-  }
-  DDB_T(1);
-  __syncthreads();
-  DDB_T(2);
-  for (int q = tid; q < FC; q += nthreads) pst_in[q] = xs[q];      // prev_in <- x
-  // ---- o_0 = PReLU(conv(2,3)([prev_in ; x]))
-  {
-    const ddb_f4 s = ddb_dense23(pin, xs, p.w_in, F, C, G, part, tid, nthreads);
-    if (tid < FG / 4) {
-      const int cq = tid & ((G >> 2) - 1);
+    if (tid < FG) vo = pst_out[tid];
+    constexpr int MAXW = (ddb_wsmall_floats(32) / 4 + NT - 1) / NT;      // 6 at 512 threads
+    constexpr int MAXR = (21 * 128 / 4 + NT - 1) / NT;                   // 2
+    const int n4 = ddb_wsmall_floats(G) >> 2, r4 = 21 * fg4;
+    ddb_f4 ws[MAXW], rv[MAXR];
+    const ddb_gf4 src = (ddb_gf4)(unsigned long long)p.wsmall;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[4 * tid + j] = ddb_prelu(s[j] + p.b_in[4 * cq + j], p.a_in);
+    for (int i = 0; i < MAXW; ++i)
+      if (tid + i * NT < n4) ws[i] = src[tid + i * NT];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+      const int q = tid + i * NT;
+      if (q < r4) {
+        const int k = ddb_blk_of(q, fg4);
+        const float* r = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
+        rv[i] = *(ddb_gf4)(unsigned long long)(r + 4 * (q - fg4 * (k * (k - 1) / 2)));
+      }
     }
+    if (tid < FC) { xs[tid] = vx; pin[tid] = vp; }
+    if (tid < FG) pout[tid] = vo;
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i)
+      if (tid + i * NT < n4) reinterpret_cast<ddb_f4*>(wgs)[tid + i * NT] = ws[i];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i)
+      if (tid + i * NT < r4) reinterpret_cast<ddb_f4*>(rings)[tid + i * NT] = rv[i];
+    DDB_T(1);
     __syncthreads();
+    DDB_T(2);
+    if (tid < FC) pst_in[tid] = vx;        // prev_in <- x
+    // ---- o_0 = PReLU(conv(2,3)([prev_in ; x]))  ->  channels [6G, 7G) of the rows
+    const ddb_f4 s = ddb_dense_run(gi, pin, C, xs, C, F, C, w, part, tid);
+    if (tid < fg4) {
+      const int f = tid >> (lg - 2), cq = tid & ((G >> 2) - 1);
+      ddb_f4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = ddb_prelu(s[j] + sm[24 * G + 4 * cq + j], a_in);
+      *reinterpret_cast<ddb_f4*>(R + f * G7 + 6 * G + 4 * cq) = r;
+    }
   }
+  // the `out` conv's K slice: requested now, used after the chain
+  const DdbDense go = ddb_dense_geom(F, G, C, tid, NT);
+  ddb_f4 wo[24];
+  ddb_dense_load(go, p.w_out, C, wo);
+  __syncthreads();
   DDB_T(3);
-  // ---- blocks 1..6 (sequential: dense connectivity)
+  // ---- blocks 1..6 (sequential: dense connectivity) on the threads that own an output
+  const bool one_wave = FG <= 64;
+  const int f = tid >> lg, g = tid & (G - 1);
   int roff = 0, woff = 0;
+#pragma unroll
   for (int k = 1; k <= 6; ++k) {
     const int d = 1 << (k - 1), kG = k * G;
-    const float* ringl = rings + roff;
-    const float* wgl = wgs + woff;
     const float* sml = sm + (k - 1) * 4 * G;
     if (tid < FG) {
-      const int f = tid >> lg, g = tid & (G - 1);
+      const float* wl = wgs + woff + g * 6 * k;            // [t][kw][j]
       float a = sml[g];
+#pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int fr = f + (kw - 1) * d;
-        if (fr < 0 || fr >= F) continue;
-        for (int j = 0; j < k; ++j) {
-          const int ch = g * k + j;             // channel of in_k seen by filter g
-          const int m = ch >> lg;               // in_k = [o_{k-1}, ..., o_0]: chunk m is o_{k-1-m}
-          const float cur = o[(k - 1 - m) * FG + fr * G + (ch & (G - 1))];
-          const float old = ringl[fr * kG + ch];
-          a = fmaf(wgl[(kw * k + j) * G + g], old, a);
-          a = fmaf(wgl[(3 * k + kw * k + j) * G + g], cur, a);
+        if (fr >= 0 && fr < F) {
+          const float* cur = R + fr * G7 + (7 - k) * G + g * k;      // in_k of this frame, channels g*k ..
+          const float* old = rings + roff + fr * kG + g * k;         // in_k of frame t-d
+#pragma unroll
+          for (int j = 0; j < k; ++j) {
+            a = fmaf(wl[kw * k + j], old[j], a);
+            a = fmaf(wl[(3 + kw) * k + j], cur[j], a);
+          }
         }
       }
       yv[tid] = a;
     }
-    // ring slot <- in_k of this frame (every read of the old slot went through LDS)
-    {
-      float* ring = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
-      for (int q = tid; q < F * kG; q += nthreads) {
-        const int f = (q >= kG) + (q >= 2 * kG) + (q >= 3 * kG), ch = q - f * kG;      // F <= 4
-        const int m = ch >> lg;
-        ring[q] = o[(k - 1 - m) * FG + f * G + (ch & (G - 1))];
-      }
-    }
-    __syncthreads();
+    if (one_wave) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
     if (tid < FG) {
-      const int f = tid >> lg, g = tid & (G - 1);
-      const float* w1l = w1s + (k - 1) * G * G;
-      float z = sml[G + g];
-      for (int gi = 0; gi < G; ++gi) z = fmaf(w1l[gi * G + g], yv[f * G + gi], z);     // [gin][gout]
+      const ddb_f4* w1l = reinterpret_cast<const ddb_f4*>(w1s + (k - 1) * G * G + g * G);
+      const ddb_f4* yr = reinterpret_cast<const ddb_f4*>(yv + f * G);
+      float z0 = sml[G + g], z1 = 0.f;
+      for (int i = 0; i < (G >> 2); i += 2) {
+        const ddb_f4 wa = w1l[i], ya = yr[i], wb = w1l[i + 1], yb = yr[i + 1];
+        z0 += wa[0] * ya[0] + wa[1] * ya[1] + wa[2] * ya[2] + wa[3] * ya[3];
+        z1 += wb[0] * yb[0] + wb[1] * yb[1] + wb[2] * yb[2] + wb[3] * yb[3];
+      }
+      const float z = z0 + z1;
       // LayerNorm over the G channels of row f = G consecutive lanes
       const float inv_g = 1.0f / static_cast<float>(G);
       const float mean = ddb_row_sum(z, G) * inv_g;
       const float dv = z - mean;
       const float rstd = __builtin_amdgcn_rsqf(ddb_row_sum(dv * dv, G) * inv_g + 1e-8f);
-      o[k * FG + tid] = ddb_prelu(dv * rstd * sml[2 * G + g] + sml[3 * G + g], p.alpha[k - 1]);
+      R[f * G7 + (6 - k) * G + g] = ddb_prelu(dv * rstd * sml[2 * G + g] + sml[3 * G + g], alpha[k - 1]);
     }
-    __syncthreads();
+    if (one_wave) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else __syncthreads();
     roff += F * kG;
     woff += 6 * kG;
   }
+  __syncthreads();
   DDB_T(4);
-  // ---- out conv over [prev_out ; o_6], then prev_out <- o_6
+  // ---- ring slots <- in_k of this frame (every read of the old slots went through LDS); prev_out <- o_6
+  for (int q = tid; q < 21 * fg4; q += NT) {
+    const int k = ddb_blk_of(q, fg4);
+    const int kq = (k * G) >> 2;                                                      // float4s per row of block k
+    const int local = q - fg4 * (k * (k - 1) / 2);
+    const int fr = (local >= kq) + (local >= 2 * kq) + (local >= 3 * kq), c4 = local - fr * kq;      // F <= 4
+    float* ring = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
+    *reinterpret_cast<ddb_f4*>(ring + 4 * local) = *reinterpret_cast<const ddb_f4*>(R + fr * G7 + (7 - k) * G + 4 * c4);
+  }
+  if (tid < FG) pst_out[tid] = R[f * G7 + g];
+  // ---- out conv over [prev_out ; o_6]
   {
-    const ddb_f4 s = ddb_dense23(pout, o + 6 * FG, p.w_out, F, G, C, part, tid, nthreads);
+    const ddb_f4 s = ddb_dense_run(go, pout, G, R, G7, F, G, wo, part, tid);
     if (tid < FC / 4) {
-      const int f = tid >> (lg - 1), cq = tid & ((C >> 2) - 1);
+      const int fo = tid >> (lg - 1), cq = tid & ((C >> 2) - 1);
       ddb_f4 r;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = ddb_prelu(s[j] + p.b_out[4 * cq + j], p.a_out);
-      *reinterpret_cast<ddb_f4*>(p.dst + soff + f * p.dst_ld + 4 * cq) = r;
-      if (lds_y) *reinterpret_cast<ddb_f4*>(lds_y + f * lds_y_pitch + 4 * cq) = r;
+      for (int j = 0; j < 4; ++j) r[j] = ddb_prelu(s[j] + sm[25 * G + 4 * cq + j], a_out);
+      *reinterpret_cast<ddb_f4*>(pdst + fo * dst_ld + 4 * cq) = r;
+      if (lds_y) *reinterpret_cast<ddb_f4*>(lds_y + fo * lds_y_pitch + 4 * cq) = r;
     }
-    for (int q = tid; q < FG; q += nthreads) pst_out[q] = o[6 * FG + q];
   }
   DDB_T(5);
   __syncthreads();

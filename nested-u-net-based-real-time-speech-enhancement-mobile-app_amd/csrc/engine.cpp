@@ -346,7 +346,9 @@ static int prep_ddb_weights(Engine* e, const WeightMap& wm) {
     };
     if ((rc = conv_prelu(tag + "_in", &W.w_in, &W.b_in, &W.a_in))) return rc;
     if ((rc = conv_prelu(tag + "_out", &W.w_out, &W.b_out, &W.a_out))) return rc;
-    std::vector<float> pk_wg, pk_w1, pk_sm;      // the LDS image of ddb_block_wg: wg all blocks | w1 all blocks | bg,b1,gamma,beta per block
+    // the LDS image of ddb_block_wg (ddb_device.hpp): wg all blocks [G][2][3][k] | w1 all blocks [G out][G in] |
+    // bg, b1, gamma, beta per block | b_in | b_out -- a thread's grouped kernel and its 1x1 row are contiguous
+    std::vector<float> pk_wg, pk_w1, pk_sm;
     for (int k = 1; k <= 6; ++k) {
       const std::string n = tag + "_" + std::to_string(k);
       const HostTensor* wg = find(wm, n + ".wg", &err);
@@ -369,13 +371,29 @@ static int prep_ddb_weights(Engine* e, const WeightMap& wm) {
       if ((rc = upload(e, gm->data, &W.gamma[k - 1]))) return rc;
       if ((rc = upload(e, bt->data, &W.beta[k - 1]))) return rc;
       W.alpha[k - 1] = al->data[0];
-      const std::vector<float> wgt = ohwi_to_tkio(*wg), w1t = transpose2d(*w1, G, G);
-      pk_wg.insert(pk_wg.end(), wgt.begin(), wgt.end());
-      pk_w1.insert(pk_w1.end(), w1t.begin(), w1t.end());
+      pk_wg.insert(pk_wg.end(), wg->data.begin(), wg->data.end());
+      pk_w1.insert(pk_w1.end(), w1->data.begin(), w1->data.end());
       for (const HostTensor* t : {bg, b1, gm, bt}) pk_sm.insert(pk_sm.end(), t->data.begin(), t->data.end());
     }
     pk_wg.insert(pk_wg.end(), pk_w1.begin(), pk_w1.end());
     pk_wg.insert(pk_wg.end(), pk_sm.begin(), pk_sm.end());
+    for (const char* bn : {"_in.b", "_out.b"}) {
+      const HostTensor* tb = find(wm, tag + bn, &err);
+      if (!tb) return fail(NUTLS_ERR_WEIGHTS, err);
+      pk_wg.insert(pk_wg.end(), tb->data.begin(), tb->data.end());
+    }
+    // the fused kernel's copy of the 1x1 kernels (ddb_fused.hpp): row g pre-rotated for DPP row rotations,
+    // entry n = w1[g][((g - n) mod 16) + 16 h], first the lane's own half h of the row, then (G = 32) the other one
+    {
+      const int G = static_cast<int>(pk_sm.size()) / 24;
+      for (int k = 0; k < 6; ++k)
+        for (int g = 0; g < G; ++g)
+          for (int half = 0; half < G / 16; ++half)
+            for (int n = 0; n < 16; ++n) {
+              const int h = half == 0 ? g >> 4 : 1 - (g >> 4);
+              pk_wg.push_back(pk_w1[(static_cast<size_t>(k) * G + g) * G + ((g - n) & 15) + 16 * h]);
+            }
+    }
     if ((rc = upload(e, pk_wg, &W.wsmall))) return rc;
   }
   return NUTLS_OK;

@@ -28,7 +28,6 @@
 
 #include "nutls_internal.hpp"
 #include "fused_plan.hpp"
-#include "ddb_device.hpp"
 
 #ifndef FZ_PROF
 #define FZ_PROF 0
@@ -66,7 +65,7 @@ struct Ctx {
   gf_t io_out;
   unsigned long long* prof;
   const DdbParams* ddb;        // baseline variant: the 13 dilated-dense blocks of this step's parity
-  int stream;
+  int stream, step;            // step: frame counter (position in the dilated-dense history rings)
 };
 
 // profiling build: phase stamps inside an op (wave 0 of workgroup 0), slot k of op I at prof[kNumOps + 1 + 8 I + k]
@@ -753,14 +752,25 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
   }
 }
 
+#if FZ_BASE
 // ---- dilated-dense bottleneck of the baseline variant (models/nunet_tls.py:277-359, streaming converter_nunet_tls.py:374-411):
 //      ddb_device.hpp's workgroup form -- input rows from the state tensor in HBM (the op before drained its stores), history
 //      rings in HBM, output to HBM and, here, straight into the next conv's image.
 template <int I>
 __device__ __forceinline__ void ddb_op(const Ctx& cx, int tid) {
   constexpr OpD d = kOps[I];
-  ddb_block_wg(cx.ddb[d.bidx], cx.stream, lds + DDB_LDS_B / 4, tid, THREADS, nullptr, lds + d.y_b / 4, d.x_pitch_b / 4);
+  // (profiling build: the block's own stamps, wave 0, go to the op's phase slots -- loads issued, loads landed, o_0, chain, ring stores, out)
+  unsigned long long* dbg = (FZ_PROF && cx.prof) ? reinterpret_cast<unsigned long long*>(lds + (DDB_LDS_B + 72 * 1024) / 4) : nullptr;
+  constexpr int G = d.x_cols / 2, F = d.din / d.x_cols;
+  static_assert(ddbz_lds_floats<G>(F) * 4 <= 70 * 1024, "dilated-dense scratch over its LDS region");
+  ddb_block_fz<THREADS, G, F>(cx.ddb[d.bidx], cx.stream, cx.step, lds + DDB_LDS_B / 4, tid, dbg, lds + d.y_b / 4, d.x_pitch_b / 4);
+  if (FZ_PROF && cx.prof && tid == 0) {
+    constexpr int slot[6] = {0, 5, 6, 1, 2, 3};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cx.prof[kNumOps + 1 + 8 * I + slot[k]] = dbg[k + 1];
+  }
 }
+#endif
 
 // 64 -> 16 (ReLU) -> 64 perceptron of the CTFA gates, evaluated by ONE wave without barriers (lane c = channel c)
 __device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1)[4], float b1_u, const f32x4 (&w2)[4], float b2, int scr_b, int lane) {
@@ -883,8 +893,10 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
     else conv_r32<I>(cx, tid, c, p1, p3);
   } else if constexpr (d.type == T_LSTM) {
     lstm_op<I>(cx, tid, c);
+#if FZ_BASE
   } else if constexpr (d.type == T_DDB) {
     ddb_op<I>(cx, tid);
+#endif
   } else {
     ctfa_op<I>(cx, tid, c);
   }
@@ -948,6 +960,7 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
   cx.ddb = a.ddb ? a.ddb + a.par * 13 : nullptr;
   cx.stream = stream;
+  cx.step = a.ddb ? *a.ddb->step : 0;
   Carry<0> c0;
   {
     int tid = threadIdx.x;

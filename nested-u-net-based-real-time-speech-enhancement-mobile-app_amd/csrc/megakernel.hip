@@ -972,7 +972,7 @@ __global__ __launch_bounds__(MK_THREADS) void nutls_stream_step_kernel(const Ste
         } else if (op == DEV_OP_INLAYER) {
           input_layer_op(cur, a, stream, lds_in, tid, nc_hand, nxt);
         } else if (DDB && op == DEV_OP_DDB) {
-          ddb_block_wg(a.ddb[cur.w[0]], stream, lds_out, tid, MK_THREADS,
+          ddb_block_wg<MK_THREADS>(a.ddb[cur.w[0]], stream, lds_out, tid,
                        (PROF && dbg) ? reinterpret_cast<unsigned long long*>(lds_out + MK_LDS_OUT) : nullptr);
           if (PROF && dbg) {
             __syncthreads();
