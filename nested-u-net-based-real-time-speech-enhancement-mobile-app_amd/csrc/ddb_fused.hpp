@@ -3,7 +3,8 @@
 // (G = 16 or 32 channels per block, F = 1, 2 or 4 frequency bins) and the chain in -> six blocks -> out arranged
 // around its latency -- the arithmetic is a few hundred FMAs per thread:
 //   * all loads that do not depend on this frame (rings, previous input / output rows, the blocks' small weights, the
-//     K slice of the `in` kernel) are issued together at the top; the `out` kernel's slice before the chain;
+//     K slice of the `in` kernel) are requested two ops ahead and travel in the fused kernel's carry registers
+//     (ddbz_prefetch); the `out` kernel's slice is requested before the chain;
 //   * barriers wait for LDS only (the stores to the state tensors and the weight prefetch stay in flight);
 //   * the input rows are read where the previous conv op left them (the next image in LDS);
 //   * the six blocks run on the F*G threads that own an output.  Per block ONE LDS round trip: o_{k-1} is written,
@@ -12,6 +13,8 @@
 //     a register, the 1x1 conv gathers the row's G values with DPP row rotations (the thread's kernel row is stored
 //     pre-rotated: w1rot[g][n] = w1[g][(g - n) mod 16 ...]), LayerNorm sums are DPP row sums.
 #pragma once
+#include <cstddef>
+
 #include "ddb_device.hpp"
 
 namespace nutls {
@@ -88,11 +91,111 @@ __device__ __forceinline__ void ddbz_mv16(float y, const float (&w)[16], float& 
 template <int G>
 constexpr int ddbz_lds_floats(int F) { return 2 * F * G + F * G + 7 * F * G + 21 * F * G + 126 * G + 6 * G * G + 27 * G + 2048; }
 
+// What the op's loads that do not depend on this frame occupy in the fused kernel's carry (float4 slots per thread):
+// [K slice of the `in` kernel, when it is small] [small weights] [ring rows] [previous input, previous o_6]
+template <int NT, int G, int F>
+struct DdbzCarry {
+  static constexpr int epk = DdbzDense<NT, F, 2 * G, G>::epk;
+  static constexpr int WI = epk <= 8 ? epk : 0;                 // (the central block's 24-slot slice is loaded in the op)
+  static constexpr int n_wg = 126 * G / 4, n_w1 = 6 * G * G / 4, n_sm = 27 * G / 4, n4 = n_wg + n_w1 + n_sm;
+  static constexpr int MAXW = (n4 + NT - 1) / NT, MAXR = (21 * F * G / 4 + NT - 1) / NT;
+  static constexpr int N = WI + MAXW + MAXR + 1;
+};
+
+// The op's parameter record (DdbParams, global memory) read with SCALAR loads, one round trip for all of it.  Left to
+// the compiler these are vector loads -- the kernel stores to global memory, so nothing is provably unclobbered -- each
+// followed by `s_waitcnt vmcnt(0)` because the next address depends on it: five dependent memory round trips (~3 us)
+// at the top of the op.  (The records are never written by the kernel: the scalar cache is coherent for them.)
+struct DdbzRec {
+  const float *w_in, *w_out, *wsmall;
+  float *st_in, *st_out, *dst, *st_blk[6];
+  float a_in, a_out, alpha[6];
+  int dst_ld;
+  long long sstride;
+};
+#define DDBZ_OFF(f) static_cast<int>(offsetof(DdbParams, f))
+__device__ __forceinline__ DdbzRec ddbz_load_rec(const DdbParams* gp) {
+  unsigned long long q[12];
+  asm volatile(
+      "s_load_dwordx2 %0, %12, %13\n\ts_load_dwordx2 %1, %12, %14\n\ts_load_dwordx2 %2, %12, %15\n\t"
+      "s_load_dwordx2 %3, %12, %16\n\ts_load_dwordx2 %4, %12, %17\n\ts_load_dwordx2 %5, %12, %18\n\t"
+      "s_load_dwordx2 %6, %12, %19\n\ts_load_dwordx2 %7, %12, %20\n\ts_load_dwordx2 %8, %12, %21\n\t"
+      "s_load_dwordx2 %9, %12, %22\n\ts_load_dwordx2 %10, %12, %23\n\ts_load_dwordx2 %11, %12, %24\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(q[0]), "=&s"(q[1]), "=&s"(q[2]), "=&s"(q[3]), "=&s"(q[4]), "=&s"(q[5]), "=&s"(q[6]), "=&s"(q[7]), "=&s"(q[8]),
+        "=&s"(q[9]), "=&s"(q[10]), "=&s"(q[11])
+      : "s"(gp), "n"(DDBZ_OFF(w_in)), "n"(DDBZ_OFF(w_out)), "n"(DDBZ_OFF(wsmall)), "n"(DDBZ_OFF(st_in)), "n"(DDBZ_OFF(st_out)),
+        "n"(DDBZ_OFF(dst)), "n"(DDBZ_OFF(st_blk[0])), "n"(DDBZ_OFF(st_blk[1])), "n"(DDBZ_OFF(st_blk[2])), "n"(DDBZ_OFF(st_blk[3])),
+        "n"(DDBZ_OFF(st_blk[4])), "n"(DDBZ_OFF(st_blk[5])));
+  unsigned long long ss;
+  unsigned f[9];
+  asm volatile(
+      "s_load_dword %0, %10, %11\n\ts_load_dword %1, %10, %12\n\ts_load_dword %2, %10, %13\n\ts_load_dword %3, %10, %14\n\t"
+      "s_load_dword %4, %10, %15\n\ts_load_dword %5, %10, %16\n\ts_load_dword %6, %10, %17\n\ts_load_dword %7, %10, %18\n\t"
+      "s_load_dword %8, %10, %19\n\ts_load_dwordx2 %9, %10, %20\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(f[0]), "=&s"(f[1]), "=&s"(f[2]), "=&s"(f[3]), "=&s"(f[4]), "=&s"(f[5]), "=&s"(f[6]), "=&s"(f[7]), "=&s"(f[8]), "=&s"(ss)
+      : "s"(gp), "n"(DDBZ_OFF(a_in)), "n"(DDBZ_OFF(a_out)), "n"(DDBZ_OFF(alpha[0])), "n"(DDBZ_OFF(alpha[1])), "n"(DDBZ_OFF(alpha[2])),
+        "n"(DDBZ_OFF(alpha[3])), "n"(DDBZ_OFF(alpha[4])), "n"(DDBZ_OFF(alpha[5])), "n"(DDBZ_OFF(dst_ld)), "n"(DDBZ_OFF(sstride)));
+  DdbzRec r;
+  r.w_in = reinterpret_cast<const float*>(q[0]); r.w_out = reinterpret_cast<const float*>(q[1]); r.wsmall = reinterpret_cast<const float*>(q[2]);
+  r.st_in = reinterpret_cast<float*>(q[3]); r.st_out = reinterpret_cast<float*>(q[4]); r.dst = reinterpret_cast<float*>(q[5]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    r.st_blk[k] = reinterpret_cast<float*>(q[6 + k]);
+    r.alpha[k] = __builtin_bit_cast(float, f[2 + k]);
+  }
+  r.a_in = __builtin_bit_cast(float, f[0]);
+  r.a_out = __builtin_bit_cast(float, f[1]);
+  r.dst_ld = static_cast<int>(f[8]);
+  r.sstride = static_cast<long long>(ss);
+  return r;
+}
+#undef DDBZ_OFF
+
+__device__ __forceinline__ float* ddbz_ring(const DdbzRec& p, size_t soff, int step, int k /* 0..5 */, int F, int G) {
+  return p.st_blk[k] + soff + static_cast<size_t>(step & ((1 << k) - 1)) * F * (k + 1) * G;
+}
+
+// Issues those loads (any time after the previous frame's launch: the rings are only rewritten by this op itself).
+template <int NT, int G, int F>
+__device__ __forceinline__ void ddbz_prefetch(const DdbzRec& p, int stream, int step, int tid, ddb_f4 (&pre)[DdbzCarry<NT, G, F>::N]) {
+  using K = DdbzCarry<NT, G, F>;
+  constexpr int C = 2 * G, FG = F * G, FC = F * C, fg4 = FG / 4;
+  const size_t soff = static_cast<size_t>(stream) * p.sstride;
+  if constexpr (K::WI > 0) {
+    ddb_f4 wi[K::epk];
+    ddbz_dense_load<NT, F, C, G>(p.w_in, tid, wi);
+#pragma unroll
+    for (int j = 0; j < K::epk; ++j) pre[j] = wi[j];
+  }
+  const ddb_gf4 src = (ddb_gf4)(unsigned long long)p.wsmall;      // global blob = wg | w1 (plain) | sm | w1 (rotated); LDS = wg | w1 rotated | sm
+#pragma unroll
+  for (int i = 0; i < K::MAXW; ++i) {
+    const int q = tid + i * NT;
+    if (q < K::n4) pre[K::WI + i] = src[(q >= K::n_wg && q < K::n_wg + K::n_w1) ? q + K::n_w1 + K::n_sm : q];      // (sm sits at the same offset in both)
+  }
+  const float* rp[6];          // (scalar registers; indexing the record with a per-lane k would be a dependent vector load)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rp[k] = ddbz_ring(p, soff, step, k, F, G);
+#pragma unroll
+  for (int i = 0; i < K::MAXR; ++i) {
+    const int q = tid + i * NT;
+    if (q < 21 * fg4) {
+      const int k = ddb_blk_of(q, fg4);
+      const float* r = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
+      pre[K::WI + K::MAXW + i] = *(ddb_gf4)(unsigned long long)(r + 4 * (q - fg4 * (k * (k - 1) / 2)));
+    }
+  }
+  if (tid < FC) pre[K::N - 1][0] = (p.st_in + soff)[tid];
+  if (tid < FG) pre[K::N - 1][1] = (p.st_out + soff)[tid];
+}
+
 // lds: ddbz_lds_floats<G>(F) floats of scratch.  lds_y: the next image's rows (pitch lds_pitch floats): channels [0, 2G)
 // receive the block's output, channels [2G, 4G) hold its input.  `step`: the frame counter (ring position).
 template <int NT, int G, int F>
-__device__ __forceinline__ void ddb_block_fz(const DdbParams& p, int stream, int step, float* lds, int tid, unsigned long long* dbg_lds,
-                                             float* lds_y, int lds_pitch) {
+__device__ __forceinline__ void ddb_block_fz(const DdbzRec& p, int stream, int step, float* lds, int tid, unsigned long long* dbg_lds,
+                                             float* lds_y, int lds_pitch, const ddb_f4 (&pre)[DdbzCarry<NT, G, F>::N]) {
 #define DDBZ_T(k) do { if (dbg_lds && (tid & 63) == 0) dbg_lds[(tid >> 6) * 16 + (k)] = wall_clock64(); } while (0)
   static_assert((G == 16 || G == 32) && (F == 1 || F == 2 || F == 4) && NT >= 512 && NT % 64 == 0, "unsupported block shape");
   constexpr int C = 2 * G, FG = F * G, FC = F * C, G7 = 7 * G, lg = ddbz_log2(G), fg4 = FG / 4;
@@ -116,45 +219,29 @@ __device__ __forceinline__ void ddb_block_fz(const DdbParams& p, int stream, int
   float* rp[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    rp[k] = p.st_blk[k] + soff + static_cast<size_t>(step & ((1 << k) - 1)) * F * (k + 1) * G;
+    rp[k] = ddbz_ring(p, soff, step, k, F, G);
     alpha[k] = p.alpha[k];
   }
-  // ---- phase A: every load that is already known, all in flight together
+  // ---- phase A: what was requested ahead (ddbz_prefetch) goes to LDS
   using DI = DdbzDense<NT, F, C, G>;
   using DO = DdbzDense<NT, F, G, C>;
+  using K = DdbzCarry<NT, G, F>;
   {
     ddb_f4 wi[DI::epk];
-    ddbz_dense_load<NT, F, C, G>(p.w_in, tid, wi);
-    float vp = 0.f, vo = 0.f;
-    if (tid < FC) vp = pst_in[tid];
-    if (tid < FG) vo = pst_out[tid];
-    // small weights: global blob = wg | w1 (plain) | sm | w1 (rotated); LDS = wg | w1 rotated | sm
-    constexpr int n_wg = 126 * G / 4, n_w1 = 6 * G * G / 4, n_sm = 27 * G / 4, n4 = n_wg + n_w1 + n_sm;
-    constexpr int MAXW = (n4 + NT - 1) / NT, MAXR = (21 * fg4 + NT - 1) / NT;
-    ddb_f4 ws[MAXW], rv[MAXR];
-    const ddb_gf4 src = (ddb_gf4)(unsigned long long)p.wsmall;
+    if constexpr (K::WI > 0) {
 #pragma unroll
-    for (int i = 0; i < MAXW; ++i) {
-      const int q = tid + i * NT;
-      if (q < n4) ws[i] = src[(q >= n_wg && q < n_wg + n_w1) ? q + n_w1 + n_sm : q];      // (sm sits at the same offset in both)
+      for (int j = 0; j < DI::epk; ++j) wi[j] = pre[j];
+    } else {
+      ddbz_dense_load<NT, F, C, G>(p.w_in, tid, wi);
     }
+    if (tid < FC) pin[tid] = pre[K::N - 1][0];
+    if (tid < FG) pout[tid] = pre[K::N - 1][1];
 #pragma unroll
-    for (int i = 0; i < MAXR; ++i) {
-      const int q = tid + i * NT;
-      if (q < 21 * fg4) {
-        const int k = ddb_blk_of(q, fg4);
-        const float* r = k == 1 ? rp[0] : (k == 2 ? rp[1] : (k == 3 ? rp[2] : (k == 4 ? rp[3] : (k == 5 ? rp[4] : rp[5]))));
-        rv[i] = *(ddb_gf4)(unsigned long long)(r + 4 * (q - fg4 * (k * (k - 1) / 2)));
-      }
-    }
-    if (tid < FC) pin[tid] = vp;
-    if (tid < FG) pout[tid] = vo;
+    for (int i = 0; i < K::MAXW; ++i)
+      if (tid + i * NT < K::n4) reinterpret_cast<ddb_f4*>(wgs)[tid + i * NT] = pre[K::WI + i];
 #pragma unroll
-    for (int i = 0; i < MAXW; ++i)
-      if (tid + i * NT < n4) reinterpret_cast<ddb_f4*>(wgs)[tid + i * NT] = ws[i];
-#pragma unroll
-    for (int i = 0; i < MAXR; ++i)
-      if (tid + i * NT < 21 * fg4) reinterpret_cast<ddb_f4*>(rings)[tid + i * NT] = rv[i];
+    for (int i = 0; i < K::MAXR; ++i)
+      if (tid + i * NT < 21 * fg4) reinterpret_cast<ddb_f4*>(rings)[tid + i * NT] = pre[K::WI + K::MAXW + i];
     DDBZ_T(1);
     ddbz_barrier();
     DDBZ_T(2);

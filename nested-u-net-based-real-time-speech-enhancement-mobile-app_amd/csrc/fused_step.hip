@@ -153,6 +153,13 @@ constexpr int carry_w(int i) {
   if (d.type == T_CONV) return ring_sf(d);
   if (d.type == T_LSTM) return lstm_s0(d) + 10;
   if (d.type == T_CTFA) return ctfa_ni(d) + 2;
+#if FZ_BASE
+  if (d.type == T_DDB) {
+    if (d.x_cols == 64) return DdbzCarry<THREADS, 32, 4>::N;
+    const int F = d.din / d.x_cols;
+    return F == 4 ? DdbzCarry<THREADS, 16, 4>::N : (F == 2 ? DdbzCarry<THREADS, 16, 2>::N : DdbzCarry<THREADS, 16, 1>::N);
+  }
+#endif
   return 0;
 }
 
@@ -309,6 +316,10 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
         w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((BIAS + 4 * tid) * 4));
         w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + tid) * 4));
       }
+#if FZ_BASE
+    } else if constexpr (d.type == T_DDB) {
+      ddbz_prefetch<THREADS, d.x_cols / 2, d.din / d.x_cols>(ddbz_load_rec(cx.ddb + d.bidx), cx.stream, cx.step, tid, w);
+#endif
     } else if constexpr (d.type == T_CTFA) {
       constexpr int NI = ctfa_ni(d);
       const int c4 = tid & 15, rg = tid >> 4;
@@ -757,13 +768,14 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
 //      ddb_device.hpp's workgroup form -- input rows from the state tensor in HBM (the op before drained its stores), history
 //      rings in HBM, output to HBM and, here, straight into the next conv's image.
 template <int I>
-__device__ __forceinline__ void ddb_op(const Ctx& cx, int tid) {
+__device__ __forceinline__ void ddb_op(const Ctx& cx, int tid, Carry<I>& c) {
   constexpr OpD d = kOps[I];
   // (profiling build: the block's own stamps, wave 0, go to the op's phase slots -- loads issued, loads landed, o_0, chain, ring stores, out)
   unsigned long long* dbg = (FZ_PROF && cx.prof) ? reinterpret_cast<unsigned long long*>(lds + (DDB_LDS_B + 72 * 1024) / 4) : nullptr;
   constexpr int G = d.x_cols / 2, F = d.din / d.x_cols;
   static_assert(ddbz_lds_floats<G>(F) * 4 <= 70 * 1024, "dilated-dense scratch over its LDS region");
-  ddb_block_fz<THREADS, G, F>(cx.ddb[d.bidx], cx.stream, cx.step, lds + DDB_LDS_B / 4, tid, dbg, lds + d.y_b / 4, d.x_pitch_b / 4);
+  static_assert(carry_w(I) == DdbzCarry<THREADS, G, F>::N, "carry slots of the dilated-dense op");
+  ddb_block_fz<THREADS, G, F>(ddbz_load_rec(cx.ddb + d.bidx), cx.stream, cx.step, lds + DDB_LDS_B / 4, tid, dbg, lds + d.y_b / 4, d.x_pitch_b / 4, c.w);
   if (FZ_PROF && cx.prof && tid == 0) {
     constexpr int slot[6] = {0, 5, 6, 1, 2, 3};
 #pragma unroll
@@ -895,7 +907,7 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
     lstm_op<I>(cx, tid, c);
 #if FZ_BASE
   } else if constexpr (d.type == T_DDB) {
-    ddb_op<I>(cx, tid);
+    ddb_op<I>(cx, tid, c);
 #endif
   } else {
     ctfa_op<I>(cx, tid, c);
@@ -961,6 +973,15 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.ddb = a.ddb ? a.ddb + a.par * 13 : nullptr;
   cx.stream = stream;
   cx.step = a.ddb ? *a.ddb->step : 0;
+#if FZ_BASE
+  {
+    // one pass over the 13 parameter records of the dilated-dense ops: they stay in the scalar cache for the rest of
+    // the launch (ddbz_load_rec reads them with scalar loads, twice per op)
+    unsigned t;
+    for (int o = 0; o < static_cast<int>(13 * sizeof(DdbParams)); o += 64) asm volatile("s_load_dword %0, %1, %2" : "=s"(t) : "s"(cx.ddb), "s"(o));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+#endif
   Carry<0> c0;
   {
     int tid = threadIdx.x;
