@@ -44,15 +44,21 @@ def synthetic_pool(batch, n, seed):
     return (0.25 * np.abs(rng.standard_normal((n, batch, 256)))).astype(np.float32)
 
 
-def kernel_source_sha16(mode):
+def kernel_source_sha16(mode, variant="lstm"):
     """Identity of the kernel a PMC traffic record belongs to: hash of the sources of the step kernel."""
-    files = {"fused": ["fused_step.hip", "fused_plan.hpp", "fused_plan_lstm.inc", "fused_plan_base.inc", "ddb_device.hpp", "ddb_fused.hpp"],
-             "persistent": ["megakernel.hip", "ddb_device.hpp"]}.get(mode, [])
+    fused = ["fused_step.hip", "fused_plan.hpp", "fused_plan_lstm.inc"]
+    if variant == "baseline":
+        fused = ["fused_step.hip", "fused_base.hip", "fused_plan.hpp", "fused_plan_base.inc", "ddb_device.hpp", "ddb_fused.hpp"]
+    files = {"fused": fused, "persistent": ["megakernel.hip", "ddb_device.hpp"]}.get(mode, [])
     h = hashlib.sha256()
     for f in files:
         with open(os.path.join(PKG, "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16] if files else None
+
+
+def pmc_traffic_path(variant="lstm"):
+    return os.path.join(ROOT, "profiles", "pmc_traffic.json" if variant == "lstm" else "pmc_traffic_%s.json" % variant)
 
 
 def fused_kernel_name(variant):
@@ -330,11 +336,11 @@ def kernel_report(args, eng, pool, out, B, mode):
         avg_ms = ev[0].elapsed_time(ev[1]) / args.steps
         achieved = step_flops / (avg_ms * 1e-3) / 1e12
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        tpath = pmc_traffic_path(args.variant)
         if os.path.exists(tpath):     # HBM bytes per launch from rocprofv3 PMC passes -- only if they were taken on THIS kernel
             t = json.load(open(tpath))
             if (t.get("batch") == B and t.get("mode") == mode and t.get("variant", "lstm") == args.variant
-                    and t.get("kernel_source_sha16") == kernel_source_sha16(mode)):
+                    and t.get("kernel_source_sha16") == kernel_source_sha16(mode, args.variant)):
                 traffic = t["traffic_bytes"]
         rep["roofline"] = {"kernel": fused_kernel_name(args.variant) if mode == "fused" else "nutls_stream_step_kernel", "bound": "mfma",
                            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
