@@ -107,7 +107,7 @@ def bench_offline(args, rank, world, local_rank):
     import torch
     import nunet_amd
     T_ = args.offline
-    off = nunet_amd.NutlsOffline(max_frames=T_, device=local_rank)
+    off = nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, pipeline=args.offline_chunks)
     pool = torch.from_numpy(synthetic_pool(T_, 4, 1234 + rank)).cuda()
     out = torch.empty(T_, 256, device="cuda")
     for s in range(max(2, args.warmup // 8)):
@@ -125,7 +125,8 @@ def bench_offline(args, rank, world, local_rank):
                           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic magnitudes 0.25*|N(0,1)|, trained weights",
                           "config": {"workload": "offline / block mode: ONE utterance, %d consecutive frames per call (SURVEY 8f.2)" % T_,
-                                     "frames_per_block": T_, "mode": "per-layer kernels, frame index as stream index, LSTM scan"},
+                                     "frames_per_block": T_, "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames)",
+                                     "mode": "per-layer kernels, frame index as stream index, single-wavefront LSTM scan, block pipeline"},
                           "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6)}))
     off.close()
 
@@ -187,6 +188,7 @@ def main():
                     help="a step = STFT analysis + model step + inverse STFT/overlap-add of one 256-sample hop per stream, all on the GPU")
     ap.add_argument("--offline", type=int, default=0, metavar="T",
                     help="offline / block mode: ONE utterance, a step = one block of T consecutive frames (frames/s of that utterance)")
+    ap.add_argument("--offline-chunks", type=int, default=0, help="offline mode: chunks of the block pipeline (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default="", help="write the per-op timeline here")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)

@@ -1286,7 +1286,6 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
   int C = e->ochunks;
   if (C == 0) C = n_frames >= 256 ? 2 : 1;
-  if (const char* env = getenv("NUTLS_OFFLINE_CHUNKS")) C = atoi(env);          // debugging aid
   C = std::max(1, std::min({C, static_cast<int>(Engine::kMaxChunks), n_frames}));
   if (C == 1) {
     int rc = launch_block_range(e, 0, e->plan_off.size(), 0, n_frames, true, s);
