@@ -59,3 +59,43 @@ def test_product_path_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_fused_host_entry_points_validate_their_arguments(lib):
+    """The host-only entry points of the fused kernel's plan (no GPU needed) know both variants and nothing else."""
+    assert lib.nutls_fused_num_ops(0) == 154 and lib.nutls_fused_num_ops(1) == 154 and lib.nutls_fused_num_ops(2) == 0
+    assert lib.nutls_fused_blob_floats(0) > 0 and lib.nutls_fused_blob_floats(1) > 0 and lib.nutls_fused_blob_floats(-1) == 0
+    name, fl = ctypes.c_char_p(), ctypes.c_double()
+    assert lib.nutls_fused_op_info(1, 8, ctypes.byref(name), ctypes.byref(fl)) == 0
+    assert name.value == b"msfe6_en_ddb" and fl.value > 0          # the baseline plan's first dilated-dense op
+    assert lib.nutls_fused_op_info(0, 8, ctypes.byref(name), ctypes.byref(fl)) == 0 and name.value == b"msfe6_en_lstm"
+    assert lib.nutls_fused_op_info(0, 154, ctypes.byref(name), ctypes.byref(fl)) == -1
+    assert lib.nutls_fused_op_info(3, 0, ctypes.byref(name), ctypes.byref(fl)) == -1
+    assert lib.nutls_offline_set_pipeline(None, 2) == -1
+    assert lib.nutls_offline_set_ctfa_mode(None, 0) == -1
+
+
+def test_int8_container_round_trip():
+    """`write_blob(..., int8_convs=True)` stores the conv kernels the way the reference's export does (symmetric int8 per
+    output channel, tensors below 1024 elements and the dilated-dense blocks' kernels stay float); `parse_blob` gives
+    back exactly q * scale, and the library's own parser accepts the container."""
+    import numpy as np
+    from nunet_amd.weights import parse_blob, quantize_conv_kernels, synthetic_weights, write_blob
+    w = synthetic_weights("baseline", seed=3, bias_std=0.1, affine_jitter=0.1)
+    q = quantize_conv_kernels(w)
+    blob = write_blob(w, int8_convs=True)
+    back, raw = parse_blob(blob), parse_blob(blob, dequantize=False)
+    assert set(back) == set(w)
+    n_q = 0
+    for name, arr in w.items():
+        if isinstance(q[name], tuple):
+            n_q += 1
+            qi, sc = q[name]
+            assert qi.dtype == np.int8 and sc.shape == (arr.shape[0],) and np.abs(qi).max() <= 127
+            assert np.array_equal(raw[name][0], qi) and np.array_equal(raw[name][1], sc)
+            assert np.array_equal(back[name], qi.astype(np.float32) * sc.reshape(-1, 1, 1, 1))
+            assert np.abs(back[name] - arr).max() <= 0.5 * sc.max() * 1.0001            # half a quantisation step
+        else:
+            assert np.array_equal(back[name], np.asarray(arr, np.float32)), name
+            assert "ddb" in name or not name.endswith(".w") or np.asarray(arr).ndim != 4 or np.asarray(arr).size < 1024
+    assert n_q == 128                                            # every encoder / decoder conv kernel of the network
