@@ -348,6 +348,9 @@ def kernel_report(args, eng, pool, out, B, mode):
                            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "launches_per_step": 1,
                            "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": step_flops}
+        if traffic:      # the same launch against the HBM roofline (the north-star asks for it; the step is MFMA-bound)
+            gbps = traffic / (avg_ms * 1e-3) / 1e9
+            rep["roofline"]["hbm"] = {"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
         # in-kernel timeline of workgroup 0 (wall clock stamps at every op boundary)
         prof = eng.profile_fused if mode == "fused" else eng.profile_persistent
         names = [p["layer"] for p in (eng.fused_plan() if mode == "fused" else plan)]
