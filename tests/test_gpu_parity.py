@@ -402,3 +402,29 @@ def test_baseline_runner_through_the_host_loop(baseline_weights, clip):
     want, _ = SE.real_time_speech_enhancer(audio, oracle_runner)
     assert enh.shape == want.shape and np.isfinite(enh).all()
     assert rms(enh, want) < 1e-4 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("variant", ["lstm", "baseline"])
+def test_fused_timeline_api(variant, request):
+    """`profile_fused` (the profiling build of the fused kernel: workgroup 0 stamps every op boundary) computes the same
+    step as the plain build and returns one positive duration per op of the variant's static schedule."""
+    if variant == "lstm":
+        weights = None
+    else:
+        weights = request.getfixturevalue("baseline_weights")[1]
+    a = NutlsEngine(weights, batch=2, variant=variant)
+    b = NutlsEngine(weights, batch=2, variant=variant)
+    assert a.mode == b.mode == "fused"
+    plan = a.fused_plan()
+    assert len(plan) == 154 and plan[0]["layer"] == "input_layer"
+    assert sum(p["layer"].endswith("_ddb") or p["layer"] == "ddb" for p in plan) == (13 if variant == "baseline" else 0)
+    mags = synthetic_mags(2, 6, seed=3)
+    for s in range(3):
+        a.step(mags[s]); b.step(mags[s])
+    us = b.profile_fused()                      # one more step on b, profiled; its input is what step 2 left in the staging buffer
+    want = a.step(mags[2])
+    assert us.shape == (154,) and (us > 0).all() and us.sum() < 5e4
+    for name in ("msfe6_ee_prev1", "msfe3_dd_prev2"):
+        assert rms(a.state_get(name), b.state_get(name)) < 1e-6, name
+    assert np.isfinite(want).all()
+    a.close(); b.close()
