@@ -1190,7 +1190,7 @@ static int build_offline_plan(Engine* e) {
     e->ogroup.push_back(g);
     if (L.kind == Launch::LSTM) ++g;
   }
-  if (g + 1 > Engine::kGroups) return fail(NUTLS_ERR_ARG, "offline plan: more bottlenecks than pipeline groups");
+  if (g + 2 > Engine::kGroups) return fail(NUTLS_ERR_ARG, "offline plan: more bottlenecks than pipeline groups");      // (the last event of a chunk is its join event)
   for (int c = 0; c < Engine::kMaxChunks; ++c) {
     hipStream_t st = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1297,22 +1297,27 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
     const int n_groups = e->ogroup.back() + 1;
     HIP_TRY(hipEventRecord(e->oev_fork, s));
     for (int c = 0; c < C; ++c) HIP_TRY(hipStreamWaitEvent(e->ostream[c], e->oev_fork, 0));
+    int rc = NUTLS_OK;
     size_t first = 0;
-    for (int g = 0; g < n_groups; ++g) {
+    for (int g = 0; g < n_groups && rc == NUTLS_OK; ++g) {
       size_t last = first;
       while (last < e->plan_off.size() && e->ogroup[last] == g) ++last;
-      for (int c = 0; c < C; ++c) {
+      for (int c = 0; c < C && rc == NUTLS_OK; ++c) {
         const int t0 = c * per, n = std::min(per, n_frames - t0);
         if (n <= 0) continue;
-        if (c > 0) HIP_TRY(hipStreamWaitEvent(e->ostream[c], e->oev[(c - 1) * Engine::kGroups + g], 0));
-        int rc = launch_block_range(e, first, last, t0, n, false, e->ostream[c]);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(e->oev[c * Engine::kGroups + g], e->ostream[c]));
+        if (c > 0 && hipStreamWaitEvent(e->ostream[c], e->oev[(c - 1) * Engine::kGroups + g], 0) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipStreamWaitEvent");
+        if (rc == NUTLS_OK) rc = launch_block_range(e, first, last, t0, n, false, e->ostream[c]);
+        if (rc == NUTLS_OK && hipEventRecord(e->oev[c * Engine::kGroups + g], e->ostream[c]) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipEventRecord");
       }
       first = last;
     }
-    for (int c = 0; c < C; ++c)
-      if (c * per < n_frames) HIP_TRY(hipStreamWaitEvent(s, e->oev[c * Engine::kGroups + n_groups - 1], 0));
+    // join: the caller's stream continues after every chunk stream -- also when a launch failed half way, so that
+    // whatever was enqueued is ordered before the caller's next work
+    for (int c = 0; c < C; ++c) {
+      hipEvent_t done = e->oev[c * Engine::kGroups + Engine::kGroups - 1];
+      if (hipEventRecord(done, e->ostream[c]) == hipSuccess) (void)hipStreamWaitEvent(s, done, 0);
+    }
+    if (rc) return rc;
     if (e->ctfa_causal)
       for (int k = 0; k < 12; ++k) {
         hipError_t err = launch_ctfa_hist_roll(e->ta_hist + static_cast<size_t>(k) * (31 + e->offline) * 64, n_frames, s);

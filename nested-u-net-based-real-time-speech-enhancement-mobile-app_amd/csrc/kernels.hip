@@ -13,6 +13,8 @@
 // registers of lanes l and l+32, so the per-position LayerNorm (over channels) is a register
 // reduction plus ONE cross-lane exchange, and the result leaves as 16-byte channels-last stores.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <cstdlib>
 
 #include "nutls_internal.hpp"
@@ -216,6 +218,8 @@ int conv_pick_nw(ConvKind, int B, int f_out) {
   return (static_cast<long long>(B) * f_out >= 128LL * 512) ? 4 : 1;
 }
 
+constexpr int kMaxDevices = 64;
+
 template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int G>
 static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) {
   const int nw = conv_pick_nw(k, p.B, p.F_out);
@@ -223,21 +227,31 @@ static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) 
   const long long total = static_cast<long long>(p.B) * p.F_out;
   if (nw == 4) {
     auto kern = conv_mfma_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4>;
-    static size_t lds_cap = 64 * 1024;   // raise the dynamic-LDS cap once per instantiation
-    if (lds > lds_cap) {
+    // raise the dynamic-LDS cap once per instantiation AND device (function attributes are per device; handles on
+    // several GPUs share this process-wide cache)
+    static std::atomic<size_t> lds_cap[kMaxDevices] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& cap = lds_cap[dev >= 0 && dev < kMaxDevices ? dev : 0];
+    if (lds > 64 * 1024 && (lds > cap.load(std::memory_order_relaxed) || dev >= kMaxDevices)) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
       if (e != hipSuccess) return e;
-      lds_cap = lds;
+      cap.store(lds, std::memory_order_relaxed);
     }
     const unsigned grid = static_cast<unsigned>((total + 127) / 128);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
   } else {
     auto kern = conv_mfma_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1>;
-    static size_t lds_cap = 64 * 1024;   // raise the dynamic-LDS cap once per instantiation
-    if (lds > lds_cap) {
+    // raise the dynamic-LDS cap once per instantiation AND device (function attributes are per device; handles on
+    // several GPUs share this process-wide cache)
+    static std::atomic<size_t> lds_cap[kMaxDevices] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& cap = lds_cap[dev >= 0 && dev < kMaxDevices ? dev : 0];
+    if (lds > 64 * 1024 && (lds > cap.load(std::memory_order_relaxed) || dev >= kMaxDevices)) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
       if (e != hipSuccess) return e;
-      lds_cap = lds;
+      cap.store(lds, std::memory_order_relaxed);
     }
     const unsigned grid = static_cast<unsigned>((total + 31) / 32);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, p);
