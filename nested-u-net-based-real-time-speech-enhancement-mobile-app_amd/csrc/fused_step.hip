@@ -254,7 +254,7 @@ template <int I>
 __device__ __forceinline__ Task conv_task(int wave) {
   constexpr OpD d = kOps[I];
   Task t;
-  t.active = wave < ntask(d);
+  t.active = ntask(d) >= 8 ? 1 : wave < ntask(d);      // (a compile-time fact where all 8 waves have a task: no branch around their loads)
   if constexpr (d.path == P_X4) {
     t.a = wave & (d.CG - 1); t.b = wave >> clog2(d.CG); t.ks = 0;
     t.wbase_f = wave * (conv_nsf(d) * 256);
@@ -279,43 +279,48 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
     constexpr OpD d = kOps[I];
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (d.type == T_CONV) {
+      // Every load of a prefetch is issued by EVERY thread (indices clamped, no branch around a load): the compiler counts
+      // outstanding loads per control-flow path, and after a branch that holds loads it must assume the path without them --
+      // a later wait for an OLDER load then also drains the ones just issued (seen in the disassembly as `vmcnt(1)` in front
+      // of the first MFMA of a small op: one full memory round trip per op).
       const Task t = conv_task<I>(wave);
-      if (t.active) {
-        // wave-uniform base (SGPR pair) + lane offset (VGPR) + immediate: no 64-bit vector address arithmetic
-        const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
-        sfor<carry_w(I)>([&](auto ff) {
-          constexpr int sf = decltype(ff)::value;
-          w[sf] = ldb(wbase + static_cast<unsigned long long>(sf * 1024), static_cast<unsigned>(lane * 16));
-        });
-      }
-      if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>(tid * 16));
+      // wave-uniform base (SGPR pair) + lane offset (VGPR) + immediate: no 64-bit vector address arithmetic
+      // (a wave without a task fetches the fragments of task wave mod ntask and never uses them)
+      const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
+      sfor<carry_w(I)>([&](auto ff) {
+        constexpr int sf = decltype(ff)::value;
+        w[sf] = ldb(wbase + static_cast<unsigned long long>(sf * 1024), static_cast<unsigned>(lane * 16));
+      });
+      constexpr int NP4 = (nparams(d) + 3) / 4;
+      prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>((tid < NP4 ? tid : NP4 - 1) * 16));
     } else if constexpr (d.type == T_LSTM) {
-      // everything lstm_op needs from memory (slot map there), one op ahead
+      // everything lstm_op needs from memory (slot map there), one op ahead; branch-free (see above): thread (u, sl) loads
+      // the KN weight rows of x slice sl (sl < 16) or the 6 rows + 6 values of h slice sl - 16 (16 <= sl < 20; the rest
+      // re-load slice 19), every thread a Dense row (clamped) and a bias / cell-state element (clamped)
       constexpr int KN = d.din / 16, S0 = lstm_s0(d), WB = d.lw_off, BIAS = WB + (d.din + 24) * 84, WD = BIAS + 84;
+      constexpr int NR = KN > 6 ? KN : 6;
       const int u = tid % 21, sl = tid / 21;
-      if (tid < 336) {
-        sfor<KN>([&](auto jj) {
-          constexpr int j = decltype(jj)::value;
-          w[j] = ldb(cx.wb, static_cast<unsigned>((WB + (sl * KN + j) * 84 + 4 * u) * 4));
-        });
-      } else if (tid < 420) {
-        const int hs = sl - 16;
-        sfor<6>([&](auto jj) {
-          constexpr int j = decltype(jj)::value;
-          w[j] = ldb(cx.wb, static_cast<unsigned>((WB + (d.din + 6 * hs + j) * 84 + 4 * u) * 4));
-          w[S0 + j / 4][j % 4] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + 6 * hs + j) * 4));      // (h[21..23]: slot padding, zero)
-        });
-      }
-      if (tid < d.dout) {
-        sfor<6>([&](auto jj) {
-          constexpr int j = decltype(jj)::value;
-          w[S0 + 2 + j] = ldb(cx.wb, static_cast<unsigned>((WD + tid * 24 + 4 * j) * 4));
-        });
-      }
-      if (tid < 21) {
-        w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((BIAS + 4 * tid) * 4));
-        w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + tid) * 4));
-      }
+      const bool xs = sl < 16;
+      const int hs = sl < 20 ? sl - 16 : 3;
+      const int row0 = xs ? sl * KN : d.din + 6 * hs;
+      sfor<NR>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        const int jr = xs ? (j < KN ? j : KN - 1) : (j < 6 ? j : 5);
+        w[j] = ldb(cx.wb, static_cast<unsigned>((WB + (row0 + jr) * 84 + 4 * u) * 4));
+      });
+      const int h0 = xs ? 0 : 6 * hs;
+      sfor<6>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        w[S0 + j / 4][j % 4] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + h0 + j) * 4));      // (h[21..23]: slot padding, zero)
+      });
+      const int drow = tid < d.dout ? tid : d.dout - 1;
+      sfor<6>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        w[S0 + 2 + j] = ldb(cx.wb, static_cast<unsigned>((WD + drow * 24 + 4 * j) * 4));
+      });
+      const int u21 = tid < 21 ? tid : 20;
+      w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((BIAS + 4 * u21) * 4));
+      w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4));
 #if FZ_BASE
     } else if constexpr (d.type == T_DDB) {
       ddbz_prefetch<THREADS, d.x_cols / 2, d.din / d.x_cols>(ddbz_load_rec(cx.ddb + d.bidx), cx.stream, cx.step, tid, w);

@@ -27,3 +27,18 @@ def reduce_throughput(frames: int, elapsed_s: float, dist=None, device=None) -> 
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(round(f.item())), float(t.item())
+
+
+def collective_proof(rank_rate: float, dist=None, device=None) -> dict:
+    """Evidence that the collective really spanned the job: every rank contributes a 1 to an all-reduce(SUM) (``ranks_reduced``
+    must equal the world size) and its own frames/s to an all-gather (``per_rank`` -- rank order).  ``backend`` is what
+    ``torch.distributed`` runs on ("nccl" is RCCL on ROCm; "gloo" in the CPU tests; "none" for a single process)."""
+    if dist is None:
+        return {"ranks_reduced": 1, "backend": "none", "per_rank": [float(rank_rate)]}
+    import torch
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([float(rank_rate)], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return {"ranks_reduced": int(round(one.item())), "backend": str(dist.get_backend()), "per_rank": [float(x.item()) for x in every]}

@@ -23,13 +23,17 @@ def _free_port():
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import nunet_amd  # noqa: F401
-    from nunet_amd.sharding import reduce_throughput, stream_range
+    from nunet_amd.sharding import collective_proof, reduce_throughput, stream_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = stream_range(2048 + 3, rank, world)
     frames, elapsed = (hi - lo) * 10, 1.0 + rank          # rank 1 is the slow one
     tot, mx = reduce_throughput(frames, elapsed, dist, torch.device("cpu"))
+    proof = collective_proof(frames / elapsed, dist, torch.device("cpu"))
+    assert proof["ranks_reduced"] == world and proof["backend"] == "gloo"
+    assert proof["per_rank"] == [stream_range(2048 + 3, r, world)[1] * 10.0 / (1.0 + r) - stream_range(2048 + 3, r, world)[0] * 10.0 / (1.0 + r)
+                                 for r in range(world)]
     q.put((rank, lo, hi, tot, mx))
     dist.destroy_process_group()
 
@@ -89,3 +93,10 @@ def test_bench_py_rank_plumbing_two_ranks_gloo(launcher):
     assert j["unit"] == "frames/s" and j["value"] > 0
     # whole-job frames / max-over-ranks time (ms_per_step is printed with 4 decimals: allow for its rounding)
     assert abs(j["value"] - 12 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-3 + 6e-5 / j["ms_per_step"]
+    # the line proves its own collective: an all-reduce of ones counted both ranks, over the backend it names, and the
+    # all-gathered per-rank rates are two different measurements
+    col = j["collective"]
+    assert col["ranks_reduced"] == 2 and col["backend"] == "gloo"
+    assert len(col["per_rank_frames_per_s"]) == 2 and all(r > 0 for r in col["per_rank_frames_per_s"])
+    assert col["per_rank_frames_per_s"][0] != col["per_rank_frames_per_s"][1]
+    assert j["short_window"] is True and j["timed_window_ms"] < 100.0          # 5 steps of the stand-in engine
