@@ -37,6 +37,12 @@
 #ifndef FZ_BASE
 #define FZ_BASE 0
 #endif
+// FZ_ABL: timing experiments only (tools/exp): bit mask of parts that are compiled OUT -- the results are garbage, the step time
+// tells what the part costs.  1 halo zeroing, 2 staging (HBM -> image), 4 HBM stores of the row-wise epilogue, 8 MFMA loop of the
+// 4x4x1 path, 16 LayerNorm / PReLU of the row-wise epilogue, 32 LSTM body, 64 CTFA body
+#ifndef FZ_ABL
+#define FZ_ABL 0
+#endif
 
 namespace nutls {
 namespace fz {
@@ -179,7 +185,7 @@ struct Carry {
 // ---- staging: HBM tensor blocks -> registers -> LDS image -------------------------------------------------
 template <int J, int CLS, int NR>
 __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR]) {
-  if constexpr (J >= 0 && J < kNumOps) {
+  if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 2)) {
     constexpr Img g = kOps[J].img;
     sfor<g.nparts>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
@@ -200,7 +206,7 @@ __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR
 }
 template <int J, int CLS, int NR>
 __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
-  if constexpr (J >= 0 && J < kNumOps) {
+  if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 2)) {
     constexpr Img g = kOps[J].img;
     sfor<g.nparts>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
@@ -220,7 +226,7 @@ __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
 }
 template <int J>
 __device__ __forceinline__ void zero_halos(int tid) {
-  if constexpr (J >= 0 && J < kNumOps) {
+  if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 1)) {
     constexpr Img g = kOps[J].img;
     float zf = 0.f;
     asm volatile("" : "+v"(zf));
@@ -386,7 +392,7 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       sfor<KS>([&](auto kk) { v += lds4(eb + decltype(kk)::value * (d.P * OPB)); });
       v = v * wsc + bias;
-      if constexpr (d.ln) {
+      if constexpr (d.ln && !(FZ_ABL & 16)) {
         const float mean = group_sum<LPG>(v[0] + v[1] + v[2] + v[3]) * (1.0f / GC);
         v -= mean;
         const float q = group_sum<LPG>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
@@ -398,8 +404,8 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
         }
       }
       const int row = pos * d.row_mul + d.row_add + r;
-      if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4), v);
-      if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4), v);
+      if constexpr (d.d0_on && !(FZ_ABL & 4)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4), v);
+      if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4), v);
       if constexpr (d.fwd.on) lds4(fwd_addr<I>(row, 16 * li)) = v;
     }
   });
@@ -513,7 +519,7 @@ __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, con
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   pin_regs(c.w);
   FZ_STAMP(I, 5);
-  sfor<NF>([&](auto ff) {
+  sfor<(FZ_ABL & 8) ? 0 : NF>([&](auto ff) {
     constexpr int f = decltype(ff)::value;
     constexpr int s = f / FPS, g = f % FPS, sf = f / 4;
     const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
@@ -909,13 +915,13 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
     else if constexpr (d.path == P_X4) conv_x4<I>(cx, tid, c, p1, p3);
     else conv_r32<I>(cx, tid, c, p1, p3);
   } else if constexpr (d.type == T_LSTM) {
-    lstm_op<I>(cx, tid, c);
+    if constexpr (!(FZ_ABL & 32)) lstm_op<I>(cx, tid, c);
 #if FZ_BASE
   } else if constexpr (d.type == T_DDB) {
     ddb_op<I>(cx, tid, c);
 #endif
   } else {
-    ctfa_op<I>(cx, tid, c);
+    if constexpr (!(FZ_ABL & 64)) ctfa_op<I>(cx, tid, c);
   }
   if constexpr (d.drain) drain_vm();
   lds_barrier();

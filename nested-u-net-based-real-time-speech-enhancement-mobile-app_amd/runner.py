@@ -22,7 +22,8 @@ import numpy as np
 from . import topology as T
 from .weights import DEFAULT_WEIGHTS, read_blob
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnutls_hip.so")
+# NUTLS_LIB: developer knob -- another build of the SAME library (tools/exp: timing experiments on the step kernel)
+_LIB_PATH = os.environ.get("NUTLS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnutls_hip.so")
 _lib = None
 
 NUTLS_ERR_ARG = -1

@@ -99,3 +99,59 @@ def test_int8_container_round_trip():
             assert np.array_equal(back[name], np.asarray(arr, np.float32)), name
             assert "ddb" in name or not name.endswith(".w") or np.asarray(arr).ndim != 4 or np.asarray(arr).size < 1024
     assert n_q == 128                                            # every encoder / decoder conv kernel of the network
+
+
+def test_baseline_tflite_export_rekeys_to_the_container_names():
+    """The 'nutls' export (converter_nunet_tls.py:1538-1552) is not shipped, so the importer is exercised on a constants
+    table built from synthetic baseline weights under the tensor names TF-Lite gives them (Keras layer / conv2d_N / ...,
+    SURVEY A.9): a dilated-dense block is one Sequential with two convs whose biases only differ by the conv2d_N component."""
+    import numpy as np
+    from nunet_amd.weights import synthetic_weights
+    from tools.convert_tflite_weights import rekey
+    from tools.tflite_reader import TensorInfo
+
+    want = synthetic_weights("baseline", seed=11, bias_std=0.1, affine_jitter=0.1)
+    consts, n = {}, [0, 0, 0]
+
+    def add(name, arr):
+        a = np.asarray(arr, np.float32)
+        consts[name] = TensorInfo(len(consts), name, a.shape, np.float32, 0, np.zeros(0, np.float32), np.zeros(0, np.int64), 0, a)
+
+    layers = sorted({k.rsplit(".", 1)[0] for k in want})
+    for L in layers:
+        roles = {k.rsplit(".", 1)[1] for k in want if k.rsplit(".", 1)[0] == L}
+        keras = "conv2d" if L == "out_conv" else L
+        if roles >= {"wg", "w1"}:                       # dilated-dense block: grouped conv, 1x1 conv, LN, PReLU
+            g = want[L + ".w1"].shape[0]
+            for w, b, shape in ((".wg", ".bg", None), (".w1", ".b1", (g, 1, 1, g))):
+                n[0] += 1
+                add("%s/conv2d_%d/Conv2D" % (keras, n[0]), want[L + w] if shape is None else want[L + w].reshape(shape))
+                add("%s/conv2d_%d/BiasAdd/ReadVariableOp" % (keras, n[0]), want[L + b])
+        elif roles >= {"w1", "w2"}:                     # CTFA gate perceptrons
+            for w, b in ((".w1", ".b1"), (".w2", ".b2")):
+                n[0] += 1
+                add("%s/conv1d_%d/Conv1D" % (keras, n[0]), want[L + w])
+                add("%s/conv1d_%d/BiasAdd/ReadVariableOp" % (keras, n[0]), want[L + b])
+        else:
+            n[0] += 1
+            tr = "upsampling" in L
+            add("%s/conv2d_%s%d/%s" % (keras, "transpose_" if tr else "", n[0], "conv2d_transpose" if tr else "Conv2D"), want[L + ".w"])
+            add("%s/conv2d_%s%d/BiasAdd/ReadVariableOp" % (keras, "transpose_" if tr else "", n[0]), want[L + ".b"])
+        if "gamma" in roles:
+            n[1] += 1
+            add("%s/layer_normalization_%d/batchnorm/mul/ReadVariableOp" % (keras, n[1]), want[L + ".gamma"])
+            add("%s/layer_normalization_%d/batchnorm/ReadVariableOp" % (keras, n[1]), want[L + ".beta"])
+            add("%s/layer_normalization_%d/batchnorm/add/y" % (keras, n[1]), np.float32(1e-8))
+        if "alpha" in roles:
+            n[2] += 1
+            add("%s/p_re_lu_%d/Neg/ReadVariableOp" % (keras, n[2]), want[L + ".alpha"])
+
+    class Model:
+        def constants(self):
+            return consts
+
+    got = rekey(Model())
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert np.array_equal(np.asarray(got[k].data).reshape(np.asarray(v).shape), v), k
+    assert got["msfe6_en_ddb_3.w1"].shape == (16, 16) and got["ddb_6.wg"].shape == (32, 2, 3, 6)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Extract the trained NUNet-TLS-LSTM weights from the reference's shipped
-``nutls_lstm.tflite`` into this repo's own weight container (``.nutlsw``).
+"""Extract the trained NUNet-TLS weights from a ``.tflite`` the reference exports -- the shipped
+``nutls_lstm.tflite`` (LSTM bottlenecks) or a ``nutls.tflite`` (dilated-dense baseline,
+``/root/reference/dnn_model/converter_nunet_tls.py:1538-1552``; not shipped, .MISSING_LARGE_BLOBS) --
+into this repo's own weight container (``.nutlsw``).
 
     python tools/convert_tflite_weights.py \
         /root/reference/dnn_model/tflite/nutls_lstm.tflite weights/nutls_lstm.nutlsw
@@ -16,6 +18,9 @@ re-keyed here to ``<layer>.<role>``:
     <P>_ta.w1/.b1/.w2/.b2, <P>_fa.w1/...   CTFA 64->16->64 MLPs
     <P>_lstm.wx [84,Din] / .wh [84,21] / .b [84]      <P>_dense.w [Dout,21] / .b
     out_conv.w [1,1,1,64] / .b
+    baseline only (models/nunet_tls.py:277-359; layer names of its TF-Lite model, :1040-1075 / :1464):
+    <T>_in / <T>_out   .w .b .alpha  (2,3) convs + PReLU, no LayerNorm;  T = <P>_ddb or ddb (central)
+    <T>_<k>, k = 1..6  .wg [G,2,3,k] / .bg  grouped dilated conv,  .w1 [G,G] / .b1  1x1 conv,  .gamma .beta .alpha
 
 Container layout (little-endian):  magic ``NUTLSW01`` | u32 n | n x { u16 name_len, name,
 u8 dtype (0 f32, 1 i8), u8 ndim, u32 dims[ndim], u32 n_scales, f32 scales[n_scales],
@@ -38,9 +43,29 @@ from tools.tflite_reader import TFLiteModel  # noqa: E402
 MAGIC = b"NUTLSW01"
 
 
+DDB_BLOCK = re.compile(r"(^|_)ddb_[1-6]$")
+
+
+class _Reshaped:
+    """A constant under another shape (the 1x1 kernel of a dilated-dense block as a [G, G] matrix)."""
+
+    def __init__(self, t, shape):
+        self.data = np.asarray(t.data).reshape(shape)
+        self.dtype, self.shape = t.dtype, tuple(shape)
+        self.scale, self.zero_point, self.qdim = t.scale, t.zero_point, t.qdim
+
+
 def rekey(model: TFLiteModel) -> "OrderedDict[str, object]":
     out = OrderedDict()
     consts = model.constants()
+    # A dilated-dense block is ONE Keras Sequential with TWO convs (nunet_tls.py:286-350): the grouped dilated (2,3) conv
+    # [G,2,3,k] and the 1x1 conv [G,1,1,G].  Their biases have the same length; what tells them apart is the `conv2d_N`
+    # path component each shares with its kernel.
+    pointwise = {}
+    for name, t in consts.items():
+        parts = name.split("/")
+        if DDB_BLOCK.search(parts[0]) and name.endswith("/Conv2D") and len(parts) == 3 and len(t.shape) == 4:
+            pointwise[(parts[0], parts[1])] = t.shape[1] == 1 and t.shape[2] == 1
     for name in sorted(consts):
         t = consts[name]
         if t.dtype not in (np.int8, np.float32):
@@ -50,7 +75,15 @@ def rekey(model: TFLiteModel) -> "OrderedDict[str, object]":
         key = None
         if "BroadcastTo" in name or name.endswith("/add/y"):
             continue  # all-ones broadcast helpers / LN eps constant
-        if re.search(r"/(Conv2D|Conv1D|conv2d_transpose)$", name) and len(parts) in (2, 3):
+        if DDB_BLOCK.search(layer) and len(parts) >= 3 and (layer, parts[1]) in pointwise:
+            pw = pointwise[(layer, parts[1])]
+            if name.endswith("/Conv2D"):
+                key = layer + (".w1" if pw else ".wg")
+                if pw:
+                    t = _Reshaped(t, (t.shape[0], t.shape[3]))
+            elif name.endswith("BiasAdd/ReadVariableOp"):
+                key = layer + (".b1" if pw else ".bg")
+        elif re.search(r"/(Conv2D|Conv1D|conv2d_transpose)$", name) and len(parts) in (2, 3):
             if layer.endswith(("_ta", "_fa")):
                 key = layer + (".w1" if t.shape[0] == 16 else ".w2")
             else:

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""GPU box: step time of the fused kernel at B = 256 for each experimental build of the library (tools/exp/build_abl.sh).
+    python tools/exp/time_libs.py name1 name2 ...        ("main" = the in-tree library)"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = os.path.join(ROOT, "nested-u-net-based-real-time-speech-enhancement-mobile-app_amd")
+CODE = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import nunet_amd
+B = int(os.environ.get("B", "256"))
+eng = nunet_amd.NutlsEngine(batch=B, mode="fused")
+rng = np.random.default_rng(1234)
+pool = torch.from_numpy((0.25 * np.abs(rng.standard_normal((8, B, 256)))).astype(np.float32)).cuda()
+out = torch.empty(B, 256, device="cuda")
+for s in range(32): eng.step(pool[s %% 8], out)
+torch.cuda.synchronize()
+best = 1e9
+for rep in range(3):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for s in range(200): eng.step(pool[s %% 8], out)
+    ev[1].record(); torch.cuda.synchronize()
+    best = min(best, ev[0].elapsed_time(ev[1]) / 200)
+print("%%-16s %%.4f ms/step" %% (os.environ.get("EXP_NAME"), best))
+if os.environ.get("EXP_TIMELINE"):
+    plan = eng.fused_plan()
+    for _ in range(3): eng.profile_fused()
+    us = np.zeros(len(plan))
+    for _ in range(10): us += eng.profile_fused()
+    import json
+    json.dump({"ops": [{"layer": p["layer"], "us": float(t) / 10} for p, t in zip(plan, us)]}, open(os.environ["EXP_TIMELINE"], "w"))
+eng.close()
+''' % ROOT
+for name in sys.argv[1:]:
+    env = dict(os.environ, EXP_NAME=name)
+    if name != "main":
+        env["NUTLS_LIB"] = os.path.join(PKG, "build", "exp", "libnutls_%s.so" % name)
+    r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=600)
+    sys.stdout.write(r.stdout if r.returncode == 0 else "%-16s FAILED: %s\n" % (name, r.stderr[-400:]))
+    sys.stdout.flush()
