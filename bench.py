@@ -415,7 +415,21 @@ def kernel_report(args, eng, pool, out, B, mode):
     enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
     rep["encoder_conv_stack"] = {"layers": len(enc), "ms_per_step": round(float(enc_ms), 4), "achieved": round(enc_gbs, 1),
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(enc_gbs / PEAK_HBM_GBS, 4),
-                                 "tflops": round(enc_flops / (enc_ms * 1e-3) / 1e12, 2), "concurrent_streams": resident}
+                                 "tflops": round(enc_flops / (enc_ms * 1e-3) / 1e12, 2), "concurrent_streams": resident,
+                                 # what `achieved` is: SURVEY 8(d)'s layer-fused ALGORITHMIC bytes of the 26 layers (fp32 activations in + out
+                                 # per layer, 441 344 B per frame and stream) over the time the stamped profiling build spends in them --
+                                 # an equivalent rate, not measured HBM traffic (the fused kernel keeps the current frame in LDS and the
+                                 # weights int8; the whole step's measured traffic is roofline.traffic)
+                                 "kind": "layer-fused algorithmic bytes / in-kernel timeline of the profiling build (equivalent rate, not PMC traffic)"}
+    if one_launch and mode == "fused":
+        # the stated lower bound of this stack in the one-stream-per-CU design: per layer, its MFMA issue cycles on the 4 SIMDs
+        # of ONE CU at the clock the chip sustains in this kernel (1.9 GHz under MFMA load) plus one
+        # barrier-to-barrier LDS round trip (partials out, row-wise epilogue back in: 2 x ~0.1 us) -- the streams are
+        # independent, so a layer's positions cannot be spread over more than the stream's own CU
+        per_stream = [v["flops"] / B for k, v in by_layer.items() if re.search(r"_en\d?_conv\d$", k)]
+        floor_ms = sum(f / 2.0 / (32.0 * 4.0) / 1.9e9 + 0.2e-6 for f in per_stream) * 1e3
+        rep["encoder_conv_stack"]["floor_ms"] = round(floor_ms, 4)
+        rep["encoder_conv_stack"]["floor"] = "sum over layers of MACs / (32 MAC/clk x 4 SIMDs x 1.9 GHz) + 0.2 us (one exchange round trip between two barriers)"
     if args.profile_json:
         with open(args.profile_json, "w") as f:
             json.dump({"batch": B, "mode": mode, "timeline_step_ms": float(ms.sum()),

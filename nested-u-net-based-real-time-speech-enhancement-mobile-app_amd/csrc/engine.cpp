@@ -98,7 +98,8 @@ struct Engine {
   int B = 0, device = 0;
   int variant = 0;               // NUTLS_VARIANT_LSTM / NUTLS_VARIANT_BASELINE
   long long steps = 0;           // frames processed (ring position of the baseline's dilated-dense history)
-  int* d_step = nullptr;         // the same counter on the device
+  int* d_step = nullptr;         // the same counter on the device (read by the per-layer / plan-interpreter kernels)
+  bool d_step_stale = false;     // fused-mode steps take `steps` by value and leave the device counter behind
   std::vector<DdbParams> ddbs;   // baseline: the 13 dilated-dense blocks (host copy, per parity identical)
   DdbParams* d_ddb = nullptr;
   struct DdbStates { int in, blk[6], out; };
@@ -973,9 +974,18 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof) {
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
   hipError_t err = (base ? launch_fused_base_step : launch_fused_step)(e->arena, static_cast<long long>(e->sstride), e->fz_blob, e->io_in,
                                                                        e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
-                                                                       base ? e->d_ddb : nullptr, e->B, s);
+                                                                       base ? e->d_ddb : nullptr, static_cast<int>(e->steps & 0x3fffffff), e->B, s);
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("fused step launch: ") + hipGetErrorString(err));
-  if (base) HIP_TRY(launch_incr_step(e->d_step, s));   // ring position of the dilated-dense history
+  if (base) e->d_step_stale = true;      // ring position of the dilated-dense history went in by value: one launch per step
+  return NUTLS_OK;
+}
+
+// Before a step of any other mode: bring the device-side frame counter up to date if fused-mode steps ran since.
+static int sync_step_counter(Engine* e, hipStream_t s) {
+  if (e->d_step_stale && e->d_step) {
+    HIP_TRY(launch_set_step(e->d_step, static_cast<int>(e->steps & 0x3fffffff), s));
+    e->d_step_stale = false;
+  }
   return NUTLS_OK;
 }
 
@@ -1397,12 +1407,16 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
     int rc = run_fused(e, par, s, false);
     if (rc) return rc;
   } else if (e->mode == 2) {
-    int rc = run_persistent(e, par, s, false);
+    int rc = sync_step_counter(e, s);
+    if (!rc) rc = run_persistent(e, par, s, false);
     if (rc) return rc;
   } else if (e->mode == 1) {
+    int rc = sync_step_counter(e, s);
+    if (rc) return rc;
     HIP_TRY(hipGraphLaunch(e->gexec[par], s));
   } else {
-    int rc = run_plan(e, par, s);
+    int rc = sync_step_counter(e, s);
+    if (!rc) rc = run_plan(e, par, s);
     if (rc) return rc;
   }
   if (mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
@@ -1701,6 +1715,7 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   HIP_TRY(hipSetDevice(e->device));
   std::vector<hipEvent_t> ev(plan.size() + 1);
   for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+  if (int rc = sync_step_counter(e, e->stream)) return rc;
   HIP_TRY(hipEventRecord(ev[0], e->stream));
   for (size_t i = 0; i < plan.size(); ++i) {
     HIP_TRY(run_launch(plan[i], e->stream));
@@ -1794,7 +1809,8 @@ int nutls_profile_persistent(nutls_handle* h, double* us, int n) {
   const int n_ops = static_cast<int>(e->plan[par].size());
   if (n != n_ops) return fail(NUTLS_ERR_ARG, "nutls_profile_persistent: n must equal nutls_launches_per_step");
   HIP_TRY(hipSetDevice(e->device));
-  int rc = run_persistent(e, par, e->stream, true);
+  int rc = sync_step_counter(e, e->stream);
+  if (!rc) rc = run_persistent(e, par, e->stream, true);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(e->stream));
   std::vector<unsigned long long> t(n_ops + 1);

@@ -39,7 +39,9 @@
 #endif
 // FZ_ABL: timing experiments only (tools/exp): bit mask of parts that are compiled OUT -- the results are garbage, the step time
 // tells what the part costs.  1 halo zeroing, 2 staging (HBM -> image), 4 HBM stores of the row-wise epilogue, 8 MFMA loop of the
-// 4x4x1 path, 16 LayerNorm / PReLU of the row-wise epilogue, 32 LSTM body, 64 CTFA body
+// 4x4x1 path, 16 LayerNorm / PReLU of the row-wise epilogue, 32 LSTM body, 64 CTFA body, 128 workgroup barriers, 256 MFMA loop of
+// the 16x16x4 path, 512 partial-sum reads of the row-wise epilogue, 1024 previous-frame tap segments of the 16x16x4 / 4x4x1 loops,
+// 2048 weight prefetch of the conv ops (MFMAs kept, on garbage)
 #ifndef FZ_ABL
 #define FZ_ABL 0
 #endif
@@ -86,7 +88,11 @@ extern __shared__ __attribute__((aligned(16))) float lds[];
 __device__ __forceinline__ f32x4& lds4(int boff) { return *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + boff); }
 __device__ __forceinline__ float& lds1(int boff) { return *reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + boff); }
 // workgroup barrier that orders LDS traffic only (global loads / stores stay in flight across it)
+#if FZ_ABL & 128
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 __device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <class F, int... Is>
@@ -137,20 +143,27 @@ constexpr int nparams(const OpD& d) { return 2 * ntot(d) + 2 * d.gc + 1; }      
 constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 3) / 4; }             // "super-fragments": 4 int8 fragments = one dwordx4 per lane
 constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), RING_SF); }
 constexpr int part_cls(const Part& p) { return p.round2 ? 3 : p.la; }
-constexpr int part_n(const Part& p) { return (p.rows * p.c4s + THREADS - 1) / THREADS; }
-constexpr int parts_regs(const Img& g, int cls) {
+// Who stages: the parts an op loads AND stores itself (classes 1 and 3) are handled by its "stager" threads -- all 512, or, in the
+// large-layer ops whose tiling leaves waves 4..7 without MFMA work, only those 256: the MFMA waves' weight refills then do not
+// queue behind the staging loads on the (in-order) memory counter, and the staging waves' waits cost the MFMA waves nothing.
+// Class-2 parts (loaded one op before they are stored) stay with all threads: both ops must agree on who holds what.
+constexpr int stg_threads(int i) {
+  return (i >= 0 && i < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32 && kOps[i].PG * kOps[i].CG == 4) ? 256 : THREADS;
+}
+constexpr int part_n(const Part& p, int nthr) { return (p.rows * p.c4s + nthr - 1) / nthr; }
+constexpr int parts_regs(const Img& g, int cls, int nthr) {
   int n = 0;
-  for (int k = 0; k < g.nparts; ++k) if (part_cls(g.parts[k]) == cls) n += part_n(g.parts[k]);
+  for (int k = 0; k < g.nparts; ++k) if (part_cls(g.parts[k]) == cls) n += part_n(g.parts[k], nthr);
   return n;
 }
-constexpr int part_base(const Img& g, int cls, int k) {
+constexpr int part_base(const Img& g, int cls, int k, int nthr) {
   int n = 0;
-  for (int kk = 0; kk < k; ++kk) if (part_cls(g.parts[kk]) == cls) n += part_n(g.parts[kk]);
+  for (int kk = 0; kk < k; ++kk) if (part_cls(g.parts[kk]) == cls) n += part_n(g.parts[kk], nthr);
   return n;
 }
 constexpr int nxt_of(int i) { return (i >= 0 && i < kNumOps) ? kOps[i].nxt : -1; }
-constexpr int nxt_regs(int i, int cls) { return nxt_of(i) >= 0 ? parts_regs(kOps[nxt_of(i)].img, cls) : 0; }
-constexpr int own_regs(int i, int cls) { return (i < kNumOps && kOps[i].type == T_CONV) ? parts_regs(kOps[i].img, cls) : 0; }
+constexpr int nxt_regs(int i, int cls) { return nxt_of(i) >= 0 ? parts_regs(kOps[nxt_of(i)].img, cls, cls == 1 ? stg_threads(i) : THREADS) : 0; }
+constexpr int own_regs(int i, int cls) { return (i < kNumOps && kOps[i].type == T_CONV) ? parts_regs(kOps[i].img, cls, stg_threads(i)) : 0; }
 constexpr int ctfa_ni(const OpD& d) { return (d.F + 31) / 32; }
 constexpr int lstm_s0(const OpD& d) { return cmax(d.din / 16, 6); }      // carry slots of the gate weights (see lstm_op)
 constexpr int carry_w(int i) {
@@ -169,6 +182,16 @@ constexpr int carry_w(int i) {
   return 0;
 }
 
+// Large-layer ops with a few more weight fragments than the carried ring holds: the rest is requested at the very start of the
+// op, ahead of its staging loads, and the MFMA loop runs without refills (a refill would be YOUNGER than the staging loads on
+// the in-order memory counter: waiting for it means waiting for the whole staging burst -- seen as `vmcnt(0)` in mid-loop).
+constexpr int EXT_MAX = 5;
+constexpr int ext_sf(int i) {
+  if (i < 0 || i >= kNumOps || kOps[i].type != T_CONV || kOps[i].path != P_R32) return 0;
+  const int extra = conv_nsf(kOps[i]) - ring_sf(kOps[i]);
+  return (extra > 0 && extra <= EXT_MAX) ? extra : 0;
+}
+
 // What travels in registers from op I-1 to op I: the first weight fragments of op I (or the LSTM's input
 // weights / the CTFA's residual rows and gate matrices) and the far-ahead staged parts of the image op I completes.
 template <int I>
@@ -183,7 +206,8 @@ struct Carry {
 };
 
 // ---- staging: HBM tensor blocks -> registers -> LDS image -------------------------------------------------
-template <int J, int CLS, int NR>
+// (tid: index among the NTHR staging threads)
+template <int J, int CLS, int NTHR, int NR>
 __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR]) {
   if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 2)) {
     constexpr Img g = kOps[J].img;
@@ -191,12 +215,12 @@ __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR
       constexpr int K = decltype(kk)::value;
       constexpr Part p = g.parts[K];
       if constexpr (part_cls(p) == CLS) {
-        constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K), cs = clog2(p.c4s);
+        constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s);
         const gcb_t src = p.src == S_PREV ? cx.sbp : (p.src == S_CUR ? cx.sbc : cx.sbs);
-        sfor<part_n(p)>([&](auto ii) {
+        sfor<part_n(p, NTHR)>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
-          int q = tid + THREADS * i;
-          if ((i + 1) * THREADS > items) q = q < items ? q : items - 1;      // lanes past the end re-load the last item
+          int q = tid + NTHR * i;
+          if ((i + 1) * NTHR > items) q = q < items ? q : items - 1;      // lanes past the end re-load the last item
           const int row = q >> cs, c4 = q & (p.c4s - 1);
           r[base + i] = ldb(src, static_cast<unsigned>(p.off * 4 + row * (p.ld * 4) + c4 * 16));
         });
@@ -204,7 +228,7 @@ __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR
     });
   }
 }
-template <int J, int CLS, int NR>
+template <int J, int CLS, int NTHR, int NR>
 __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
   if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 2)) {
     constexpr Img g = kOps[J].img;
@@ -212,13 +236,13 @@ __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
       constexpr int K = decltype(kk)::value;
       constexpr Part p = g.parts[K];
       if constexpr (part_cls(p) == CLS) {
-        constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K), cs = clog2(p.c4s);
-        sfor<part_n(p)>([&](auto ii) {
+        constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s);
+        sfor<part_n(p, NTHR)>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
-          const int q = tid + THREADS * i;
+          const int q = tid + NTHR * i;
           const int row = q >> cs, c4 = q & (p.c4s - 1);
           const int a = p.lds_b + img_row_rt(g.pitch_b, g.pair, g.half_b, p.row0 + row) + c4 * 16;
-          if ((i + 1) * THREADS <= items || FZ_LIKELY(q < items)) lds4(a) = r[base + i];
+          if ((i + 1) * NTHR <= items || FZ_LIKELY(q < items)) lds4(a) = r[base + i];
         });
       }
     });
@@ -233,7 +257,7 @@ __device__ __forceinline__ void zero_halos(int tid) {
     const f32x4 z = {zf, zf, zf, zf};
     sfor<g.nzero>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
-      constexpr int t0 = K * 32;                    // (a halo row is at most 32 float4)
+      constexpr int t0 = THREADS - 128 + K * 32;    // (a halo row is at most 32 float4; waves 6 and 7: never the wave that runs a small op's epilogue)
       if (FZ_LIKELY(static_cast<unsigned>(tid - t0) < static_cast<unsigned>(g.zero[K].n4))) lds4(g.zero[K].lds_b + (tid - t0) * 16) = z;
     });
   }
@@ -293,10 +317,14 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
       // wave-uniform base (SGPR pair) + lane offset (VGPR) + immediate: no 64-bit vector address arithmetic
       // (a wave without a task fetches the fragments of task wave mod ntask and never uses them)
       const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
-      sfor<carry_w(I)>([&](auto ff) {
+      sfor<(FZ_ABL & 2048) ? 0 : carry_w(I)>([&](auto ff) {
         constexpr int sf = decltype(ff)::value;
         w[sf] = ldb(wbase + static_cast<unsigned long long>(sf * 1024), static_cast<unsigned>(lane * 16));
       });
+      if constexpr ((FZ_ABL & 2048) != 0) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) asm volatile("" : "=v"(w[k]));      // (undefined contents, but "defined" for the optimiser)
+      }
       constexpr int NP4 = (nparams(d) + 3) / 4;
       prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>((tid < NP4 ? tid : NP4 - 1) * 16));
     } else if constexpr (d.type == T_LSTM) {
@@ -348,13 +376,41 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
   }
 }
 
+template <int I, int NX>
+__device__ __forceinline__ void ext_load(const Ctx& cx, int tid, f32x4 (&wx)[NX]) {
+  if constexpr (ext_sf(I) > 0) {
+    constexpr OpD d = kOps[I];
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Task t = conv_task<I>(wave);
+    const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
+    sfor<ext_sf(I)>([&](auto ff) {
+      constexpr int sf = carry_w(I) + decltype(ff)::value;
+      wx[decltype(ff)::value] = ldb(wbase + static_cast<unsigned long long>(sf * 1024), static_cast<unsigned>(lane * 16));
+    });
+  }
+}
+
 // ---- completing the next image: staged parts + halos (between the two barriers of op I) --------------------------
 template <int I, int N1, int N2>
 __device__ __forceinline__ void build_next(int tid, const f32x4 (&p1)[N1], const f32x4 (&p2)[N2]) {
-  constexpr int J = nxt_of(I);
-  stage_store<J, 1>(tid, p1);
-  stage_store<J, 2>(tid, p2);
+  constexpr int J = nxt_of(I), ST = stg_threads(I);
+  if constexpr (ST == THREADS) {
+    stage_store<J, 1, THREADS>(tid, p1);
+  } else {
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= (THREADS - ST) / 64) stage_store<J, 1, ST>(tid - (THREADS - ST), p1);
+  }
+  stage_store<J, 2, THREADS>(tid, p2);
   zero_halos<J>(tid);
+}
+// the second-round part of an op's own two-round image (between the two barriers in the middle of the op)
+template <int I, int N3>
+__device__ __forceinline__ void store_round2(int tid, const f32x4 (&p3)[N3]) {
+  constexpr int ST = stg_threads(I);
+  if constexpr (ST == THREADS) {
+    stage_store<I, 3, THREADS>(tid, p3);
+  } else {
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= (THREADS - ST) / 64) stage_store<I, 3, ST>(tid - (THREADS - ST), p3);
+  }
 }
 
 // LDS address of (output row `row`, channel byte offset cb) inside the forward target of op d
@@ -390,7 +446,7 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
       const int pos = u >> clog2(R);
       const int eb = d.ex_b + pos * OPB + (r * GC + 4 * li) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      sfor<KS>([&](auto kk) { v += lds4(eb + decltype(kk)::value * (d.P * OPB)); });
+      sfor<(FZ_ABL & 512) ? 1 : KS>([&](auto kk) { v += lds4(eb + decltype(kk)::value * (d.P * OPB)); });
       v = v * wsc + bias;
       if constexpr (d.ln && !(FZ_ABL & 16)) {
         const float mean = group_sum<LPG>(v[0] + v[1] + v[2] + v[3]) * (1.0f / GC);
@@ -438,11 +494,12 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
     if (t.active) {
-      sfor<hi - lo>([&](auto ff) {
+      sfor<(FZ_ABL & 256) ? 0 : hi - lo>([&](auto ff) {
         constexpr int f = lo + decltype(ff)::value;
         constexpr int s = f / GW, g = f % GW;
         constexpr int sf = f / 4;
         const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
+        if ((FZ_ABL & 1024) && d.KSt == 2 && ks_t == 0) return;
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
           const f32x4 b = lds4(lane_b[pt] + d.seg_b[s] + g * 64);
@@ -462,7 +519,7 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
   if constexpr (d.rounds == 2) {
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{});
     lds_barrier();
-    stage_store<I, 3>(tid, p3);
+    store_round2<I>(tid, p3);
     lds_barrier();
     half(std::integral_constant<int, NF / 2>{}, std::integral_constant<int, NF>{});
   } else {
@@ -523,6 +580,7 @@ __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, con
     constexpr int f = decltype(ff)::value;
     constexpr int s = f / FPS, g = f % FPS, sf = f / 4;
     const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
+    if ((FZ_ABL & 1024) && d.KSt == 2 && ks_t == 0) return;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const f32x4 bq = lds4(lane_b[pt] + d.seg_b[s] + g * 16);
@@ -553,11 +611,11 @@ __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, con
 // ---- conv op, large layers: 32x32x2 tiles, whole LayerNorm groups per wave, epilogue in registers ----------------------
 __device__ __forceinline__ float xor32_sum(float s) { return s + __shfl_xor(s, 32); }
 
-template <int I, int N1, int N3>
-__device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
+template <int I, int N1, int N3, int NX>
+__device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3], f32x4 (&wx)[NX]) {
   constexpr OpD d = kOps[I];
   constexpr bool UP = is_up(d);
-  constexpr int PT = d.PT, NT = d.NT, G = kgroups(d), NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d);
+  constexpr int PT = d.PT, NT = d.NT, G = kgroups(d), NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d), EXT = ext_sf(I);
   constexpr int NA = UP ? 2 : NT;                    // accumulator tiles per position tile (UP: even row, odd row)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Task t = conv_task<I>(wave);
@@ -574,7 +632,7 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
       for (int e = 0; e < 16; ++e) acc[pt][n][e] = 0.f;
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
-  if (t.active) pin_regs(c.w);
+  if (t.active) { pin_regs(c.w); if constexpr (EXT > 0) pin_regs(wx); }
   FZ_STAMP(I, 5);
   f32x4 b[PT];
   auto half = [&](auto lo_, auto hi_) {
@@ -589,12 +647,13 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
           for (int pt = 0; pt < PT; ++pt) b[pt] = lds4(lane_b[pt] + d.seg_b[s] + g * 32);
         }
         constexpr int sf = f / 4;
-        const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
+        const f32x4& wsf = (EXT > 0 && sf >= CW) ? wx[(EXT > 0 && sf >= CW) ? sf - CW : 0] : c.w[sf % CW];
+        const float a[4] = {wq(wsf, f % 4, 0), wq(wsf, f % 4, 1), wq(wsf, f % 4, 2), wq(wsf, f % 4, 3)};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) acc[pt][na] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[pt][q], acc[pt][na], 0, 0, 0);
-        if constexpr ((f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
+        if constexpr (EXT == 0 && (f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
           c.w[sf % CW] = ldb(wbase + static_cast<unsigned long long>((sf + CW) * 1024), lane16);
           sched_pin();
         }
@@ -604,7 +663,7 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
   if constexpr (d.rounds == 2) {
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{});
     lds_barrier();
-    stage_store<I, 3>(tid, p3);
+    store_round2<I>(tid, p3);
     lds_barrier();
     half(std::integral_constant<int, NF / 2>{}, std::integral_constant<int, NF>{});
   } else {
@@ -894,12 +953,27 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));          // per-op thread id: nothing derived from it is hoisted across ops
   if (PROF && cx.prof && tid == 0) cx.prof[I] = wall_clock64();
+  // Drain point of an LSTM / CTFA op: every wave waits for its own earlier HBM stores BEFORE it issues this op's loads (a
+  // wait at the end of the op would also wait for those loads -- a full HBM round trip per drain point); the op's own
+  // barriers then order the completed stores before every load a later op issues (the planner's hand-off rule).
+  constexpr bool DRAIN_FIRST = d.drain && (d.type == T_LSTM || d.type == T_CTFA);
+  if constexpr (DRAIN_FIRST) drain_vm();
   // loads in the order they are needed: parts this op stores itself, its epilogue parameters, what the next op needs first
   f32x4 p1[cmax(1, nxt_regs(I, 1))];
   f32x4 p3[cmax(1, own_regs(I, 3))];
-  stage_load<nxt_of(I), 1>(cx, tid, p1);
-  stage_load<I, 3>(cx, tid, p3);
-  stage_load<nxt_of(I + 1), 2>(cx, tid, n.p);
+  f32x4 wx[cmax(1, ext_sf(I))];
+  ext_load<I>(cx, tid, wx);             // (before the staging loads: a wait for these must not wait for those)
+  constexpr int ST = stg_threads(I);
+  if constexpr (ST == THREADS) {
+    stage_load<nxt_of(I), 1, THREADS>(cx, tid, p1);
+    stage_load<I, 3, THREADS>(cx, tid, p3);
+  } else {
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= (THREADS - ST) / 64) {
+      stage_load<nxt_of(I), 1, ST>(cx, tid - (THREADS - ST), p1);
+      stage_load<I, 3, ST>(cx, tid - (THREADS - ST), p3);
+    }
+  }
+  stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
 #pragma unroll
   for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
   n.prm = c.prm2;
@@ -913,7 +987,7 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
   } else if constexpr (d.type == T_CONV) {
     if constexpr (d.path == P_X16) conv_x16<I>(cx, tid, c, p1, p3);
     else if constexpr (d.path == P_X4) conv_x4<I>(cx, tid, c, p1, p3);
-    else conv_r32<I>(cx, tid, c, p1, p3);
+    else conv_r32<I>(cx, tid, c, p1, p3, wx);
   } else if constexpr (d.type == T_LSTM) {
     if constexpr (!(FZ_ABL & 32)) lstm_op<I>(cx, tid, c);
 #if FZ_BASE
@@ -923,7 +997,7 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
   } else {
     if constexpr (!(FZ_ABL & 64)) ctfa_op<I>(cx, tid, c);
   }
-  if constexpr (d.drain) drain_vm();
+  if constexpr (d.drain && !DRAIN_FIRST) drain_vm();
   lds_barrier();
 }
 
@@ -939,6 +1013,7 @@ __device__ __forceinline__ void run_from(const Ctx& cx, Carry<I>& c) {
 struct FzArgs {
   float* arena; long long sstride; const float* blob; const float* io_in; float* io_out; int B, par; unsigned long long* prof;
   const DdbParams* ddb;      // baseline variant: table [2 parities][13] (engine.cpp push_ddb), else null
+  int step;                  // baseline variant: frames processed so far (position in the dilated-dense history rings)
 };
 
 #ifndef FZ_PROF
@@ -983,7 +1058,7 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
   cx.ddb = a.ddb ? a.ddb + a.par * 13 : nullptr;
   cx.stream = stream;
-  cx.step = a.ddb ? *a.ddb->step : 0;
+  cx.step = a.step;
 #if FZ_BASE
   {
     // one pass over the 13 parameter records of the dilated-dense ops: they stay in the scalar cache for the rest of
@@ -1006,8 +1081,8 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
 
 #if FZ_PROF
 hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                     unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s) {
-  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, prof, ddb};
+                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s) {
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, prof, ddb, step};
   hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
   return hipGetLastError();
 }
@@ -1016,12 +1091,12 @@ hipError_t FZ_ATTR() {
 }
 #else
 hipError_t FZ_LAUNCH_PROF(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                          unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s);
+                          unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
 hipError_t FZ_ATTR_PROF();
 hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                     unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s) {
-  if (prof) return FZ_LAUNCH_PROF(arena, sstride, blob, io_in, io_out, B, par, prof, ddb, grid, s);
-  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr, ddb};
+                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s) {
+  if (prof) return FZ_LAUNCH_PROF(arena, sstride, blob, io_in, io_out, B, par, prof, ddb, step, grid, s);
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr, ddb, step};
   hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
   return hipGetLastError();
 }

@@ -591,4 +591,11 @@ hipError_t launch_incr_step(int* step, hipStream_t s) {
   return hipGetLastError();
 }
 
+__global__ void set_step_kernel(int* step, int value) { *step = value; }
+
+hipError_t launch_set_step(int* step, int value, hipStream_t s) {
+  hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, s, step, value);
+  return hipGetLastError();
+}
+
 }  // namespace nutls

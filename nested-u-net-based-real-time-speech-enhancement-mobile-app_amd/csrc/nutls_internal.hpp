@@ -111,6 +111,7 @@ struct DdbParams {
 };
 hipError_t launch_ddb(const DdbParams& p, hipStream_t s);
 hipError_t launch_incr_step(int* step, hipStream_t s);
+hipError_t launch_set_step(int* step, int value, hipStream_t s);   // after fused-mode steps (which take the counter by value)
 
 struct CtfaParams {
   const float* x; int x_ld;      // d_D  [B,F,64]
@@ -251,11 +252,12 @@ void apply_s16_plan(ConvPlan* c, const ConvParams& p);
 
 // ------------------------------------------------------------------ fused (statically scheduled) kernel ----
 // fused_step.hip (LSTM variant) / fused_base.hip (baseline variant) / fused_host.cpp: the frame step as one specialised
-// instruction stream per op.  `prof` non-null selects the profiling build; `ddb` is the baseline's block table (else null).
+// instruction stream per op.  `prof` non-null selects the profiling build; `ddb` is the baseline's block table (else null);
+// `step` = frames processed so far (ring position of the baseline's dilated-dense histories), by value: ONE launch per step.
 hipError_t launch_fused_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                             unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s);
+                             unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
 hipError_t launch_fused_base_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                                  unsigned long long* prof, const DdbParams* ddb, int grid, hipStream_t s);
+                                  unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
 hipError_t fused_step_set_attributes();
 hipError_t fused_base_step_set_attributes();
 bool fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err);

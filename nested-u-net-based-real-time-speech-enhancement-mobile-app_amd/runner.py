@@ -343,11 +343,12 @@ class NutlsRunner:
     """``runner(input=..., msfe6_ee_prev1=..., ..., msfe6_de_c=...) -> dict`` exactly like the
     reference's ``nutls_lstm_sm`` signature runner (interpreter_proposed.py:215-350), batch 1.
 
-    The caller owns the state arrays, as in the reference.  When it echoes back the very
-    arrays this runner returned last frame (what the reference loop does) the upload is
-    skipped, because the device already holds them; the returned arrays are READ-ONLY views of one
-    buffer, so a caller that wants to patch a state (zero h/c to reset a stream, ...) has to make a
-    copy -- a new object -- which is uploaded like any foreign array."""
+    The caller owns the state arrays, as in the reference, and gets fresh WRITABLE arrays back every
+    frame (TF-Lite's signature runner does the same).  When it echoes back the very arrays this
+    runner returned last frame, unchanged (what the reference loop does), the upload is skipped
+    because the device already holds them: "unchanged" is checked against a private snapshot of
+    what was handed out, so an in-place edit (zero h / c to reset a stream, ...) is noticed and
+    uploaded like any foreign array."""
 
     signature_key = "nutls_lstm_sm"
 
@@ -359,6 +360,7 @@ class NutlsRunner:
         self._in_names = T.input_names(variant)
         self._specs = T.state_specs(variant)
         self._last: Dict[str, np.ndarray] = {}
+        self._snap: Dict[str, np.ndarray] = {}       # what the device holds, per output name (private, never handed out)
 
     @staticmethod
     def _io_shape(shp):
@@ -387,16 +389,19 @@ class NutlsRunner:
             want = self._io_shape(shp)
             if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.shape != want:
                 raise ValueError("%s must be float32 %s" % (k_in, want))
-            if self._last.get(k_out) is not a:      # not the echo of our own output: upload
-                eng.state_set(k_in, a)
+            # the echo of our own output, not edited since: the device already holds it
+            if self._last.get(k_out) is a and np.array_equal(a.reshape(-1), self._snap[k_out]):
+                continue
+            eng.state_set(k_in, a)
         out = eng.step(x.reshape(1, T.N_BINS))
         res = {"model_out": out.reshape(1, 1, T.N_BINS, 1)}
-        flat = eng.state_get_all(0)                 # one D2H copy for the 130 / 208 tensors
-        flat.flags.writeable = False                # in-place edits of an echoed array would go unnoticed: forbid them
+        snap = eng.state_get_all(0)                 # one D2H copy for the 130 / 208 tensors
+        pub = snap.copy()                           # the caller's arrays: writable, independent of the snapshot
         o = 0
         for base, shp in self._specs:
             n = int(np.prod(shp))
-            res[base.format("cur")] = flat[o:o + n].reshape(self._io_shape(shp))
+            res[base.format("cur")] = pub[o:o + n].reshape(self._io_shape(shp))
+            self._snap[base.format("cur")] = snap[o:o + n]
             o += n
         self._last = res
         return res

@@ -453,6 +453,15 @@ def build(variant="lstm"):
             issue = builder[o["idx"]] - (p["la"] - 1)
             assert any(ops[k]["drain"] for k in range(prod[0], issue)), (o["name"], p, prod, issue)
             p["producer"] = prod[0]
+    # The same rule for what the kernel's weight / operand prefetch reads from THIS frame's state: a CTFA's residual rows e0
+    # (fused_step.hip prefetch_w, issued TWO ops ahead of the CTFA) were written by the stage's in-conv earlier in the frame.
+    for o in ops:
+        if o["type"] != T_CTFA:
+            continue
+        prod = [q["idx"] for q in ops for d in (q["d0"], q["d1"]) if d and d[0] == S_CUR and d[1] == o["e0_off"] and d[2] == o["e0_ld"]]
+        assert len(prod) == 1, (o["name"], "producer of the residual rows")
+        issue = o["idx"] - 2
+        assert any(ops[k]["drain"] for k in range(prod[0], issue)), (o["name"], "no drain point between", prod[0], "and the prefetch in", issue)
     return A, W, ops
 
 
