@@ -242,7 +242,7 @@ __device__ __forceinline__ void ddb_block_wg(const DdbParams& p, int stream, flo
   const int F = p.F, C = p.C, G = C >> 1;
   const int FG = F * G, FC = F * C, G7 = 7 * G;
   int lg = 0;
-  while ((1 << lg) < G) ++lg;                // G = 16 or 32, C = 2G, F = 4
+  while ((1 << lg) < G) ++lg;                // G = 16 or 32, C = 2G, F = 1, 2 or 4 (run-time here; compile time in ddb_fused.hpp)
   float* xs = lds;                    // [F][C]    current input
   float* pin = xs + FC;               // [F][C]    previous input
   float* pout = pin + FC;             // [F][G]    previous o_6

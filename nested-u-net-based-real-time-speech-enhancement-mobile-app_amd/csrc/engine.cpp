@@ -140,8 +140,9 @@ struct Engine {
   std::vector<int> ogroup;              // launch index of plan_off -> group (a group ends with an LSTM)
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
   int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel (plan interpreter),
-                         // 3 fused kernel (statically scheduled, LSTM variant only)
+                         // 3 fused kernel (statically scheduled; both variants)
   float* fz_blob = nullptr;              // weight blob of the fused kernel (plan order)
+  std::string fz_reason;                 // why there is none (what the packer said), for nutls_set_mode(3)
   unsigned long long* fz_prof = nullptr; // op boundary stamps of workgroup 0 (profiling build)
   CompactOp* dplan[2] = {nullptr, nullptr};
   unsigned long long* dprof = nullptr;
@@ -950,10 +951,12 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   if (!ok) return fail(NUTLS_ERR_ARG, "fused plan (tools/gen_fused_plan.py) does not match the engine's arena layout");
   std::vector<float> blob;
   std::string err;
-  if (!fused_pack_blob(v, wm, &blob, &err)) {
-    // a container with float conv kernels (no int8 payload): fine, it runs on the plan-interpreter kernel (mode 2)
-    if (err.find("not an int8 tensor") != std::string::npos) return NUTLS_OK;
-    return fail(NUTLS_ERR_WEIGHTS, err);
+  if (fused_pack_blob(v, wm, &blob, &err) != FZ_PACK_OK) {
+    // Not packable for the fused kernel -- float conv kernels (no int8 payload), only some of them int8, a scale count that
+    // does not match ... -- is not an error of the handle: modes 0-2 only need the de-quantised floats, the default becomes
+    // the plan-interpreter kernel (mode 2), and nutls_set_mode(3) reports the reason kept here.
+    e->fz_reason = err;
+    return NUTLS_OK;
   }
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, blob.size() * sizeof(float)));
@@ -1201,17 +1204,7 @@ static int build_offline_plan(Engine* e) {
     if (L.kind == Launch::LSTM) ++g;
   }
   if (g + 2 > Engine::kGroups) return fail(NUTLS_ERR_ARG, "offline plan: more bottlenecks than pipeline groups");      // (the last event of a chunk is its join event)
-  for (int c = 0; c < Engine::kMaxChunks; ++c) {
-    hipStream_t st = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    e->ostream.push_back(st);
-    for (int k = 0; k < Engine::kGroups; ++k) {
-      hipEvent_t ev = nullptr;
-      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      e->oev.push_back(ev);
-    }
-  }
-  HIP_TRY(hipEventCreateWithFlags(&e->oev_fork, hipEventDisableTiming));
+  // (the chunk streams and their events are created when a block first runs with that many chunks: ensure_chunk_streams)
   int rc = dev_alloc(e, static_cast<size_t>(e->offline) * 84, &e->zx, true);
   if (rc) return rc;
   return dev_alloc(e, static_cast<size_t>(12) * (31 + e->offline) * 64, &e->ta_hist, true);
@@ -1274,10 +1267,27 @@ static int launch_block_range(Engine* e, size_t first, size_t last, int t0, int 
   return NUTLS_OK;
 }
 
+// Streams + events of the block pipeline for `chunks` chunks, created on first use (a handle that never pipelines owns none).
+static int ensure_chunk_streams(Engine* e, int chunks) {
+  if (!e->oev_fork) HIP_TRY(hipEventCreateWithFlags(&e->oev_fork, hipEventDisableTiming));
+  while (static_cast<int>(e->ostream.size()) < chunks) {
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    e->ostream.push_back(st);
+    for (int k = 0; k < Engine::kGroups; ++k) {
+      hipEvent_t ev = nullptr;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      e->oev.push_back(ev);
+    }
+  }
+  return NUTLS_OK;
+}
+
 int nutls_offline_set_ctfa_mode(nutls_handle* h, int mode) {
   if (!h || !h->eng.offline) return fail(NUTLS_ERR_ARG, "nutls_offline_set_ctfa_mode: not an offline handle");
   if (mode != NUTLS_CTFA_FRAME && mode != NUTLS_CTFA_CAUSAL32) return fail(NUTLS_ERR_ARG, "nutls_offline_set_ctfa_mode: unknown mode");
   Engine* e = &h->eng;
+  if (e->ctfa_causal == (mode == NUTLS_CTFA_CAUSAL32)) return NUTLS_OK;      // already in effect: the history stays
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(e->ta_hist, 0, static_cast<size_t>(12) * (31 + e->offline) * 64 * sizeof(float)));      // a mode switch starts a new history
@@ -1305,6 +1315,7 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
     // the previous-frame taps of all its layers, the LSTM's h / c and the time-attention history of frame t0-1 exist
     const int per = (n_frames + C - 1) / C;
     const int n_groups = e->ogroup.back() + 1;
+    if (int rc0 = ensure_chunk_streams(e, C)) return rc0;
     HIP_TRY(hipEventRecord(e->oev_fork, s));
     for (int c = 0; c < C; ++c) HIP_TRY(hipStreamWaitEvent(e->ostream[c], e->oev_fork, 0));
     int rc = NUTLS_OK;
@@ -1387,7 +1398,9 @@ int nutls_use_graph(nutls_handle* h, int enable) {
 
 int nutls_set_mode(nutls_handle* h, int mode) {
   if (!h || mode < 0 || mode > 3) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode must be 0, 1, 2 or 3");
-  if (mode == 3 && !h->eng.fz_blob) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 3 (fused kernel) needs a streaming handle made from a container with int8 conv kernels");
+  if (mode == 3 && !h->eng.fz_blob)
+    return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 3 (fused kernel) needs a streaming handle made from a container with int8 conv kernels" +
+                                   (h->eng.fz_reason.empty() ? std::string() : " (" + h->eng.fz_reason + ")"));
   if (h->eng.offline && mode != 0) return fail(NUTLS_ERR_ARG, "nutls_set_mode: offline handles run per-layer launches (mode 0)");
   if (mode == 1) return nutls_use_graph(h, 1);
   h->eng.mode = mode;
@@ -1568,15 +1581,26 @@ int nutls_state_get_all(nutls_handle* h, int stream_idx, float* host_buf, size_t
   if (n_floats != total) return fail(NUTLS_ERR_ARG, "nutls_state_get_all: expected " + std::to_string(total) + " floats");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  // the stream's slice of the arena up to the end of the state slots (both parities + rings), then pick the tensors out of it
-  size_t span = 0;
-  for (const StateTensor& st : e->states)
-    for (int b = 0; b < 2; ++b) span = std::max(span, static_cast<size_t>(st.buf[b] - e->arena) + st.per_stream());
+  // Only what is asked for crosses the bus: the buffers of the `prev`-side parity are one contiguous block of the stream's
+  // arena slice (allocate_states), the baseline's history rings a second one -- one copy per run of adjacent buffers, then
+  // the tensors are picked out of the host image.
+  auto want = [&](const StateTensor& st) { return static_cast<size_t>((e->offline ? st.buf[0] : st.buf[1 - e->next_parity]) - e->arena); };
+  std::vector<std::pair<size_t, size_t>> runs;      // [begin, end) offsets inside the slice, sorted and merged
+  for (const StateTensor& st : e->states) runs.emplace_back(want(st), want(st) + st.per_stream());
+  std::sort(runs.begin(), runs.end());
+  size_t span = 0, n_runs = 0;
+  for (const auto& r : runs) {
+    if (n_runs && r.first <= runs[n_runs - 1].second + 1024) runs[n_runs - 1].second = std::max(runs[n_runs - 1].second, r.second);   // (slot padding between neighbours)
+    else runs[n_runs++] = r;
+    span = std::max(span, r.second);
+  }
+  runs.resize(n_runs);
   std::vector<float> slice(span);
-  HIP_TRY(hipMemcpy(slice.data(), e->arena + e->sstride * stream_idx, span * sizeof(float), hipMemcpyDeviceToHost));
+  for (const auto& r : runs)
+    HIP_TRY(hipMemcpy(slice.data() + r.first, e->arena + e->sstride * stream_idx + r.first, (r.second - r.first) * sizeof(float), hipMemcpyDeviceToHost));
   size_t o = 0;
   for (const StateTensor& st : e->states) {
-    const float* src = slice.data() + ((e->offline ? st.buf[0] : st.buf[1 - e->next_parity]) - e->arena);
+    const float* src = slice.data() + want(st);
     std::memcpy(host_buf + o, src, st.per_stream() * sizeof(float));
     if (st.ring_d > 1) {      // physical ring order -> the reference's oldest-first order
       const size_t frame = st.per_stream() / st.ring_d;
@@ -1746,7 +1770,7 @@ int nutls_fused_pack_blob(const void* weights, size_t n_bytes, int variant, floa
   std::vector<float> blob;
   try {
     if (!parse_weight_blob(weights, n_bytes, &wm, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
-    if (!fused_pack_blob(variant, wm, &blob, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
+    if (fused_pack_blob(variant, wm, &blob, &err) != FZ_PACK_OK) return fail(NUTLS_ERR_WEIGHTS, err);
   } catch (const std::exception& ex) {
     return fail(NUTLS_ERR_WEIGHTS, std::string("weight container: ") + ex.what());
   }

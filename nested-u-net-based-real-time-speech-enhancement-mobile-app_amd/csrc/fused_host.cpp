@@ -51,7 +51,7 @@ int fused_state_off(int variant, int i) { return FZ_BY_VARIANT(fused_state_off(i
 int fused_num_scratch(int variant) { return FZ_BY_VARIANT(fused_num_scratch()); }
 const char* fused_scratch_name(int variant, int i) { return FZ_BY_VARIANT(fused_scratch_name(i)); }
 int fused_scratch_off(int variant, int i) { return FZ_BY_VARIANT(fused_scratch_off(i)); }
-bool fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err) {
+int fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err) {
   return FZ_BY_VARIANT(fused_pack_blob(wm, out, err));
 }
 

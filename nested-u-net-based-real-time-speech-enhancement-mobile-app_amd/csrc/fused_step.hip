@@ -553,7 +553,7 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
 template <int I, int N1, int N3>
 __device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
   constexpr OpD d = kOps[I];
-  constexpr int PT = d.PT, VH = d.N < 64 ? 2 : 1, KSc = d.KSg, CPS = d.cin / KSc, FPS = CPS / 4, SEGW = d.nseg / d.KSt;
+  constexpr int PT = d.PT, VH = d.N < 64 ? 2 : 1, KSc = d.KSg, CPS = d.cin / KSc, FPS = CPS / 4;
   constexpr int NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d), OPB = (NTOT + 4) * 4;
   static_assert(d.rounds == 1 && !is_up(d), "X4 path: single-round, not the up-sampling layer");
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

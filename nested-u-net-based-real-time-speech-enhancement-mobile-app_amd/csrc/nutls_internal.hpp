@@ -260,7 +260,8 @@ hipError_t launch_fused_base_step(float* arena, long long sstride, const float* 
                                   unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
 hipError_t fused_step_set_attributes();
 hipError_t fused_base_step_set_attributes();
-bool fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err);
+enum FusedPack : int { FZ_PACK_OK = 0, FZ_PACK_NOT_INT8 = 1, FZ_PACK_MALFORMED = 2 };
+int fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err);      // -> FusedPack
 int fused_blob_floats(int variant);
 int fused_num_ops(int variant);
 const char* fused_op_name(int variant, int i);

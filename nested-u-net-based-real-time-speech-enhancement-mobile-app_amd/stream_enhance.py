@@ -74,66 +74,72 @@ def feeds_from_outputs(prev_out: Dict[str, np.ndarray], sliced_mag: np.ndarray, 
     return feeds
 
 
+def hop_frames(noisy_speech: np.ndarray) -> np.ndarray:
+    """The loop's analysis buffers, all at once: frame ``i`` = hop ``i - 1`` (zeros for the first) followed by hop ``i``
+    -- what the reference's shifting ``in_buffer`` holds at step ``i`` (interpreter_proposed.py:203-205).  ``[n, 512]``
+    float32 view-copy; ``n = (len - 256) // 256`` (:32)."""
+    audio = np.asarray(noisy_speech, np.float32)
+    n = (audio.shape[0] - (FRAME_LEN - FRAME_STEP)) // FRAME_STEP
+    padded = np.concatenate([np.zeros(FRAME_LEN - FRAME_STEP, np.float32), audio[:n * FRAME_STEP]])
+    if n <= 0:
+        return np.zeros((0, FRAME_LEN), np.float32)
+    return np.lib.stride_tricks.sliding_window_view(padded, FRAME_LEN)[::FRAME_STEP][:n]
+
+
 def frame_magnitudes(noisy_speech: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """All analysis frames of the loop at once: (|X| [n,257], angle [n,257]), float64 like
-    ``np.fft.rfft`` of the float32 windowed buffer (interpreter_proposed.py:203-210)."""
-    audio = np.asarray(noisy_speech)
-    num_blocks = (audio.shape[0] - (FRAME_LEN - FRAME_STEP)) // FRAME_STEP
-    win = analysis_window()
-    in_buffer = np.zeros((FRAME_LEN,), np.float32)
-    mags = np.zeros((num_blocks, FRAME_LEN // 2 + 1))
-    phases = np.zeros((num_blocks, FRAME_LEN // 2 + 1))
-    for idx in range(num_blocks):
-        in_buffer[:-FRAME_STEP] = in_buffer[FRAME_STEP:]
-        in_buffer[-FRAME_STEP:] = audio[idx * FRAME_STEP:(idx + 1) * FRAME_STEP]
-        spec = np.fft.rfft(in_buffer * win)
-        mags[idx], phases[idx] = np.abs(spec), np.angle(spec)
-    return mags, phases
+    """(|X| [n,257], angle [n,257]) of every analysis frame: float32 windowed buffer, float64 transform like
+    ``np.fft.rfft`` in the reference loop (interpreter_proposed.py:206-210)."""
+    spec = np.fft.rfft(hop_frames(noisy_speech) * analysis_window(), axis=-1)
+    return np.abs(spec), np.angle(spec)
+
+
+def overlap_add(blocks: np.ndarray, total: int) -> np.ndarray:
+    """Synthesis blocks ``[n, 512]`` (float32, already inverse-windowed) -> the loop's ``out_file`` of ``total`` samples:
+    output hop ``i`` = first half of block ``i`` + second half of block ``i - 1``, summed in float32 as the reference's
+    ``out_buffer`` does (interpreter_proposed.py:359-365)."""
+    n = blocks.shape[0]
+    out = np.zeros((total,))
+    if n:
+        seg = blocks[:, :FRAME_STEP].copy()
+        seg[1:] += blocks[:-1, FRAME_STEP:]
+        out[:n * FRAME_STEP] = seg.reshape(-1)
+    return out
 
 
 def real_time_speech_enhancer(noisy_speech: np.ndarray, runner: Callable[..., Dict[str, np.ndarray]],
                               dc_mode: str = "edge", variant: str = None) -> Tuple[np.ndarray, List[float]]:
-    """Frame-by-frame enhancement of one utterance; returns (waveform, per-frame seconds).
+    """Frame-by-frame enhancement of one utterance; returns (waveform, seconds spent per frame in the model call and the
+    frame's synthesis).  Same function as the reference's loop (interpreter_proposed.py:15-370), organised around the one
+    thing that has to be sequential -- the model call, whose state feeds the next frame: analysis of all frames up front
+    (:func:`frame_magnitudes`), per frame the runner call + inverse transform, overlap-add at the end (:func:`overlap_add`).
 
     ``variant``: which signature the runner implements -- ``"lstm"`` ('nutls_lstm_sm', interpreter_proposed.py:380)
     or ``"baseline"`` ('nutls', interpreter_nunet_tls.py:549); default: what the runner says (``signature_key``).
 
     ``dc_mode``: how bin 0 is re-created after the 256-bin model: ``"edge"`` (the PC loop,
-    interpreter_proposed.py:352-353) or ``"zero"`` (the phone,
-    mobile_app/.../RTSE_NUTLS_LSTM.java:677)."""
-    audio = np.asarray(noisy_speech)
-    win, inv_win = analysis_window(), inverse_window()
-    in_buffer = np.zeros((FRAME_LEN,), np.float32)
-    out_buffer = np.zeros((FRAME_LEN,), np.float32)
-    num_blocks = (audio.shape[0] - (FRAME_LEN - FRAME_STEP)) // FRAME_STEP
-    out_file = np.zeros((len(audio) + (FRAME_LEN - FRAME_STEP)))
-    time_array: List[float] = []
+    interpreter_proposed.py:352-353: bin 0 = bin 1) or ``"zero"`` (the phone, mobile_app/.../RTSE_NUTLS_LSTM.java:677)."""
+    if dc_mode not in ("edge", "zero"):
+        raise ValueError("dc_mode must be 'edge' or 'zero'")
     if variant is None:
         variant = "baseline" if getattr(runner, "signature_key", "nutls_lstm_sm") == "nutls" else "lstm"
-    model_out = zero_state(variant)
-    for idx in range(num_blocks):
+    audio = np.asarray(noisy_speech)
+    mags, phases = frame_magnitudes(audio)
+    rotors = np.exp(1j * phases)
+    inv_win = inverse_window()
+    blocks = np.zeros((mags.shape[0], FRAME_LEN), np.float32)
+    seconds: List[float] = []
+    outputs = zero_state(variant)
+    for i in range(mags.shape[0]):
         t0 = time.time()
-        in_buffer[:-FRAME_STEP] = in_buffer[FRAME_STEP:]
-        in_buffer[-FRAME_STEP:] = audio[idx * FRAME_STEP:(idx + 1) * FRAME_STEP]
-        spec = np.fft.rfft(in_buffer * win)
-        in_mag, in_phase = np.abs(spec), np.angle(spec)
-        sliced_mag = np.reshape(in_mag, (1, 1, -1, 1)).astype(np.float32)[:, :, 1:]
-        model_out = runner(**feeds_from_outputs(model_out, sliced_mag, variant))
-        est = model_out["model_out"]
-        if dc_mode == "edge":
-            est_mag = np.pad(est, ((0, 0), (0, 0), (1, 0), (0, 0)), mode="edge")
-        elif dc_mode == "zero":
-            est_mag = np.pad(est, ((0, 0), (0, 0), (1, 0), (0, 0)))
-        else:
-            raise ValueError("dc_mode must be 'edge' or 'zero'")
-        est_mag = np.squeeze(est_mag)
-        block = np.fft.irfft(est_mag * np.exp(1j * in_phase)).astype(np.float32) * inv_win
-        out_buffer[:-FRAME_STEP] = out_buffer[FRAME_STEP:]
-        out_buffer[-FRAME_STEP:] = 0
-        out_buffer += block
-        out_file[idx * FRAME_STEP:(idx + 1) * FRAME_STEP] = out_buffer[:FRAME_STEP]
-        time_array.append(time.time() - t0)
-    return out_file[FRAME_LEN - FRAME_STEP:], time_array
+        model_in = mags[i, 1:].astype(np.float32).reshape(1, 1, T.N_BINS, 1)
+        outputs = runner(**feeds_from_outputs(outputs, model_in, variant))
+        est = np.empty(FRAME_LEN // 2 + 1)
+        est[1:] = outputs["model_out"].reshape(-1)
+        est[0] = est[1] if dc_mode == "edge" else 0.0
+        blocks[i] = np.fft.irfft(est * rotors[i]).astype(np.float32) * inv_win
+        seconds.append(time.time() - t0)
+    total = len(audio) + (FRAME_LEN - FRAME_STEP)
+    return overlap_add(blocks, total)[FRAME_LEN - FRAME_STEP:], seconds
 
 
 def enhance_batch_on_device(noisy: np.ndarray, engine, dc_mode: str = "edge") -> np.ndarray:

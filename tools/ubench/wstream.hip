@@ -71,7 +71,7 @@ int main() {
     const double us = mx * 1000.0 / khz;
     printf("%-44s blob %5.1f MB: %8.1f us/pass  -> %6.1f GB/s per CU\n", name, bytes / 1048576.0, us, bytes / us / 1e3);
   };
-  for (size_t bytes : {size_t(2) << 20, size_t(3) << 20, size_t(6) << 20, size_t(11) << 20 + (1 << 19)}) {
+  for (size_t bytes : {size_t(2) << 20, size_t(3) << 20, size_t(6) << 20, (size_t(11) << 20) + (size_t(1) << 19)}) {
     const int nf = bytes / 1024;
     for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(wlat, dim3(256), dim3(512), 0, 0, w, nf, out, cyc);
     hipDeviceSynchronize();
