@@ -191,11 +191,12 @@ __device__ __forceinline__ void ddbz_prefetch(const DdbzRec& p, int stream, int 
   if (tid < FG) pre[K::N - 1][1] = (p.st_out + soff)[tid];
 }
 
-// lds: ddbz_lds_floats<G>(F) floats of scratch.  lds_y: the next image's rows (pitch lds_pitch floats): channels [0, 2G)
-// receive the block's output, channels [2G, 4G) hold its input.  `step`: the frame counter (ring position).
-template <int NT, int G, int F>
+// lds: ddbz_lds_floats<G>(F) floats of scratch.  xs: the block's input rows as fp32 in LDS (pitch lds_pitch floats; written by
+// the conv op before, visible after a barrier); put_y(row, float4 index, value): the block's output into the next conv's image
+// (whatever its format).  `step`: the frame counter (ring position).
+template <int NT, int G, int F, class PutY>
 __device__ __forceinline__ void ddb_block_fz(const DdbzRec& p, int stream, int step, float* lds, int tid, unsigned long long* dbg_lds,
-                                             float* lds_y, int lds_pitch, const ddb_f4 (&pre)[DdbzCarry<NT, G, F>::N]) {
+                                             const float* xs, int lds_pitch, PutY&& put_y, const ddb_f4 (&pre)[DdbzCarry<NT, G, F>::N]) {
 #define DDBZ_T(k) do { if (dbg_lds && (tid & 63) == 0) dbg_lds[(tid >> 6) * 16 + (k)] = wall_clock64(); } while (0)
   static_assert((G == 16 || G == 32) && (F == 1 || F == 2 || F == 4) && NT >= 512 && NT % 64 == 0, "unsupported block shape");
   constexpr int C = 2 * G, FG = F * G, FC = F * C, G7 = 7 * G, lg = ddbz_log2(G), fg4 = FG / 4;
@@ -208,7 +209,6 @@ __device__ __forceinline__ void ddb_block_fz(const DdbzRec& p, int stream, int s
   float* w1r = wgs + 126 * G;         // [6][G out][G] pre-rotated rows of the 1x1 kernels
   float* sm = w1r + 6 * G * G;        // [6][4][G] bg, b1, gamma, beta | b_in [G] | b_out [C]
   float* part = sm + 27 * G;          // K-split partial sums (<= 2048 floats)
-  const float* xs = lds_y + C;        // current input rows, pitch lds_pitch
   const size_t soff = static_cast<size_t>(stream) * p.sstride;
   float* const pst_in = p.st_in + soff;
   float* const pst_out = p.st_out + soff;
@@ -347,7 +347,7 @@ __device__ __forceinline__ void ddb_block_fz(const DdbzRec& p, int stream, int s
 #pragma unroll
       for (int j = 0; j < 4; ++j) r[j] = ddb_prelu(s[j] + sm[25 * G + 4 * cq + j], a_out);
       *reinterpret_cast<ddb_f4*>(pdst + fo * dst_ld + 4 * cq) = r;
-      *reinterpret_cast<ddb_f4*>(lds_y + fo * lds_pitch + 4 * cq) = r;
+      put_y(fo, cq, r);
     }
   }
   DDBZ_T(5);

@@ -12,20 +12,24 @@ namespace fz {
 
 enum OpType : int { T_INPUT = 0, T_CONV = 1, T_LSTM = 2, T_CTFA = 3, T_DDB = 4 };
 enum CKind : int { K_IN = 0, K_EL = 1, K_DL = 2, K_DOWN = 3, K_UP = 4 };
-enum Path : int { P_R32 = 0, P_X16 = 1, P_X4 = 2 };
+// P_R32: 32x32x2 fp32 MFMA tiles on an fp32 image (the layers whose image does not fit LDS as three bf16 planes);
+// P_R32B / P_X16B: 32x32x16 / 16x16x32 bf16 MFMA tiles on a three-plane bf16 image (x = hi + mid + lo exactly, see fused_step.hip)
+enum Path : int { P_R32 = 0, P_R32B = 3, P_X16B = 4 };
 enum Src : int { S_PREV = 0, S_CUR = 1, S_SCRATCH = 2 };   // HBM base a float offset is relative to
 
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int SCR_BYTES = 8192;                      // LSTM / CTFA scratch at the top of LDS
 constexpr int SCR_B = LDS_BYTES - SCR_BYTES;
-constexpr int MAX_PARTS = 4, MAX_ZERO = 4, MAX_SEG = 6;
-constexpr int RING_SF = 3;                           // weight ring of a wave: 3 x (dwordx4 per lane = 4 int8 MFMA fragments), first fill by the previous op
+constexpr int MAX_PARTS = 4, MAX_ZERO = 12, MAX_SEG = 6;
+constexpr int RING_SF_R32 = 6;                       // ... of the large layers (their K steps are 5x shorter than the fp32 MFMA's were)
+constexpr int XCOPY_B = SCR_B + 7168;                // fp32 copy of the rows an LSTM / dilated-dense op reads (<= 256 floats), written by the conv op before it
+constexpr int RING_SF = 3;                           // weight ring of a wave: 3 x (dwordx4 per lane = 16 int8 weights: 4 fp32-MFMA or 2 bf16-MFMA fragments), first fill by the previous op
 
 // A rectangular block of an HBM tensor that is copied into an LDS image through registers.
 struct Part {
   int src, off, ld;      // HBM: base selector, float offset of (row 0, first channel), floats between rows
   int rows, c4s;         // block size: rows x (c4s float4)
-  int lds_b;             // LDS byte address of image row 0 at the block's first channel
+  int lds_b;             // LDS byte address of image row 0 at the block's first channel (three-plane images: in the hi plane)
   int row0;              // image row of block row 0
   int la;                // 1: loads issued by the op that builds the image, 2: one op earlier
   int round2;            // belongs to the second round of a two-round image
@@ -33,15 +37,18 @@ struct Part {
 struct Zero { int lds_b, n4; };   // halo: n4 float4 of zeros
 
 // LDS image (B operand of the MFMAs) of a conv op: rows x channels per time tap, padded pitch.
-//   address(lr, c) = tap * tap_b + (pair ? (lr >> 1) * pitch_b + (lr & 1) * half_b : lr * pitch_b) + 4 c
+//   fmt 0 (fp32):            address(lr, c)    = tap * tap_b + row(lr) + 4 c
+//   fmt 1 (3 bf16 planes):   address(lr, c, p) = tap * tap_b + row(lr) + p * plane_b + 2 c      p = 0 hi, 1 mid, 2 lo
+//   row(lr) = pair ? (lr >> 1) * pitch_b + (lr & 1) * half_b : lr * pitch_b
 struct Img {
+  int fmt, plane_b;
   int taps, tap_b, pitch_b, pair, half_b, row0, bytes;
   int nparts; Part parts[MAX_PARTS];
   int nzero; Zero zero[MAX_ZERO];
 };
 
 // Where an op's output rows go inside the LDS image of the op that consumes them next.
-struct Fwd { int on, base_b, pitch_b, pair, half_b, row0; };
+struct Fwd { int on, base_b, pitch_b, pair, half_b, row0, fmt, plane_b; };
 
 struct OpD {
   int type;
@@ -60,6 +67,7 @@ struct OpD {
   int nxt;                                 // op whose image this op completes (forward + staging), -1: none
   // ---- lstm ------------------------------------------------------------------------------------
   int din, dout, x_b, x_pitch_b, x_cols, y_b, h_off, c_off, ldst_on, ldst_off, ldst_ld;
+  int x_fmt, x_plane_b;                    // format of the image the op works in place on (Img::fmt / plane_b)
   int lw_off;                              // wxT | whT | bias | wdT | bd
   // ---- ctfa ------------------------------------------------------------------------------------
   int F, e0_off, e0_ld, last, cw_off;      // operates in place on fwd-described rows; cw: ta(w1T,b1,w2,b2) | fa(...)

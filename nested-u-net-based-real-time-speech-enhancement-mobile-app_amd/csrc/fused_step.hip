@@ -8,19 +8,27 @@
 // Reference semantics: TFL_SIGNITURE.nutls_lstm, dnn_model/converter_proposed.py:188-867; blocks
 // dnn_model/models/proposed.py:162-282.
 //
+// Arithmetic of the convs: fp32 results on the bf16 matrix pipe.  The weights are int8 (exact in bf16); every fp32
+// activation is split ERROR-FREE into three bf16 pieces, x = hi + mid + lo (hi = the top 16 bits of x, mid = the top 16
+// bits of x - hi, lo = the rest: 8 + 8 + 8 significand bits), so a conv is three bf16 MFMAs per tile and K step whose
+// products w * piece are exact in fp32 and are accumulated in fp32 -- the same quantity an fp32 FMA chain rounds, with
+// fewer roundings (tools/ubench/bf16x3.hip: 2.2e-7 relative rms against 3.7e-7 for v_mfma_f32_32x32x2_f32), at 16/3
+// of the rate of the fp32 MFMA.  Everything else (scale, bias, LayerNorm, PReLU, LSTM, CTFA) is fp32 on the VALU.
+//
 // Data flow of a conv op I (inconv / strided conv / sub-pixel conv / down / up, proposed.py:198-265):
-//   * its B operand is an LDS image [time tap][row][channel] with zero halo rows; the op BEFORE it completes
-//     that image: the rows it produces go there straight from registers, everything else (previous-frame
-//     tap = the other parity of the state tensor in HBM, skip-connection channels) is loaded from HBM into
-//     registers one or two ops ahead and stored into the image between the two barriers of the op before;
-//   * its A operand (weights, MFMA fragment order, one blob in plan order) streams from L2 through a
-//     12-fragment register ring whose first fill is issued by the previous op;
-//   * large layers: 32x32x2 fp32 MFMA tiles, each wave owns whole LayerNorm groups, epilogue in registers;
-//     small layers (<= 64 positions): 16x16x4 tiles, K split over the waves, partial tiles meet in an LDS
+//   * its B operand is an LDS image [time tap][row][plane hi | mid | lo][channel] of bf16 with zero halo rows (the two
+//     largest images stay fp32 and are split when they are read); the op BEFORE it completes that image: the rows it
+//     produces go there straight from registers (split in its epilogue), everything else (previous-frame tap = the other
+//     parity of the state tensor in HBM, skip-connection channels) is loaded from HBM into registers one or two ops
+//     ahead and split + stored into the image between the two barriers of the op before;
+//   * its A operand (int8 weights in MFMA fragment order, one blob in plan order) streams from L2 through a register
+//     ring whose first fill is issued two ops ahead, converted to bf16 pairs in the MFMA shadow;
+//   * large layers: 32x32x16 bf16 MFMA tiles, each wave owns whole LayerNorm groups, epilogue in registers;
+//     small layers (<= 64 positions): 16x16x32 tiles, K split over the waves, partial tiles meet in an LDS
 //     exchange buffer and a row-wise epilogue finishes them (LayerNorm over channels with DPP exchanges);
-//   * the epilogue writes the state tensor (HBM, `cur` parity) and the next image (LDS).
-// Barriers order LDS only; the memory counter is never drained except at the plan's drain points (after
-// every LSTM and CTFA), which is what makes same-frame HBM hand-offs of skip connections safe.
+//   * the epilogue writes the state tensor (HBM, `cur` parity, fp32) and the next image (LDS).
+// Barriers order LDS only; the memory counter is never drained except at the plan's drain points (at every LSTM and
+// CTFA), which is what makes same-frame HBM hand-offs of skip connections safe.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -38,10 +46,9 @@
 #define FZ_BASE 0
 #endif
 // FZ_ABL: timing experiments only (tools/exp): bit mask of parts that are compiled OUT -- the results are garbage, the step time
-// tells what the part costs.  1 halo zeroing, 2 staging (HBM -> image), 4 HBM stores of the row-wise epilogue, 8 MFMA loop of the
-// 4x4x1 path, 16 LayerNorm / PReLU of the row-wise epilogue, 32 LSTM body, 64 CTFA body, 128 workgroup barriers, 256 MFMA loop of
-// the 16x16x4 path, 512 partial-sum reads of the row-wise epilogue, 1024 previous-frame tap segments of the 16x16x4 / 4x4x1 loops,
-// 2048 weight prefetch of the conv ops (MFMAs kept, on garbage)
+// tells what the part costs.  1 halo zeroing, 2 staging (HBM -> image), 4 HBM stores of the row-wise epilogue, 16 LayerNorm / PReLU
+// of the row-wise epilogue, 32 LSTM body, 64 CTFA body, 128 workgroup barriers, 256 MFMA loops of the 16x16x32 path, 512 partial-sum
+// reads of the row-wise epilogue, 2048 weight prefetch of the conv ops (MFMAs kept, on garbage), 4096 MFMA loops of the 32x32x16 path
 #ifndef FZ_ABL
 #define FZ_ABL 0
 #endif
@@ -57,6 +64,9 @@ namespace fz {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef const char __attribute__((address_space(1))) * gcb_t;
 typedef char __attribute__((address_space(1))) * gb_t;
 typedef const f32x4 __attribute__((address_space(1))) * gc4_t;
@@ -87,6 +97,8 @@ __device__ __forceinline__ void stb1(gcb_t base, unsigned boff, float v) { *(gf_
 extern __shared__ __attribute__((aligned(16))) float lds[];
 __device__ __forceinline__ f32x4& lds4(int boff) { return *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + boff); }
 __device__ __forceinline__ float& lds1(int boff) { return *reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + boff); }
+__device__ __forceinline__ u32x2& lds2u(int boff) { return *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(lds) + boff); }
+__device__ __forceinline__ unsigned short& lds_h(int boff) { return *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(lds) + boff); }
 // workgroup barrier that orders LDS traffic only (global loads / stores stay in flight across it)
 #if FZ_ABL & 128
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -128,27 +140,95 @@ __device__ __forceinline__ float group_sum(float s) {      // sum over LPG conse
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
+// ---- error-free split of fp32 into three bf16 pieces, and the image accessors built on it -------------------------------
+// x = hi + mid + lo exactly: hi = the top 16 bits of x (a bf16: 8 significand bits), mid = the top 16 bits of the exact
+// remainder x - hi (<= 16 significand bits), lo = what is left (<= 8 bits, so its fp32 pattern has 16 zero low bits).
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bitsf(unsigned b) { return __builtin_bit_cast(float, b); }
+// dword of two bf16: low half = the top 16 bits of a, high half = the top 16 bits of b  (v_perm_b32)
+__device__ __forceinline__ unsigned pk_top16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ void split3(float x, unsigned& xb, unsigned& rb, unsigned& lb) {
+  xb = fbits(x);
+  const float r = x - bitsf(xb & 0xffff0000u);
+  rb = fbits(r);
+  lb = fbits(r - bitsf(rb & 0xffff0000u));
+}
+struct Pieces4 { u32x2 hi, mid, lo; };       // 4 consecutive channels as 4 bf16 per plane
+__device__ __forceinline__ Pieces4 split4(const f32x4& v) {
+  unsigned xb[4], rb[4], lb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const float x = v[e]; split3(x, xb[e], rb[e], lb[e]); }
+  Pieces4 o;
+  o.hi = u32x2{pk_top16(xb[0], xb[1]), pk_top16(xb[2], xb[3])};
+  o.mid = u32x2{pk_top16(rb[0], rb[1]), pk_top16(rb[2], rb[3])};
+  o.lo = u32x2{pk_top16(lb[0], lb[1]), pk_top16(lb[2], lb[3])};
+  return o;
+}
+__device__ __forceinline__ float join3(unsigned h16, unsigned m16, unsigned l16) {      // pieces in the TOP halves of the arguments
+  return (bitsf(h16) + bitsf(m16)) + bitsf(l16);      // (exact: 16 bits, then 24 bits)
+}
+// Image accessors: `a` = LDS byte address of (row, first channel) -- in the hi plane of a three-plane image (FMT 1)
+template <int FMT>
+__device__ __forceinline__ void img_st4(int a, int plane_b, const f32x4& v) {
+  if constexpr (FMT == 0) {
+    lds4(a) = v;
+  } else {
+    const Pieces4 q = split4(v);
+    lds2u(a) = q.hi;
+    lds2u(a + plane_b) = q.mid;
+    lds2u(a + 2 * plane_b) = q.lo;
+  }
+}
+template <int FMT>
+__device__ __forceinline__ f32x4 img_ld4(int a, int plane_b) {
+  if constexpr (FMT == 0) {
+    return lds4(a);
+  } else {
+    const u32x2 h = lds2u(a), m = lds2u(a + plane_b), l = lds2u(a + 2 * plane_b);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned hh = h[e], mm = m[e], ll = l[e];
+      v[2 * e] = join3(hh << 16, mm << 16, ll << 16);
+      v[2 * e + 1] = join3(hh & 0xffff0000u, mm & 0xffff0000u, ll & 0xffff0000u);
+    }
+    return v;
+  }
+}
+template <int FMT>
+__device__ __forceinline__ void img_st1(int a, int plane_b, float x) {
+  if constexpr (FMT == 0) {
+    lds1(a) = x;
+  } else {
+    unsigned xb, rb, lb;
+    split3(x, xb, rb, lb);
+    lds_h(a) = static_cast<unsigned short>(xb >> 16);
+    lds_h(a + plane_b) = static_cast<unsigned short>(rb >> 16);
+    lds_h(a + 2 * plane_b) = static_cast<unsigned short>(lb >> 16);
+  }
+}
+constexpr int esz_of(int fmt) { return fmt ? 2 : 4; }      // bytes per channel inside a row (plane)
+
 // ---- static facts about an op ------------------------------------------------------------------------
 constexpr bool is_up(const OpD& d) { return d.kind == K_UP; }
 constexpr int ntot(const OpD& d) { return d.N * (is_up(d) ? 2 : 1); }
-constexpr int kgroups(const OpD& d) { return d.cin / (d.path == P_R32 ? 8 : 16); }            // K groups per segment
+constexpr int ksl(const OpD& d) { return d.KSt * d.KSg; }                                        // K slices (X16B)
+constexpr int kgroups(const OpD& d) { return d.cin / (d.path == P_R32B ? 16 : 32); }            // K steps (one MFMA deep) per segment
 constexpr int gw(const OpD& d) { return kgroups(d) / d.KSg; }                                     // ... per wave
 constexpr int segw(const OpD& d) { return is_up(d) ? 3 : d.nseg / d.KSt; }                       // segments per wave
-constexpr int tn(const OpD& d) { return d.N / (d.path == P_R32 ? 32 : 16); }                     // channel tiles per segment row of the blob
-constexpr int conv_nf(const OpD& d) {                                                              // weight fragments per wave
-  return d.path == P_X4 ? (d.nseg / d.KSt) * (d.cin / d.KSg / 4) : segw(d) * gw(d) * d.NT;
-}
-constexpr int ntask(const OpD& d) { return d.path == P_X4 ? 8 : d.PG * d.CG * d.KSt * d.KSg; }
+// weight fragments (one A operand: the 8 K values of a lane) per wave
+constexpr int conv_nf(const OpD& d) { return segw(d) * gw(d) * d.NT; }
+constexpr int ntask(const OpD& d) { return d.PG * d.CG * d.KSt * d.KSg; }
 constexpr int nparams(const OpD& d) { return 2 * ntot(d) + 2 * d.gc + 1; }      // bias | weight scale | gamma | beta | alpha
-constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 3) / 4; }             // "super-fragments": 4 int8 fragments = one dwordx4 per lane
-constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), RING_SF); }
+constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 1) / 2; }             // "super-fragments": 2 int8 fragments = one dwordx4 per lane
+constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), d.path == P_R32B ? RING_SF_R32 : RING_SF); }
 constexpr int part_cls(const Part& p) { return p.round2 ? 3 : p.la; }
 // Who stages: the parts an op loads AND stores itself (classes 1 and 3) are handled by its "stager" threads -- all 512, or, in the
 // large-layer ops whose tiling leaves waves 4..7 without MFMA work, only those 256: the MFMA waves' weight refills then do not
 // queue behind the staging loads on the (in-order) memory counter, and the staging waves' waits cost the MFMA waves nothing.
 // Class-2 parts (loaded one op before they are stored) stay with all threads: both ops must agree on who holds what.
 constexpr int stg_threads(int i) {
-  return (i >= 0 && i < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32 && kOps[i].PG * kOps[i].CG == 4) ? 256 : THREADS;
+  return (i >= 0 && i < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32B && kOps[i].PG * kOps[i].CG == 4) ? 256 : THREADS;
 }
 constexpr int part_n(const Part& p, int nthr) { return (p.rows * p.c4s + nthr - 1) / nthr; }
 constexpr int parts_regs(const Img& g, int cls, int nthr) {
@@ -187,7 +267,7 @@ constexpr int carry_w(int i) {
 // the in-order memory counter: waiting for it means waiting for the whole staging burst -- seen as `vmcnt(0)` in mid-loop).
 constexpr int EXT_MAX = 5;
 constexpr int ext_sf(int i) {
-  if (i < 0 || i >= kNumOps || kOps[i].type != T_CONV || kOps[i].path != P_R32) return 0;
+  if (i < 0 || i >= kNumOps || kOps[i].type != T_CONV || kOps[i].path != P_R32B) return 0;
   const int extra = conv_nsf(kOps[i]) - ring_sf(kOps[i]);
   return (extra > 0 && extra <= EXT_MAX) ? extra : 0;
 }
@@ -241,34 +321,63 @@ __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
           constexpr int i = decltype(ii)::value;
           const int q = tid + NTHR * i;
           const int row = q >> cs, c4 = q & (p.c4s - 1);
-          const int a = p.lds_b + img_row_rt(g.pitch_b, g.pair, g.half_b, p.row0 + row) + c4 * 16;
-          if ((i + 1) * NTHR <= items || FZ_LIKELY(q < items)) lds4(a) = r[base + i];
+          const int a = p.lds_b + img_row_rt(g.pitch_b, g.pair, g.half_b, p.row0 + row) + c4 * (4 * esz_of(g.fmt));
+          if ((i + 1) * NTHR <= items || FZ_LIKELY(q < items)) img_st4<g.fmt>(a, g.plane_b, r[base + i]);
         });
       }
     });
   }
 }
+// halo blocks (float4 units) of image J: block K is zeroed by threads [t0_K, t0_K + n4_K) at the top of the workgroup
+constexpr int zero_total(const Img& g) { int n = 0; for (int k = 0; k < g.nzero; ++k) n += g.zero[k].n4; return n; }
+constexpr int zero_start(const Img& g, int k) { int n = THREADS - zero_total(g); for (int kk = 0; kk < k; ++kk) n += g.zero[kk].n4; return n; }
 template <int J>
 __device__ __forceinline__ void zero_halos(int tid) {
   if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 1)) {
     constexpr Img g = kOps[J].img;
+    static_assert(zero_total(g) <= THREADS, "halo blocks: one float4 per thread");
     float zf = 0.f;
     asm volatile("" : "+v"(zf));
     const f32x4 z = {zf, zf, zf, zf};
     sfor<g.nzero>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
-      constexpr int t0 = THREADS - 128 + K * 32;    // (a halo row is at most 32 float4; waves 6 and 7: never the wave that runs a small op's epilogue)
+      constexpr int t0 = zero_start(g, K);
       if (FZ_LIKELY(static_cast<unsigned>(tid - t0) < static_cast<unsigned>(g.zero[K].n4))) lds4(g.zero[K].lds_b + (tid - t0) * 16) = z;
     });
   }
 }
 
-// A operand of the MFMAs: byte q of the lane's dword of fragment f (int8 weight, exact in fp32); the per-channel scale
-// of the quantisation is applied to the accumulators in the epilogue.
-__device__ __forceinline__ float wq(const f32x4& sfrag, int j, int q) {
-  const float x = sfrag[j];           // (a scalar copy first: __builtin_bit_cast applied to `vec[j]` directly reads element 0, ROCm 7.2 clang)
-  const int v = __builtin_bit_cast(int, x);
-  return static_cast<float>(static_cast<signed char>(v >> (8 * q)));
+// A operand of the bf16 MFMAs: fragment `fr` (0 / 1) of a super-fragment = 8 int8 weights of this lane (exact in bf16) -> four
+// dwords of two bf16 each; the per-channel scale of the quantisation is applied to the accumulators in the epilogue.
+__device__ __forceinline__ bf16x8 wfrag(const f32x4& sfrag, int fr) {
+  const float x0 = sfrag[2 * fr], x1 = sfrag[2 * fr + 1];     // (scalar copies first: __builtin_bit_cast applied to `vec[j]` directly reads element 0, ROCm 7.2 clang)
+  const int v0 = __builtin_bit_cast(int, x0), v1 = __builtin_bit_cast(int, x1);
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int v = q < 2 ? v0 : v1;
+    const float f0 = static_cast<float>(static_cast<signed char>(v >> (16 * (q & 1))));
+    const float f1 = static_cast<float>(static_cast<signed char>(v >> (16 * (q & 1) + 8)));
+    o[q] = pk_top16(fbits(f0), fbits(f1));
+  }
+  return __builtin_bit_cast(bf16x8, o);
+}
+__device__ __forceinline__ bf16x8 as_bf(const f32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+// B operand from an fp32 image: 8 consecutive channels -> the three bf16 fragments (split when read)
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8 (&b)[3]) {
+  unsigned xb[8], rb[8], lb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float x = e < 4 ? x0[e & 3] : x1[e & 3]; split3(x, xb[e], rb[e], lb[e]); }
+  u32x4 h, m, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h[q] = pk_top16(xb[2 * q], xb[2 * q + 1]);
+    m[q] = pk_top16(rb[2 * q], rb[2 * q + 1]);
+    l[q] = pk_top16(lb[2 * q], lb[2 * q + 1]);
+  }
+  b[0] = __builtin_bit_cast(bf16x8, h);
+  b[1] = __builtin_bit_cast(bf16x8, m);
+  b[2] = __builtin_bit_cast(bf16x8, l);
 }
 // The carried weights become visible to the optimiser only here: without this it hoists the byte extraction up to the
 // loads in the previous op -- and waits for them there, which turns the prefetch into a synchronous load.
@@ -279,25 +388,23 @@ __device__ __forceinline__ void pin_regs(f32x4 (&r)[N]) {
 }
 
 // ---- wave task of a conv op -----------------------------------------------------------------------------------
-struct Task { int active, wbase_f, a, b, ks; };   // a/b: (pg, cg) on the R32 path, (ct, ks_t | ks_g) decoded by the caller on X16
+struct Task { int active, wbase_f, a, b, ks; };   // a: position group, b: channel group / tile, ks: K slice (X16B)
 template <int I>
 __device__ __forceinline__ Task conv_task(int wave) {
   constexpr OpD d = kOps[I];
   Task t;
   t.active = ntask(d) >= 8 ? 1 : wave < ntask(d);      // (a compile-time fact where all 8 waves have a task: no branch around their loads)
-  if constexpr (d.path == P_X4) {
-    t.a = wave & (d.CG - 1); t.b = wave >> clog2(d.CG); t.ks = 0;
-    t.wbase_f = wave * (conv_nsf(d) * 256);
-  } else if constexpr (d.path == P_R32) {
-    t.a = wave & (d.PG - 1);           // position group
+  if constexpr (d.path == P_R32B) {
+    t.a = wave & (d.PG - 1);                    // position group
     t.b = (wave >> clog2(d.PG)) & (d.CG - 1);   // channel group
     t.ks = 0;
     t.wbase_f = t.b * (conv_nsf(d) * 256);
   } else {
-    const int ct = wave & (d.CG - 1), ks = (wave >> clog2(d.CG)) & (d.KSt * d.KSg - 1);
-    const int ks_g = ks & (d.KSg - 1), ks_t = ks >> clog2(d.KSg);
-    t.a = ct; t.b = ks_t * 256 + ks_g; t.ks = ks;
-    t.wbase_f = (wave & (ntask(d) - 1)) * (conv_nsf(d) * 256);
+    // wave = ct + CG (ks + KS pg): the waves of one position group share the weights of (ct, ks)
+    t.b = wave & (d.CG - 1);
+    t.ks = (wave >> clog2(d.CG)) & (ksl(d) - 1);
+    t.a = (wave >> clog2(d.CG * ksl(d))) & (d.PG - 1);
+    t.wbase_f = (t.ks * d.CG + t.b) * (conv_nsf(d) * 256);
   }
   return t;
 }
@@ -413,14 +520,20 @@ __device__ __forceinline__ void store_round2(int tid, const f32x4 (&p3)[N3]) {
   }
 }
 
-// LDS address of (output row `row`, channel byte offset cb) inside the forward target of op d
+// LDS address of (output row `row`, channel c) inside the forward target of op I (hi plane of a three-plane image)
 template <int I>
-__device__ __forceinline__ int fwd_addr(int row, int cb) {
+__device__ __forceinline__ int fwd_addr(int row, int c) {
   constexpr Fwd f = kOps[I].fwd;
-  return f.base_b + img_row_rt(f.pitch_b, f.pair, f.half_b, f.row0 + row) + cb;
+  return f.base_b + img_row_rt(f.pitch_b, f.pair, f.half_b, f.row0 + row) + c * esz_of(f.fmt);
 }
+template <int I>
+__device__ __forceinline__ void fwd_st4(int row, int c, const f32x4& v) { img_st4<kOps[I].fwd.fmt>(fwd_addr<I>(row, c), kOps[I].fwd.plane_b, v); }
+template <int I>
+__device__ __forceinline__ f32x4 fwd_ld4(int row, int c) { return img_ld4<kOps[I].fwd.fmt>(fwd_addr<I>(row, c), kOps[I].fwd.plane_b); }
+// does op I feed an LSTM / dilated-dense op (which reads its rows as fp32 from XCOPY_B)?
+constexpr bool feeds_x(int i) { return i + 1 < kNumOps && (kOps[i + 1].type == T_LSTM || kOps[i + 1].type == T_DDB); }
 
-// ---- row-wise epilogue of the X16 path ----------------------------------------------------------------------------
+// ---- row-wise epilogue of the X16B path ---------------------------------------------------------------------------
 // LPG lanes per output row (float4 each): K-slice sum + bias, LayerNorm over the row's channels, PReLU, stores.
 template <int I>
 __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
@@ -462,31 +575,39 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
       const int row = pos * d.row_mul + d.row_add + r;
       if constexpr (d.d0_on && !(FZ_ABL & 4)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4), v);
       if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4), v);
-      if constexpr (d.fwd.on) lds4(fwd_addr<I>(row, 16 * li)) = v;
+      if constexpr (d.fwd.on) fwd_st4<I>(row, 4 * li, v);
+      if constexpr (feeds_x(I)) lds4(XCOPY_B + (row * GC + 4 * li) * 4) = v;
     }
   });
 }
 
-// ---- conv op, small layers: 16x16x4 tiles, K split over waves, LDS exchange -----------------------------------------
+// ---- conv op, small layers: 16x16x32 bf16 tiles, K split over waves, LDS exchange -------------------------------------
+// Wave task = (position group pg, 16-channel tile ct, K slice (time tap ks_t, channel-group range ks_g)); per K step (32
+// channels of one (time tap, frequency tap) segment) and position tile: three MFMAs, one per plane of the image, each into
+// its own accumulator (summed hi + (mid + lo) at the end).  Lane (j = lane & 15, h = lane >> 4): A = weights of channel
+// 16 ct + j, B = position j, both for the 8 channels 8 h .. 8 h + 7 of the step; D = channels 4 h .. 4 h + 3 of position j.
 template <int I, int N1, int N3>
-__device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
+__device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
   constexpr OpD d = kOps[I];
   constexpr bool UP = is_up(d);
   constexpr int PT = d.PT, GW = gw(d), NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d), OPB = (NTOT + 4) * 4;
+  static_assert(d.img.fmt == 1, "X16B: three-plane image");
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Task t = conv_task<I>(wave);
-  const int ks_t = t.b >> 8, ks_g = t.b & 255;
+  const int ks_t = t.ks >> clog2(d.KSg), ks_g = t.ks & (d.KSg - 1);
   const int j = lane & 15, h = lane >> 4;
   int lane_b[PT];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    int pos = 16 * pt + j;
+    int pos = 16 * (t.a * PT + pt) + j;
     if (pos > d.P - 1) pos = d.P - 1;
     lane_b[pt] = pos * d.img.pitch_b + 16 * h + ks_t * d.img.tap_b + ks_g * (GW * 64);
   }
-  f32x4 acc[PT], acco[PT];
+  f32x4 acc[PT][3], acco[UP ? PT : 1][3];
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) { acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f}; acco[pt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) { acc[pt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (UP) acco[pt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   if (t.active) pin_regs(c.w);
@@ -497,19 +618,18 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
       sfor<(FZ_ABL & 256) ? 0 : hi - lo>([&](auto ff) {
         constexpr int f = lo + decltype(ff)::value;
         constexpr int s = f / GW, g = f % GW;
-        constexpr int sf = f / 4;
-        const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
-        if ((FZ_ABL & 1024) && d.KSt == 2 && ks_t == 0) return;
+        constexpr int sf = f / 2;
+        const bf16x8 a = wfrag(c.w[sf % CW], f % 2);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-          const f32x4 b = lds4(lane_b[pt] + d.seg_b[s] + g * 64);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (UP && s == 2) acco[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acco[pt], 0, 0, 0);
-            else acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc[pt], 0, 0, 0);
+          for (int pl = 0; pl < 3; ++pl) {
+            const bf16x8 b = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 64 + pl * d.img.plane_b));
+            if constexpr (UP && s == 2) acco[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acco[pt][pl], 0, 0, 0);
+            else acc[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[pt][pl], 0, 0, 0);
           }
         }
-        if constexpr ((f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
+        if constexpr ((f % 2 == 1 || f + 1 == NF) && sf + CW < NSF) {
           c.w[sf % CW] = ldb(wbase + static_cast<unsigned long long>((sf + CW) * 1024), lane16);
           sched_pin();
         }
@@ -517,6 +637,7 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
     }
   };
   if constexpr (d.rounds == 2) {
+    static_assert(NF % 2 == 0, "two rounds: the same number of fragments per round");
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{});
     lds_barrier();
     store_round2<I>(tid, p3);
@@ -528,11 +649,11 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
   if (t.active) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int pos = 16 * pt + j;
+      const int pos = 16 * (t.a * PT + pt) + j;
       if (pos < d.P) {
-        const int eb = d.ex_b + (t.ks * d.P + pos) * OPB + (16 * t.a + 4 * h) * 4;
-        lds4(eb) = acc[pt];
-        if (UP) lds4(eb + d.N * 4) = acco[pt];
+        const int eb = d.ex_b + (t.ks * d.P + pos) * OPB + (16 * t.b + 4 * h) * 4;
+        lds4(eb) = acc[pt][0] + (acc[pt][1] + acc[pt][2]);
+        if constexpr (UP) lds4(eb + d.N * 4) = acco[pt][0] + (acco[pt][1] + acco[pt][2]);
       }
     }
   }
@@ -546,83 +667,25 @@ __device__ __forceinline__ void conv_x16(const Ctx& cx, int tid, Carry<I>& c, co
   FZ_STAMP(I, 4);
 }
 
-// ---- conv op, tiny layers (<= 8 positions): 4x4x1 tiles -- one MFMA = 16 blocks of (4 channels x 4 positions), one K step ----
-// Lane (block b, j): A = weight of channel 4 b + (lane & 3), B = activation of position j (the same for every block),
-// D = channels 4 b .. 4 b + 3 of position j.  All 8 waves split K (time tap x channel range of every frequency-tap
-// segment); a 32-channel layer runs two K slices in the two halves of the 16 blocks.  Exchange + row-wise epilogue as X16.
-template <int I, int N1, int N3>
-__device__ __forceinline__ void conv_x4(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3]) {
-  constexpr OpD d = kOps[I];
-  constexpr int PT = d.PT, VH = d.N < 64 ? 2 : 1, KSc = d.KSg, CPS = d.cin / KSc, FPS = CPS / 4;
-  constexpr int NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d), OPB = (NTOT + 4) * 4;
-  static_assert(d.rounds == 1 && !is_up(d), "X4 path: single-round, not the up-sampling layer");
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Task t = conv_task<I>(wave);
-  const int b = lane >> 2, j = lane & 3, hv = VH == 2 ? (b >> 3) : 0;
-  const int v = t.b * VH + hv, ks_t = v / KSc, ks_c = v % KSc;
-  int lane_b[PT];
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    int pos = 4 * pt + j;
-    if (pos > d.P - 1) pos = d.P - 1;
-    lane_b[pt] = pos * d.img.pitch_b + ks_t * d.img.tap_b + ks_c * (CPS * 4);
-  }
-  f32x4 acc4[PT][4];           // one accumulator per K step of a fragment: four independent MFMA chains
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc4[pt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
-  const unsigned lane16 = static_cast<unsigned>(lane * 16);
-  pin_regs(c.w);
-  FZ_STAMP(I, 5);
-  sfor<(FZ_ABL & 8) ? 0 : NF>([&](auto ff) {
-    constexpr int f = decltype(ff)::value;
-    constexpr int s = f / FPS, g = f % FPS, sf = f / 4;
-    const float a[4] = {wq(c.w[sf % CW], f % 4, 0), wq(c.w[sf % CW], f % 4, 1), wq(c.w[sf % CW], f % 4, 2), wq(c.w[sf % CW], f % 4, 3)};
-    if ((FZ_ABL & 1024) && d.KSt == 2 && ks_t == 0) return;
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-      const f32x4 bq = lds4(lane_b[pt] + d.seg_b[s] + g * 16);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc4[pt][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[q], bq[q], acc4[pt][q], 0, 0, 0);
-    }
-    if constexpr ((f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
-      c.w[sf % CW] = ldb(wbase + static_cast<unsigned long long>((sf + CW) * 1024), lane16);
-      sched_pin();
-    }
-  });
-  FZ_STAMP(I, 6);
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    const int pos = 4 * pt + j;
-    if (pos < d.P) lds4(d.ex_b + (v * d.P + pos) * OPB + (64 * t.a + 4 * (VH == 2 ? (b & 7) : b)) * 4) = (acc4[pt][0] + acc4[pt][1]) + (acc4[pt][2] + acc4[pt][3]);
-  }
-  if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
-  FZ_STAMP(I, 1);
-  lds_barrier();
-  FZ_STAMP(I, 2);
-  x_epilogue<I>(cx, tid);
-  FZ_STAMP(I, 3);
-  build_next<I>(tid, p1, c.p);
-  FZ_STAMP(I, 4);
-}
-
-// ---- conv op, large layers: 32x32x2 tiles, whole LayerNorm groups per wave, epilogue in registers ----------------------
+// ---- conv op, large layers: 32x32x16 bf16 tiles, whole LayerNorm groups per wave, epilogue in registers -----------------
+// Lane (j = lane & 31, h = lane >> 5): A = weights of channel 32 T + j, B = position j, both for the 8 channels 8 h .. 8 h + 7
+// of the K step (16 channels of one segment); three MFMAs per tile and step (hi, mid, lo plane) into the tile's accumulator.
+// The two images that do not fit LDS as three planes are fp32 (img.fmt 0): their B fragments are split when they are read.
 __device__ __forceinline__ float xor32_sum(float s) { return s + __shfl_xor(s, 32); }
 
 template <int I, int N1, int N3, int NX>
-__device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3], f32x4 (&wx)[NX]) {
+__device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3], f32x4 (&wx)[NX]) {
   constexpr OpD d = kOps[I];
   constexpr bool UP = is_up(d);
   constexpr int PT = d.PT, NT = d.NT, G = kgroups(d), NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d), EXT = ext_sf(I);
   constexpr int NA = UP ? 2 : NT;                    // accumulator tiles per position tile (UP: even row, odd row)
+  constexpr int FMT = d.img.fmt;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Task t = conv_task<I>(wave);
   const int j = lane & 31, h = lane >> 5;
   int lane_b[PT];
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) lane_b[pt] = (32 * (t.a * PT + pt) + j) * d.img.pitch_b + 16 * h;
+  for (int pt = 0; pt < PT; ++pt) lane_b[pt] = (32 * (t.a * PT + pt) + j) * d.img.pitch_b + (8 * esz_of(FMT)) * h;
   f32x16 acc[PT][NA];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt)
@@ -634,26 +697,33 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   if (t.active) { pin_regs(c.w); if constexpr (EXT > 0) pin_regs(wx); }
   FZ_STAMP(I, 5);
-  f32x4 b[PT];
+  bf16x8 b[PT][3];
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
     if (t.active) {
-      sfor<hi - lo>([&](auto ff) {
+      sfor<(FZ_ABL & 4096) ? 0 : hi - lo>([&](auto ff) {
         constexpr int f = lo + decltype(ff)::value;
         constexpr int nt = f % NT, sg = f / NT, s = sg / G, g = sg % G;
         constexpr int na = UP ? (s == 2 ? 1 : 0) : nt;
         if constexpr (nt == 0) {
 #pragma unroll
-          for (int pt = 0; pt < PT; ++pt) b[pt] = lds4(lane_b[pt] + d.seg_b[s] + g * 32);
+          for (int pt = 0; pt < PT; ++pt) {
+            if constexpr (FMT == 1) {
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl) b[pt][pl] = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 32 + pl * d.img.plane_b));
+            } else {
+              split8(lds4(lane_b[pt] + d.seg_b[s] + g * 64), lds4(lane_b[pt] + d.seg_b[s] + g * 64 + 16), b[pt]);
+            }
+          }
         }
-        constexpr int sf = f / 4;
+        constexpr int sf = f / 2;
         const f32x4& wsf = (EXT > 0 && sf >= CW) ? wx[(EXT > 0 && sf >= CW) ? sf - CW : 0] : c.w[sf % CW];
-        const float a[4] = {wq(wsf, f % 4, 0), wq(wsf, f % 4, 1), wq(wsf, f % 4, 2), wq(wsf, f % 4, 3)};
+        const bf16x8 a = wfrag(wsf, f % 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-          for (int pt = 0; pt < PT; ++pt) acc[pt][na] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[pt][q], acc[pt][na], 0, 0, 0);
-        if constexpr (EXT == 0 && (f % 4 == 3 || f + 1 == NF) && sf + CW < NSF) {
+          for (int pt = 0; pt < PT; ++pt) acc[pt][na] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[pt][pl], acc[pt][na], 0, 0, 0);
+        if constexpr (EXT == 0 && (f % 2 == 1 || f + 1 == NF) && sf + CW < NSF) {
           c.w[sf % CW] = ldb(wbase + static_cast<unsigned long long>((sf + CW) * 1024), lane16);
           sched_pin();
         }
@@ -661,6 +731,7 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
     }
   };
   if constexpr (d.rounds == 2) {
+    static_assert(NF % 2 == 0, "two rounds: the same number of fragments per round");
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{});
     lds_barrier();
     store_round2<I>(tid, p3);
@@ -735,7 +806,7 @@ __device__ __forceinline__ void conv_r32(const Ctx& cx, int tid, Carry<I>& c, co
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
           const int cc = c0 + 8 * q + 4 * h;
-          if constexpr (d.fwd.on) lds4(fwd_addr<I>(row, cc * 4)) = v;
+          if constexpr (d.fwd.on) fwd_st4<I>(row, cc, v);
           if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4), v);
           if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4), v);
         }
@@ -772,7 +843,7 @@ __device__ __forceinline__ void input_op(const Ctx& cx, int tid) {
       const float v = y[e] * rstd * gm[e] + bt[e];
       o[e] = v >= 0.f ? v : alpha * v;
     }
-    lds4(fwd_addr<I>(pos, 16 * c4)) = o;
+    fwd_st4<I>(pos, 4 * c4, o);
   }
 }
 
@@ -793,7 +864,7 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
 #pragma unroll
     for (int j = 0; j < KN; ++j) {
       const int k = sl * KN + j;
-      a += c.w[j] * lds1(d.x_b + (k >> XS) * d.x_pitch_b + (k & (d.x_cols - 1)) * 4);
+      a += c.w[j] * lds1(XCOPY_B + k * 4);        // (the conv op before left its rows here as fp32, [row][x_cols] = element k)
     }
     lds4(PART + (sl * 21 + u) * 16) = a;
   } else if (tid < 420) {
@@ -828,7 +899,7 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
     }
     a = fmaf(c.w[S0 + 2 + 5][0], lds1(HN + 80), a);
     const int f = tid >> XS, cc = tid & (d.x_cols - 1);
-    lds1(d.y_b + f * d.x_pitch_b + cc * 4) = a;
+    img_st1<d.x_fmt>(d.y_b + f * d.x_pitch_b + cc * esz_of(d.x_fmt), d.x_plane_b, a);
     if constexpr (d.ldst_on) stb1(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4), a);
   }
 }
@@ -845,7 +916,9 @@ __device__ __forceinline__ void ddb_op(const Ctx& cx, int tid, Carry<I>& c) {
   constexpr int G = d.x_cols / 2, F = d.din / d.x_cols;
   static_assert(ddbz_lds_floats<G>(F) * 4 <= 70 * 1024, "dilated-dense scratch over its LDS region");
   static_assert(carry_w(I) == DdbzCarry<THREADS, G, F>::N, "carry slots of the dilated-dense op");
-  ddb_block_fz<THREADS, G, F>(ddbz_load_rec(cx.ddb + d.bidx), cx.stream, cx.step, lds + DDB_LDS_B / 4, tid, dbg, lds + d.y_b / 4, d.x_pitch_b / 4, c.w);
+  // input rows: the fp32 copy the strided conv before left at XCOPY_B ([F][2G]); output rows: split into the next image
+  auto put_y = [&](int fo, int cq, const f32x4& r) { img_st4<d.x_fmt>(d.y_b + fo * d.x_pitch_b + 4 * cq * esz_of(d.x_fmt), d.x_plane_b, r); };
+  ddb_block_fz<THREADS, G, F>(ddbz_load_rec(cx.ddb + d.bidx), cx.stream, cx.step, lds + DDB_LDS_B / 4, tid, dbg, lds + XCOPY_B / 4, 2 * G, put_y, c.w);
   if (FZ_PROF && cx.prof && tid == 0) {
     constexpr int slot[6] = {0, 5, 6, 1, 2, 3};
 #pragma unroll
@@ -911,7 +984,7 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int f = rg + 32 * i;
-    if (f < d.F) s4 += lds4(fwd_addr<I>(f, 16 * c4));
+    if (f < d.F) s4 += fwd_ld4<I>(f, 4 * c4);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -935,12 +1008,12 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
   for (int i = 0; i < NI; ++i) {
     const int f = rg + 32 * i;
     if (f < d.F) {
-      const f32x4 y = lds4(fwd_addr<I>(f, 16 * c4)) * g4 + c.w[i];      // (re-read: cheaper than 32 registers held across the gates)
+      const f32x4 y = fwd_ld4<I>(f, 4 * c4) * g4 + c.w[i];      // (re-read: cheaper than 32 registers held across the gates)
       if constexpr (d.last) {
         const float s = group_sum<16>(y[0] * ow[0] + y[1] * ow[1] + y[2] * ow[2] + y[3] * ow[3]);
         if (c4 == 0) cx.io_out[f] = s + ob;
       } else {
-        lds4(fwd_addr<I>(f, 16 * c4)) = y;
+        fwd_st4<I>(f, 4 * c4, y);
       }
     }
   }
@@ -985,9 +1058,8 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
     input_op<I>(cx, tid);
     build_next<I>(tid, p1, c.p);
   } else if constexpr (d.type == T_CONV) {
-    if constexpr (d.path == P_X16) conv_x16<I>(cx, tid, c, p1, p3);
-    else if constexpr (d.path == P_X4) conv_x4<I>(cx, tid, c, p1, p3);
-    else conv_r32<I>(cx, tid, c, p1, p3, wx);
+    if constexpr (d.path == P_X16B) conv_x16b<I>(cx, tid, c, p1, p3);
+    else conv_r32b<I>(cx, tid, c, p1, p3, wx);
   } else if constexpr (d.type == T_LSTM) {
     if constexpr (!(FZ_ABL & 32)) lstm_op<I>(cx, tid, c);
 #if FZ_BASE

@@ -59,57 +59,33 @@ def test_blob_packing_round_trips_the_container(variant):
         if o["type"] != 1:
             continue
         n_conv += 1
-        r32, up = o["path"] == 0, o["kind"] == 4
+        r32, up = o["path"] == 3, o["kind"] == 4     # 3: 32x32x16 tiles, 4: 16x16x32 tiles (bf16 MFMA, 8 K values per lane and fragment)
+        assert o["path"] in (3, 4)
         cin, N = o["cin"], o["N"]
         q, sc = Wq[o["wkey"] + ".w"]
         perm = _perm(o)
-        if o["path"] == 2:           # the walk of conv_x4 (fused_step.hip)
-            VH, KSc = (2 if N < 64 else 1), o["KSg"]
-            cps = cin // KSc
-            fps, segw = cps // 4, o["nseg"] // o["KSt"]
-            nf = segw * fps
-            nsf = (nf + 3) // 4
-            raw = out[o["w_off"]:o["w_off"] + 8 * nsf * 256].view(np.int8).reshape(8, nsf, 64, 16)
-            rec = np.full(q.shape, 99, np.int32)
-            b, i = lane >> 2, lane & 3
-            hv = (b >> 3) if VH == 2 else 0 * b
-            for wv in range(8):
-                ct, kwv = wv % o["CG"], wv // o["CG"]
-                v = kwv * VH + hv
-                ks_t, ks_c = v // KSc, v % KSc
-                npk = 64 * ct + 4 * ((b & 7) if VH == 2 else b) + i
-                for f in range(nf):
-                    sg = ks_t * segw + f // fps
-                    c0 = ks_c * cps + 4 * (f % fps)
-                    for l in range(64):
-                        t, kw = o["seg_tk"][sg[l]] >> 2, o["seg_tk"][sg[l]] & 3
-                        rec[perm[npk[l]], t, kw, c0[l]:c0[l] + 4] = raw[wv, f // 4, l, (f % 4) * 4:(f % 4) * 4 + 4]
-            assert np.array_equal(rec, q.astype(np.int32)), o["name"]
-            G = None
-        else:
-            G = cin // (8 if r32 else 16)
-        wt = 0 if G is None else o["CG"] * o["KSt"] * o["KSg"]
-        if G is not None:
-            GW = G // o["KSg"]
-            segw = 3 if up else o["nseg"] // o["KSt"]
-            nf = segw * GW * o["NT"]
-            nsf = (nf + 3) // 4
-            raw = out[o["w_off"]:o["w_off"] + wt * nsf * 256].view(np.int8).reshape(wt, nsf, 64, 16)
-            rec = np.full(q.shape, 99, np.int32)
+        G = cin // (16 if r32 else 32)
+        wt = o["CG"] if r32 else o["CG"] * o["KSt"] * o["KSg"]
+        GW = G // o["KSg"]
+        segw = 3 if up else o["nseg"] // o["KSt"]
+        nf = segw * GW * o["NT"]
+        nsf = (nf + 1) // 2
+        raw = out[o["w_off"]:o["w_off"] + wt * nsf * 256].view(np.int8).reshape(wt, nsf, 64, 16)
+        rec = np.full(q.shape, 99, np.int32)
         for task in range(wt):
             ct, ks = task % o["CG"], task // o["CG"]
             ks_g, ks_t = ks % o["KSg"], ks // o["KSg"]
-            for f in range(nf):          # the walk of conv_x16 / conv_r32 (fused_step.hip)
+            for f in range(nf):          # the walk of conv_x16b / conv_r32b (fused_step.hip)
                 if r32:
                     nt, sgi = f % o["NT"], f // o["NT"]
                     sg, g, T = sgi // G, sgi % G, ct * o["NT"] + nt
-                    npk, c0 = 32 * T + (lane & 31), 8 * g + 4 * (lane >> 5)
+                    npk, c0 = 32 * T + (lane & 31), 16 * g + 8 * (lane >> 5)
                 else:
                     sg, g, T = ks_t * segw + f // GW, ks_g * GW + f % GW, ct
-                    npk, c0 = 16 * T + (lane & 15), 16 * g + 4 * (lane >> 4)
+                    npk, c0 = 16 * T + (lane & 15), 32 * g + 8 * (lane >> 4)
                 t, kw = o["seg_tk"][sg] >> 2, o["seg_tk"][sg] & 3
-                for qq in range(4):
-                    rec[perm[npk], t, kw, c0 + qq] = raw[task, f // 4, :, (f % 4) * 4 + qq]
+                for qq in range(8):
+                    rec[perm[npk], t, kw, c0 + qq] = raw[task, f // 2, :, (f % 2) * 8 + qq]
         assert np.array_equal(rec, q.astype(np.int32)), o["name"]          # every weight covered, every byte right
         ntot, gc = N * (2 if up else 1), o["gc"]
         blk = out[o["p_off"]:o["p_off"] + 2 * ntot + 2 * gc + 1]
@@ -133,7 +109,7 @@ def test_plan_images_fit_lds_and_ops_cover_the_network(name, bottleneck):
     assert 0.96 < flops / (2 * 73_967_252) < 1.0
     for o in ops:
         if o["type"] == 1:
-            lim = o["ex_b"] if o["path"] in (1, 2) else 160 * 1024 - 8192
+            lim = o["ex_b"] if o["path"] == 4 else 160 * 1024 - 8192
             assert o["img"]["bytes"] <= lim, o["name"]
             for p in o["parts"]:
                 assert p["la"] in (1, 2)

@@ -49,12 +49,12 @@ DEC = [("msfe3_de", 3, 8, "msfe3_de", "msfe3_dd", "msfe3_upsampling"),
 T_INPUT, T_CONV, T_LSTM, T_CTFA, T_DDB = 0, 1, 2, 3, 4
 DDB_LDS_B = 64 * 1024        # LDS scratch of a dilated-dense block op (70 KB), above the small image it completes
 K_IN, K_EL, K_DL, K_DOWN, K_UP = 0, 1, 2, 3, 4
-P_R32, P_X16, P_X4 = 0, 1, 2
+P_R32, P_R32B, P_X16B = 0, 3, 4
 S_PREV, S_CUR, S_SCRATCH = 0, 1, 2
 LDS_BYTES = 160 * 1024
 SCR_BYTES = 8192
 SCR_B = LDS_BYTES - SCR_BYTES
-MAX_PARTS, MAX_ZERO, MAX_SEG, CARRY_FRAGS = 4, 4, 6, 12
+MAX_PARTS, MAX_ZERO, MAX_SEG, CARRY_FRAGS = 4, 12, 6, 12
 
 
 def r64(n):
@@ -151,63 +151,81 @@ R32_TABLE = {   # (kind, N, P) -> (PT, NT, PG, CG)
 
 
 def tiling(kind, N, P, cin, taps, rounds=1):
-    """-> dict(path, PT, NT, PG, CG, KSt, KSg)"""
+    """-> dict(path, PT, NT, PG, CG, KSt, KSg).  R32B: 32x32x16 bf16 tiles, PT x NT tiles per wave, PG x CG wave tasks, whole
+    LayerNorm groups per wave.  X16B: 16x16x32 bf16 tiles, wave task = (position group pg, channel tile ct, K slice
+    (time tap ks_t, channel-group range ks_g)), PT tiles per wave; the K slices meet in the LDS exchange buffer."""
     if (kind, N, P) in R32_TABLE:
         PT, NT, PG, CG = R32_TABLE[(kind, N, P)]
-        return dict(path=P_R32, PT=PT, NT=NT, PG=PG, CG=CG, KSt=1, KSg=1)
+        return dict(path=P_R32B, PT=PT, NT=NT, PG=PG, CG=CG, KSt=1, KSg=1)
     assert P <= 64, (kind, N, P)
-    if P <= 8 and kind != K_UP and os.environ.get("NUTLS_PLAN_NO_X4") is None:
-        # 4x4x1 MFMA (16 blocks of 4 channels x 4 positions, one K step per instruction): a tile is 64 channels x 4 positions,
-        # so layers with <= 8 positions waste nothing on position padding.  All 8 waves split K; a 32-channel layer uses the
-        # two halves of the 16 blocks as two K slices (VH = 2).
-        CG = max(1, N // 64)
-        VH = 2 if N < 64 else 1
-        KS = (8 // CG) * VH
-        KSt = min(taps, 2)
-        KSc = KS // KSt
-        assert cin % (4 * KSc) == 0, (kind, N, P, cin)
-        return dict(path=P_X4, PT=(P + 3) // 4, NT=1, PG=1, CG=CG, KSt=KSt, KSg=KSc)
     CT = N // 16
-    G16 = cin // 16
-    KS = max(1, 8 // CT)
-    KSt = 1 if rounds == 2 else min(taps, KS)      # a two-round image holds one time tap at a time
-    KSg = KS // KSt
-    while G16 % KSg:
-        KSg //= 2
-    return dict(path=P_X16, PT=(P + 15) // 16, NT=1, PG=1, CG=CT, KSt=KSt, KSg=KSg)
+    ptiles = (P + 15) // 16
+    rem = max(1, 8 // CT)
+    KSt = 1 if (rounds == 2 or kind == K_UP) else min(taps, rem)
+    rem //= KSt
+    KSg = 1
+    while kind != K_UP and KSg * 2 <= rem and (cin // 32) % (KSg * 2) == 0:
+        KSg *= 2
+    rem //= KSg
+    PG = 1
+    while PG * 2 <= rem and ptiles % (PG * 2) == 0:
+        PG *= 2
+    return dict(path=P_X16B, PT=ptiles // PG, NT=1, PG=PG, CG=CT, KSt=KSt, KSg=KSg)
 
 
-def make_img(kind, P, cin, rounds=1):
-    """LDS image geometry of a conv op: dict(taps, tap_b, pitch_b, pair, half_b, row0, bytes, zero[], seg_b[], seg_tk[])."""
+def make_img(kind, P, cin, rounds=1, fmt=1, csplit=1):
+    """LDS image geometry of a conv op: dict(fmt, plane_b, taps, tap_b, pitch_b, pair, half_b, row0, bytes, zero[], seg_b[], seg_tk[], seg_c0[]).
+    fmt 1: every row holds three bf16 planes (hi | mid | lo of the fp32 activations, x = hi + mid + lo exactly) of `rowch` channels
+    each, fmt 0: fp32 rows.  csplit 2 (1x1 layers only): the image holds one half of the input channels at a time (two rounds)."""
+    esz = 2 if fmt else 4
+    npl = 3 if fmt else 1
+    cimg = cin // csplit
+
+    def halo(byte0, nch):
+        # nch channels starting at byte0 (plane 0): one block if the planes are adjacent, else one per plane
+        return [(byte0 + p * plane_b, nch * esz // 16) for p in range(npl)] if plane_b != nch * esz else [(byte0, npl * nch * esz // 16)]
+
     if kind == K_IN:
-        pitch = (cin + 4) * 4
+        plane_b = cimg * esz
+        pitch = npl * plane_b + 16
         g = dict(taps=1, pitch_b=pitch, pair=0, half_b=0, row0=0, one=P * pitch, zero=[])
-        segs = [(0, 0, 0)]
+        segs = [(0, 0, 0, c * cimg) for c in range(csplit)]
     elif kind == K_EL:
-        pitch = (2 * cin + 4) * 4
-        half = cin * 4
+        plane_b = 2 * cin * esz
+        pitch = npl * plane_b + 16
+        half = cin * esz
         g = dict(taps=2, pitch_b=pitch, pair=1, half_b=half, row0=1, one=(P + 1) * pitch,
-                 zero=[(0, cin // 4), (P * pitch + half, cin // 4)])
-        segs = [(t, k, (k >> 1) * pitch + (k & 1) * half) for t in (0, 1) for k in (0, 1, 2)]
+                 zero=halo(0, cin) + halo(P * pitch + half, cin))
+        segs = [(t, k, (k >> 1) * pitch + (k & 1) * half, 0) for t in (0, 1) for k in (0, 1, 2)]
     elif kind == K_DL:
-        pitch = (cin + 4) * 4
+        plane_b = cin * esz
+        pitch = npl * plane_b + 16
         g = dict(taps=2, pitch_b=pitch, pair=0, half_b=0, row0=1, one=(P + 2) * pitch,
-                 zero=[(0, cin // 4), ((P + 1) * pitch, cin // 4)])
-        segs = [(t, k, k * pitch) for t in (0, 1) for k in (0, 1, 2)]
+                 zero=halo(0, cin) + halo((P + 1) * pitch, cin))
+        segs = [(t, k, k * pitch, 0) for t in (0, 1) for k in (0, 1, 2)]
     elif kind == K_DOWN:
-        pitch = (2 * cin + 4) * 4
-        half = cin * 4
-        g = dict(taps=1, pitch_b=pitch, pair=1, half_b=half, row0=0, one=(P + 1) * pitch, zero=[(P * pitch, cin // 4)])
-        segs = [(0, k, (k >> 1) * pitch + (k & 1) * half) for k in (0, 1, 2)]
+        plane_b = 2 * cin * esz
+        pitch = npl * plane_b + 16
+        half = cin * esz
+        g = dict(taps=1, pitch_b=pitch, pair=1, half_b=half, row0=0, one=(P + 1) * pitch, zero=halo(P * pitch, cin))
+        segs = [(0, k, (k >> 1) * pitch + (k & 1) * half, 0) for k in (0, 1, 2)]
     elif kind == K_UP:
         # Conv2DTranspose (1,3) stride 2 (proposed.py:260-265, SURVEY A.6): out[2i] = W0 x[i] + W2 x[i-1], out[2i+1] = W1 x[i]
-        pitch = (cin + 4) * 4
-        g = dict(taps=1, pitch_b=pitch, pair=0, half_b=0, row0=1, one=(P + 1) * pitch, zero=[(0, cin // 4)])
-        segs = [(0, 2, 0), (0, 0, pitch), (0, 1, pitch)]      # (t, kw, byte offset): two even segments, one odd
+        plane_b = cin * esz
+        pitch = npl * plane_b + 16
+        g = dict(taps=1, pitch_b=pitch, pair=0, half_b=0, row0=1, one=(P + 1) * pitch, zero=halo(0, cin))
+        segs = [(0, 2, 0, 0), (0, 0, pitch, 0), (0, 1, pitch, 0)]      # (t, kw, byte offset, first channel): two even segments, one odd
     else:
         raise ValueError(kind)
+    g["fmt"] = fmt
+    g["plane_b"] = plane_b if fmt else 0
     one = (g.pop("one") + 255) // 256 * 256
-    if g["taps"] == 2 and rounds == 2:
+    if csplit == 2:
+        assert kind == K_IN and rounds == 2
+        g["tap_b"] = 0
+        g["bytes"] = one
+        g["seg_b"] = [s[2] for s in segs]
+    elif g["taps"] == 2 and rounds == 2:
         g["tap_b"] = 0
         g["bytes"] = one
         segs = [s for s in segs if s[0] == 1] + [s for s in segs if s[0] == 0]     # current-frame tap first
@@ -221,6 +239,7 @@ def make_img(kind, P, cin, rounds=1):
             zs += [(t * g["tap_b"] + z[0], z[1]) for z in g["zero"]]
         g["zero"] = zs
     g["seg_tk"] = [s[0] * 4 + s[1] for s in segs]
+    g["seg_c0"] = [s[3] for s in segs]
     return g
 
 
@@ -242,40 +261,47 @@ def build(variant="lstm"):
                  ln=0, R=1, gc=0, rounds=1, nseg=0, seg_b=[], seg_tk=[], ex_b=0, w_off=0, p_off=0,
                  d0=None, d1=None, row_mul=1, row_add=0, fwd=None, img=None, nxt=-1, parts=[],
                  din=0, dout=0, x_b=0, x_pitch_b=0, x_cols=0, y_b=0, h_off=0, c_off=0, ldst=None, lw_off=0,
-                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0)
+                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0, x_fmt=0, x_plane_b=0)
         d.update(kw)
         ops.append(d)
         return d
 
     def conv_op(name, wkey, kind, side, idx, D, P, d0=None, d1=None, row_mul=1, row_add=0):
         cin, N, taps, kf, stride, ln, R, gc = conv_geom(kind, side, idx, D)
-        rounds = 2 if (kind == K_EL and cin == 128 and P >= 64) else 1     # both taps of these images do not fit LDS
+        # both taps of these images do not fit LDS: one tap at a time (the previous-frame tap is staged in mid-op)
+        rounds = 2 if (kind == K_EL and P >= 64 and cin * P >= 128 * 64) else 1
         o = new_op(type=T_CONV, name=name, wkey=wkey, kind=kind, P=P, cin=cin, N=N, taps=taps, kf=kf, stride=stride, ln=ln, R=R, gc=gc,
                    rounds=rounds, d0=d0, d1=d1, row_mul=row_mul, row_add=row_add)
         o.update(tiling(kind, N, P, cin, taps, rounds))
-        g = make_img(kind, P, cin, rounds)
+        ntot = N * (2 if kind == K_UP else 1)
+        x16 = o["path"] == P_X16B
+        if x16:
+            ks = o["KSt"] * o["KSg"]
+            ex = ks * P * (ntot + 4) * 4
+            o["ex_b"] = (SCR_B - ex) // 256 * 256
+        lim = o["ex_b"] if x16 else SCR_B
+        # the image as three bf16 planes where that fits LDS; the two largest stay fp32 and are split when they are read
+        g = make_img(kind, P, cin, rounds, fmt=1)
+        if g["bytes"] > lim:
+            assert not x16, name
+            g = make_img(kind, P, cin, rounds, fmt=0)
         o["img"] = g
         o["nseg"] = len(g["seg_b"])
         o["seg_b"] = g["seg_b"]
         o["seg_tk"] = g["seg_tk"]
-        ntot = N * (2 if kind == K_UP else 1)
         K = (3 * cin) if kind == K_UP else taps * kf * cin
         o["flops"] = 2 * P * (K * N if kind != K_UP else 3 * cin * N)
-        # int8 weights, MFMA fragment order: per wave task a run of "super-fragments" (4 fragments = one dwordx4 per lane)
-        r32 = o["path"] == P_R32
-        G = cin // (8 if r32 else 16)
+        # int8 weights in bf16-MFMA fragment order (a fragment = the 8 K values of a lane): per wave task a run of
+        # "super-fragments" (2 fragments = 16 bytes = one dwordx4 per lane)
         segw = 3 if kind == K_UP else len(g["seg_b"]) // o["KSt"]
-        nf = segw * (G // o["KSg"]) * o["NT"]
-        wtasks = o["CG"] * o["KSt"] * o["KSg"]
-        if o["path"] == P_X4:
-            nf = segw * (cin // o["KSg"] // 4)          # fragments (64 channels x 4 K) per wave
-            wtasks = 8
-        o["w_off"] = W.add(wtasks * ((nf + 3) // 4) * 256, "conv_w", wkey)
-        o["p_off"] = W.add(2 * ntot + 2 * gc + 1, "conv_p", wkey)      # bias | gamma | beta | alpha | per-channel weight scale
-        if o["path"] in (P_X16, P_X4):
-            ks = o["KSt"] * o["KSg"]
-            ex = ks * P * (ntot + 4) * 4
-            o["ex_b"] = (SCR_B - ex) // 256 * 256
+        if x16:
+            nf = segw * (cin // 32 // o["KSg"])
+            wtasks = o["CG"] * o["KSt"] * o["KSg"]
+        else:
+            nf = segw * (cin // 16) * o["NT"]
+            wtasks = o["CG"]
+        o["w_off"] = W.add(wtasks * ((nf + 1) // 2) * 256, "conv_w", wkey)
+        o["p_off"] = W.add(2 * ntot + 2 * gc + 1, "conv_p", wkey)      # bias | per-channel weight scale | gamma | beta | alpha
         return o
 
     # ---- op list --------------------------------------------------------------------------------
@@ -356,7 +382,9 @@ def build(variant="lstm"):
     def fwd_into(o, tgt, coff):
         g = tgt["img"]
         cur_tap = g["taps"] - 1
-        o["fwd"] = dict(on=1, base_b=cur_tap * g["tap_b"] + coff * 4, pitch_b=g["pitch_b"], pair=g["pair"], half_b=g["half_b"], row0=g["row0"])
+        esz = 2 if g["fmt"] else 4
+        o["fwd"] = dict(on=1, base_b=cur_tap * g["tap_b"] + coff * esz, pitch_b=g["pitch_b"], pair=g["pair"], half_b=g["half_b"], row0=g["row0"],
+                        fmt=g["fmt"], plane_b=g["plane_b"])
 
     for o in ops:
         if o["type"] not in (T_CONV, T_INPUT) or o["nxt"] < 0:
@@ -369,7 +397,7 @@ def build(variant="lstm"):
             coff = 64          # z -> channels [64,128) of the first up-sampling input; the central LSTM writes [0,64)
         fwd_into(o, tgt, coff)
     # the last sub-pixel conv of the network feeds the last CTFA (+ output conv): plain [256][64+4] rows at LDS 0
-    last_conv["fwd"] = dict(on=1, base_b=0, pitch_b=68 * 4, pair=0, half_b=0, row0=0)
+    last_conv["fwd"] = dict(on=1, base_b=0, pitch_b=68 * 4, pair=0, half_b=0, row0=0, fmt=0, plane_b=0)
 
     # LSTM / CTFA work in place on the image of the conv op that follows them
     for o in ops:
@@ -378,9 +406,11 @@ def build(variant="lstm"):
             g = tgt["img"]
             base = (g["taps"] - 1) * g["tap_b"] + g["row0"] * g["pitch_b"]
             assert not g["pair"]
-            o["x_b"] = base + o["x_cols"] * 4
+            o["x_b"] = base + o["x_cols"] * (2 if g["fmt"] else 4)
             o["y_b"] = base
             o["x_pitch_b"] = g["pitch_b"]
+            o["x_fmt"] = g["fmt"]
+            o["x_plane_b"] = g["plane_b"]
             if o["type"] == T_DDB:
                 assert g["bytes"] <= DDB_LDS_B and DDB_LDS_B + 17920 * 4 <= SCR_B
         if o["type"] == T_CTFA:
@@ -391,6 +421,9 @@ def build(variant="lstm"):
     # ---- staged parts of every image --------------------------------------------------------------
     def part(src, off, ld, rows, c4s, lds_b, row0, la, round2=0):
         return dict(src=src, off=off, ld=ld, rows=rows, c4s=c4s, lds_b=lds_b, row0=row0, la=la, round2=round2)
+
+    def esz(g):
+        return 2 if g["fmt"] else 4
 
     def la_of(rows, c4s):
         return 2 if (rows * c4s + 511) // 512 <= 2 else 1
@@ -408,7 +441,7 @@ def build(variant="lstm"):
                 parts.append(part(S_PREV, st_off(ct, i), cin, rows, cin // 4, 0, g["row0"], 1 if r2 else la_of(rows, cin // 4), r2))
                 if side:
                     sk = 64 if i == 1 else 32
-                    parts.append(part(S_CUR, st_off(ct, i) + sk, cin, rows, sk // 4, g["tap_b"] + sk * 4, g["row0"], la_of(rows, sk // 4)))
+                    parts.append(part(S_CUR, st_off(ct, i) + sk, cin, rows, sk // 4, g["tap_b"] + sk * esz(g), g["row0"], la_of(rows, sk // 4)))
                 o["parts"] = parts
             for j in range(1, D + 1):
                 o = lst[D + 1 + j]
@@ -419,27 +452,30 @@ def build(variant="lstm"):
                     # e_{D-j+1}, written this frame by strided conv D-j+1: visible after the LSTM's drain point,
                     # i.e. its loads may be issued by sub-pixel conv 1 at the earliest
                     la = 1 if j == 2 else la_of(rows, 8)
-                    parts.append(part(S_CUR, st_off(stg, j) + 32, 64, rows, 8, g["tap_b"] + 32 * 4, g["row0"], la))
+                    parts.append(part(S_CUR, st_off(stg, j) + 32, 64, rows, 8, g["tap_b"] + 32 * esz(g), g["row0"], la))
                 o["parts"] = parts
             if side and s >= 1:
                 o = ups[s]
                 g = o["img"]
                 rows = o["P"]
-                o["parts"] = [part(S_SCRATCH, A.scratch["upcat%d" % s] + 64, 128, rows, 16, 64 * 4, g["row0"], la_of(rows, 16))]
+                o["parts"] = [part(S_SCRATCH, A.scratch["upcat%d" % s] + 64, 128, rows, 16, 64 * esz(g), g["row0"], la_of(rows, 16))]
 
     # ---- checks -----------------------------------------------------------------------------------
     for o in ops:
         if o["type"] != T_CONV:
             continue
         g = o["img"]
-        lim = o["ex_b"] if o["path"] in (P_X16, P_X4) else SCR_B
+        lim = o["ex_b"] if o["path"] == P_X16B else SCR_B
         assert g["bytes"] <= lim, (o["name"], g["bytes"], lim)
         if o["nxt"] >= 0:
             assert ops[o["nxt"]]["img"]["bytes"] <= lim, (o["name"], "next image over the exchange buffer")
         assert len(o["parts"]) <= MAX_PARTS and len(g["zero"]) <= MAX_ZERO and o["nseg"] <= MAX_SEG
         tasks = o["PG"] * o["CG"] * o["KSt"] * o["KSg"]
-        assert tasks in (1, 2, 4, 8) or o["path"] == P_X4, (o["name"], tasks)
-        if o["path"] == P_R32:
+        assert tasks in (1, 2, 4, 8), (o["name"], tasks)
+        assert g["fmt"] == 1 or o["path"] == P_R32B, o["name"]
+        if o["path"] == P_X16B:
+            assert o["PT"] * o["PG"] * 16 >= o["P"] and (o["cin"] // 32) % o["KSg"] == 0 and o["nseg"] % o["KSt"] == 0
+        if o["path"] == P_R32B:
             assert o["P"] % (32 * o["PT"] * o["PG"]) == 0 and (not o["ln"] or o["NT"] * 32 == o["gc"])
     # Same-frame HBM hand-offs (skip connections): the loads of a staged part may only be issued after a
     # drain point (every wave has waited for its own stores) that follows the producing op.
@@ -473,17 +509,17 @@ def c_part(p):
 def c_img(o):
     g = o["img"]
     if g is None:
-        return "{0,0,0,0,0,0,0,0,{%s},0,{%s}}" % (",".join(["{0,0,0,0,0,0,0,0,0}"] * MAX_PARTS), ",".join(["{0,0}"] * MAX_ZERO))
+        return "{0,0,0,0,0,0,0,0,0,0,{%s},0,{%s}}" % (",".join(["{0,0,0,0,0,0,0,0,0}"] * MAX_PARTS), ",".join(["{0,0}"] * MAX_ZERO))
     parts = [c_part(p) for p in o["parts"]] + ["{0,0,0,0,0,0,0,0,0}"] * (MAX_PARTS - len(o["parts"]))
     zs = ["{%d,%d}" % z for z in g["zero"]] + ["{0,0}"] * (MAX_ZERO - len(g["zero"]))
-    return "{%d,%d,%d,%d,%d,%d,%d,%d,{%s},%d,{%s}}" % (g["taps"], g["tap_b"], g["pitch_b"], g["pair"], g["half_b"], g["row0"], g["bytes"],
-                                                       len(o["parts"]), ",".join(parts), len(g["zero"]), ",".join(zs))
+    return "{%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,{%s},%d,{%s}}" % (g["fmt"], g["plane_b"], g["taps"], g["tap_b"], g["pitch_b"], g["pair"], g["half_b"], g["row0"],
+                                                             g["bytes"], len(o["parts"]), ",".join(parts), len(g["zero"]), ",".join(zs))
 
 
 def c_fwd(f):
     if not f:
-        return "{0,0,0,0,0,0}"
-    return "{%d,%d,%d,%d,%d,%d}" % (f["on"], f["base_b"], f["pitch_b"], f["pair"], f["half_b"], f["row0"])
+        return "{0,0,0,0,0,0,0,0}"
+    return "{%d,%d,%d,%d,%d,%d,%d,%d}" % (f["on"], f["base_b"], f["pitch_b"], f["pair"], f["half_b"], f["row0"], f["fmt"], f["plane_b"])
 
 
 def c_dst(d):
@@ -506,13 +542,13 @@ def emit(A, W, ops):
         seg_b = ",".join(str(x) for x in pad(o["seg_b"], MAX_SEG))
         ldst = o["ldst"]
         row = ("{%d, /*conv*/ %d,%d,%d,%d,%d,%d,%d, %d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, %d,{%s}, %d, %d,%d, %s, %s, %d,%d, %s, %s, %d, "
-               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d},   // %d %s") % (
+               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
             o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
             c_fwd(o["fwd"]), c_img(o), o["nxt"],
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
-            1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["lw_off"],
+            1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["x_fmt"], o["x_plane_b"], o["lw_off"],
             o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["idx"], o["name"])
         L.append("  " + row)
     L.append("};")
@@ -564,7 +600,7 @@ def main():
             continue
         open(inc_path(variant), "w").write(inc)
         open(json_path(variant), "w").write(js)
-        r32 = [o for o in ops if o["type"] == T_CONV and o["path"] == P_R32]
+        r32 = [o for o in ops if o["type"] == T_CONV and o["path"] == P_R32B]
         print("%-8s ops %d (conv %d, of which %d on 32x32 tiles), arena %d floats (parity stride %d), blob %d floats" % (
             variant, len(ops), sum(o["type"] == T_CONV for o in ops), len(r32), A.floats, A.PS, W.cur))
     sys.exit(1 if stale else 0)
