@@ -324,6 +324,12 @@ class NutlsEngine:
             res.append({"layer": name.value.decode(), "flops": fl.value})
         return res
 
+    def weight_blob_bytes(self) -> int:
+        """Bytes of weights one launch reads: the fused kernel's packed blob (conv kernels int8), else the fp32 tensors."""
+        if self.mode == "fused":
+            return 4 * int(self._lib.nutls_fused_blob_floats(self.VARIANTS[self.variant]))
+        return 11_460_668 if self.variant == "lstm" else 11_500_000      # SURVEY.md section 8(d): fp32 weights of the graph
+
     def profile_fused(self) -> np.ndarray:
         """One fused-mode step with workgroup 0 time-stamping every op boundary; microseconds per op."""
         us = np.zeros(self._lib.nutls_fused_num_ops(self.VARIANTS[self.variant]), np.float64)
