@@ -90,7 +90,7 @@ struct StageStates {
   int h, c;
 };
 
-struct ConvLayerW { float *wpk, *wpk16, *bias, *gamma, *beta; float alpha; };
+struct ConvLayerW { float *wpk, *wpk16, *bias, *gamma, *beta; float alpha; float *wbf, *wscale; };
 struct LstmW { float *wxT, *whT, *bias, *wdT, *bd; int din, dout; };
 struct CtfaW { float *w1T, *b1, *w2T, *b2, *w2; };   // w2: [64][16] as stored (persistent kernel), w2T: [16][64]
 
@@ -127,6 +127,7 @@ struct Engine {
   float* upcat[6] = {nullptr};
   int offline = 0;       // > 0: offline / block handle for up to this many frames per call (arena slot 0 = carried state)
   std::vector<Launch> plan_off;   // plan[0] with 'previous frame' = one arena slot earlier
+  bool off_bf16 = false;          // block mode: convs on the bf16 matrix pipe where the container holds int8 kernels (NUTLS_OFFLINE_FP32=1: the fp32-MFMA kernels)
   float* zx = nullptr;   // [offline][84] LSTM input products of a block
   int ctfa_causal = 0;   // offline handles: 1 = true 32-frame causal average in the CTFA frequency branch (proposed.py:143-147)
   float* ta_hist = nullptr;   // [12 stages][31 + offline][64] time-attention history (causal mode)
@@ -279,6 +280,17 @@ static int prep_conv(Engine* e, const WeightMap& wm, const std::string& layer, c
   std::vector<float> bp(perm.size());
   for (size_t i = 0; i < perm.size(); ++i) bp[i] = b->data[perm[i]];
   if ((rc = upload(e, bp, &cw.bias))) return rc;
+  if (e->off_bf16) {
+    // block mode on an int8 container: the int8 payload as bf16 fragments + the per-channel scale (conv_bf16x3_kernel)
+    const std::vector<float> wb = pack_conv_weights_bf16(*w, perm, taps, sh.tt, sh.cin, sh.nt);
+    if (!wb.empty() && (w->scales.size() == 1 || static_cast<int>(w->scales.size()) == w->dims[0])) {
+      std::vector<float> sc(perm.size(), 0.f);
+      for (size_t i = 0; i < perm.size(); ++i)
+        if (perm[i] >= 0) sc[i] = w->scales.size() == 1 ? w->scales[0] : w->scales[perm[i]];
+      if ((rc = upload(e, wb, &cw.wbf))) return rc;
+      if ((rc = upload(e, sc, &cw.wscale))) return rc;
+    }
+  }
   if (sh.epi_ln) {
     const HostTensor* g = find(wm, layer + ".gamma", &err);
     const HostTensor* bt = find(wm, layer + ".beta", &err);
@@ -593,6 +605,7 @@ static void push_conv(Engine* e, std::vector<Launch>* plan, const std::string& w
   L.encoder_strided = enc_strided;
   ConvParams& p = L.conv;
   p.src0 = src0; p.src1 = src1; p.wpk = w.wpk; p.wpk16 = w.wpk16; p.bias = w.bias; p.gamma = w.gamma; p.beta = w.beta;
+  p.wbf = w.wbf; p.wscale = w.wscale; p.use_bf16 = 0;
   p.dst0 = dst0; p.dst1 = dst1; p.src_ld = src_ld; p.ld0 = ld0; p.ld1 = ld1;
   p.B = e->B; p.F_in = f_in; p.F_out = f_out; p.log2_fout = ilog2(f_out);
   p.row_mul = row_mul; p.row_add = row_add; p.alpha = w.alpha; p.sstride = static_cast<long long>(e->sstride);
@@ -1101,6 +1114,7 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
   e->B = batch;
   e->device = device;
   e->variant = variant;
+  e->off_bf16 = offline_frames > 0 && getenv("NUTLS_OFFLINE_FP32") == nullptr;      // (developer knob: block mode on the fp32-MFMA kernels)
   HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   int rc;
   if ((rc = prep_weights(e, wm))) return rc;
@@ -1234,6 +1248,7 @@ static int launch_block_range(Engine* e, size_t first, size_t last, int t0, int 
       case Launch::CONV:
         shc(L.conv.src0); shc(L.conv.src1); sh(L.conv.dst0); sh(L.conv.dst1);
         L.conv.B = n;
+        L.conv.use_bf16 = e->off_bf16 && L.conv.wbf != nullptr;
         err = launch_conv(L.ck, L.conv, s);
         break;
       case Launch::LSTM:

@@ -222,7 +222,9 @@ constexpr int ntask(const OpD& d) { return d.PG * d.CG * d.KSt * d.KSg; }
 constexpr int nparams(const OpD& d) { return 2 * ntot(d) + 2 * d.gc + 1; }      // bias | weight scale | gamma | beta | alpha
 constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 1) / 2; }             // "super-fragments": 2 int8 fragments = one dwordx4 per lane
 constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), d.path == P_R32B ? RING_SF_R32 : RING_SF); }
-constexpr int part_cls(const Part& p) { return p.round2 ? 3 : p.la; }
+// staging classes of a part: 1 loaded and stored by the op that builds the image, 2 loaded one op earlier (carried); second-round parts
+// of a two-round image (stored in the middle of the op that OWNS the image): 3 loaded at the start of that op, 4 loaded one op earlier
+constexpr int part_cls(const Part& p) { return p.round2 ? (p.la == 2 ? 4 : 3) : p.la; }
 // Who stages: the parts an op loads AND stores itself (classes 1 and 3) are handled by its "stager" threads -- all 512, or, in the
 // large-layer ops whose tiling leaves waves 4..7 without MFMA work, only those 256: the MFMA waves' weight refills then do not
 // queue behind the staging loads on the (in-order) memory counter, and the staging waves' waits cost the MFMA waves nothing.
@@ -243,7 +245,7 @@ constexpr int part_base(const Img& g, int cls, int k, int nthr) {
 }
 constexpr int nxt_of(int i) { return (i >= 0 && i < kNumOps) ? kOps[i].nxt : -1; }
 constexpr int nxt_regs(int i, int cls) { return nxt_of(i) >= 0 ? parts_regs(kOps[nxt_of(i)].img, cls, cls == 1 ? stg_threads(i) : THREADS) : 0; }
-constexpr int own_regs(int i, int cls) { return (i < kNumOps && kOps[i].type == T_CONV) ? parts_regs(kOps[i].img, cls, stg_threads(i)) : 0; }
+constexpr int own_regs(int i, int cls) { return (i < kNumOps && kOps[i].type == T_CONV) ? parts_regs(kOps[i].img, cls, cls == 4 ? THREADS : stg_threads(i)) : 0; }
 constexpr int ctfa_ni(const OpD& d) { return (d.F + 31) / 32; }
 constexpr int lstm_s0(const OpD& d) { return cmax(d.din / 16, 6); }      // carry slots of the gate weights (see lstm_op)
 constexpr int carry_w(int i) {
@@ -278,6 +280,7 @@ template <int I>
 struct Carry {
   f32x4 w[cmax(1, carry_w(I))];
   f32x4 p[cmax(1, nxt_regs(I, 2))];
+  f32x4 p4[cmax(1, own_regs(I, 4))];      // the previous-frame tap of op I's own two-round image, requested by op I-1 (all threads hold it)
   f32x4 prm;                   // conv ops: this thread's float4 of the epilogue parameter block (bias | scale | gamma | beta | alpha)
   // the same for op I+1, already requested by op I-1: weights are fetched TWO ops ahead (a fetch that misses L2 -- the
   // state tensors stream through it all the time -- takes longer than one small op)
@@ -287,6 +290,18 @@ struct Carry {
 
 // ---- staging: HBM tensor blocks -> registers -> LDS image -------------------------------------------------
 // (tid: index among the NTHR staging threads)
+// Who holds which item: the items of a part are dealt to the threads from the TOP of the workgroup downwards, and every
+// part starts one wavefront below the end of the part before it.  Between the two barriers of a small conv op the row-wise
+// epilogue keeps the LOWEST waves busy (a few dozen rows); the stores of the staged parts and the halo zeroing (middle
+// waves) then run beside it on other SIMDs instead of queueing behind it on wave 0.
+constexpr int part_shift(const Img& g, int cls, int k, int nthr) {
+  int sh = 0;
+  for (int kk = 0; kk < k; ++kk)
+    if (part_cls(g.parts[kk]) == cls) sh += (cmin(g.parts[kk].rows * g.parts[kk].c4s, nthr) + 63) / 64 * 64;
+  return sh % nthr;
+}
+template <int NTHR>
+__device__ __forceinline__ int stage_slot(int tid, int shift) { return (2 * NTHR - 1 - tid - shift) & (NTHR - 1); }
 template <int J, int CLS, int NTHR, int NR>
 __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR]) {
   if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 2)) {
@@ -297,9 +312,10 @@ __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR
       if constexpr (part_cls(p) == CLS) {
         constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s);
         const gcb_t src = p.src == S_PREV ? cx.sbp : (p.src == S_CUR ? cx.sbc : cx.sbs);
+        const int slot = stage_slot<NTHR>(tid, part_shift(g, CLS, K, NTHR));
         sfor<part_n(p, NTHR)>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
-          int q = tid + NTHR * i;
+          int q = slot + NTHR * i;
           if ((i + 1) * NTHR > items) q = q < items ? q : items - 1;      // lanes past the end re-load the last item
           const int row = q >> cs, c4 = q & (p.c4s - 1);
           r[base + i] = ldb(src, static_cast<unsigned>(p.off * 4 + row * (p.ld * 4) + c4 * 16));
@@ -317,9 +333,10 @@ __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
       constexpr Part p = g.parts[K];
       if constexpr (part_cls(p) == CLS) {
         constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s);
+        const int slot = stage_slot<NTHR>(tid, part_shift(g, CLS, K, NTHR));
         sfor<part_n(p, NTHR)>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
-          const int q = tid + NTHR * i;
+          const int q = slot + NTHR * i;
           const int row = q >> cs, c4 = q & (p.c4s - 1);
           const int a = p.lds_b + img_row_rt(g.pitch_b, g.pair, g.half_b, p.row0 + row) + c4 * (4 * esz_of(g.fmt));
           if ((i + 1) * NTHR <= items || FZ_LIKELY(q < items)) img_st4<g.fmt>(a, g.plane_b, r[base + i]);
@@ -328,27 +345,35 @@ __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
     });
   }
 }
-// halo blocks (float4 units) of image J: block K is zeroed by threads [t0_K, t0_K + n4_K) at the top of the workgroup
+// halo blocks (float4 units) of image J: block K is zeroed by threads [t0_K, t0_K + n4_K), one float4 per thread, ONE masked
+// store for all blocks (the block a thread belongs to is found with a compare + select per block: a branch per block cost
+// 0.4 us per op).  The halo threads start at wave 4: below them the row-wise epilogue, above them the staged parts.
 constexpr int zero_total(const Img& g) { int n = 0; for (int k = 0; k < g.nzero; ++k) n += g.zero[k].n4; return n; }
-constexpr int zero_start(const Img& g, int k) { int n = THREADS - zero_total(g); for (int kk = 0; kk < k; ++kk) n += g.zero[kk].n4; return n; }
+constexpr int zero_first(const Img& g) { return cmin(THREADS / 2, THREADS - zero_total(g)); }
+constexpr int zero_start(const Img& g, int k) { int n = zero_first(g); for (int kk = 0; kk < k; ++kk) n += g.zero[kk].n4; return n; }
 template <int J>
 __device__ __forceinline__ void zero_halos(int tid) {
   if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 1)) {
     constexpr Img g = kOps[J].img;
     static_assert(zero_total(g) <= THREADS, "halo blocks: one float4 per thread");
-    float zf = 0.f;
-    asm volatile("" : "+v"(zf));
-    const f32x4 z = {zf, zf, zf, zf};
-    sfor<g.nzero>([&](auto kk) {
-      constexpr int K = decltype(kk)::value;
-      constexpr int t0 = zero_start(g, K);
-      if (FZ_LIKELY(static_cast<unsigned>(tid - t0) < static_cast<unsigned>(g.zero[K].n4))) lds4(g.zero[K].lds_b + (tid - t0) * 16) = z;
-    });
+    if constexpr (g.nzero > 0) {
+      int delta = g.zero[0].lds_b - zero_start(g, 0) * 16;        // LDS address of thread t's float4 = delta + 16 t
+      sfor<g.nzero - 1>([&](auto kk) {
+        constexpr int K = decltype(kk)::value + 1;
+        delta = tid >= zero_start(g, K) ? g.zero[K].lds_b - zero_start(g, K) * 16 : delta;
+      });
+      float zf = 0.f;
+      asm volatile("" : "+v"(zf));
+      const f32x4 z = {zf, zf, zf, zf};
+      if (static_cast<unsigned>(tid - zero_first(g)) < static_cast<unsigned>(zero_total(g))) lds4(delta + tid * 16) = z;
+    }
   }
 }
 
 // A operand of the bf16 MFMAs: fragment `fr` (0 / 1) of a super-fragment = 8 int8 weights of this lane (exact in bf16) -> four
 // dwords of two bf16 each; the per-channel scale of the quantisation is applied to the accumulators in the epilogue.
+// (The blob stays int8: with the weights widened to bf16 on the host the conversion disappears from the loops -- 12 VALU per
+//  fragment -- but twice the bytes per op through L2 cost more than that: 0.385 -> 0.418 ms/step, DESIGN.md "tried and dropped".)
 __device__ __forceinline__ bf16x8 wfrag(const f32x4& sfrag, int fr) {
   const float x0 = sfrag[2 * fr], x1 = sfrag[2 * fr + 1];     // (scalar copies first: __builtin_bit_cast applied to `vec[j]` directly reads element 0, ROCm 7.2 clang)
   const int v0 = __builtin_bit_cast(int, x0), v1 = __builtin_bit_cast(int, x1);
@@ -510,14 +535,15 @@ __device__ __forceinline__ void build_next(int tid, const f32x4 (&p1)[N1], const
   zero_halos<J>(tid);
 }
 // the second-round part of an op's own two-round image (between the two barriers in the middle of the op)
-template <int I, int N3>
-__device__ __forceinline__ void store_round2(int tid, const f32x4 (&p3)[N3]) {
+template <int I, int N3, int N4>
+__device__ __forceinline__ void store_round2(int tid, const f32x4 (&p3)[N3], const f32x4 (&p4)[N4]) {
   constexpr int ST = stg_threads(I);
   if constexpr (ST == THREADS) {
     stage_store<I, 3, THREADS>(tid, p3);
   } else {
     if (__builtin_amdgcn_readfirstlane(tid >> 6) >= (THREADS - ST) / 64) stage_store<I, 3, ST>(tid - (THREADS - ST), p3);
   }
+  stage_store<I, 4, THREADS>(tid, p4);
 }
 
 // LDS address of (output row `row`, channel c) inside the forward target of op I (hi plane of a three-plane image)
@@ -640,7 +666,7 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
     static_assert(NF % 2 == 0, "two rounds: the same number of fragments per round");
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{});
     lds_barrier();
-    store_round2<I>(tid, p3);
+    store_round2<I>(tid, p3, c.p4);
     lds_barrier();
     half(std::integral_constant<int, NF / 2>{}, std::integral_constant<int, NF>{});
   } else {
@@ -734,7 +760,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
     static_assert(NF % 2 == 0, "two rounds: the same number of fragments per round");
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF / 2>{});
     lds_barrier();
-    store_round2<I>(tid, p3);
+    store_round2<I>(tid, p3, c.p4);
     lds_barrier();
     half(std::integral_constant<int, NF / 2>{}, std::integral_constant<int, NF>{});
   } else {
@@ -1047,6 +1073,7 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
     }
   }
   stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+  stage_load<I + 1, 4, THREADS>(cx, tid, n.p4);
 #pragma unroll
   for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
   n.prm = c.prm2;

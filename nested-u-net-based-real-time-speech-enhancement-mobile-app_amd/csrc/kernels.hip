@@ -183,6 +183,191 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(const ConvParams p) 
   }
 }
 
+// ================================================================================================
+//  The same tap-GEMM on the bf16 matrix pipe (offline / block mode, int8 containers): fp32 results from three bf16 MFMAs per
+//  product.  The weights are the container's int8 values (exact in bf16; the per-channel scale is applied to the fp32 sums
+//  in the epilogue), every fp32 activation is split ERROR-FREE into three bf16 pieces when it is staged into LDS
+//  (x = hi + mid + lo: 8 + 8 + 8 significand bits, see fused_step.hip), so every product w * piece is exact in fp32 and is
+//  accumulated in fp32 -- the quantity an fp32 FMA chain rounds, at 16/3 of the fp32 MFMA's rate.
+//  LDS row (stride 1) or row pair (stride 2): [plane hi | mid | lo][channel] bf16 + 16 bytes of padding (pitch = an odd
+//  number of 16-byte slots); lane (pos p, half h) reads the 8 channels 16 g + 8 h .. + 7 of a K step with one ds_read_b128
+//  per plane; v_mfma_f32_32x32x16_bf16 (A = weights of channel tile n, B = positions).
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned kb_bits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float kb_float(unsigned b) { return __builtin_bit_cast(float, b); }
+__device__ __forceinline__ unsigned kb_top16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // {top16(a), top16(b)}
+__device__ __forceinline__ void kb_split4(const f32x4& v, u32x2& hi, u32x2& mid, u32x2& lo) {
+  unsigned xb[4], rb[4], lb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = v[e];
+    xb[e] = kb_bits(x);
+    const float r = x - kb_float(xb[e] & 0xffff0000u);
+    rb[e] = kb_bits(r);
+    lb[e] = kb_bits(r - kb_float(rb[e] & 0xffff0000u));
+  }
+  hi = u32x2{kb_top16(xb[0], xb[1]), kb_top16(xb[2], xb[3])};
+  mid = u32x2{kb_top16(rb[0], rb[1]), kb_top16(rb[2], rb[3])};
+  lo = u32x2{kb_top16(lb[0], lb[1]), kb_top16(lb[2], lb[3])};
+}
+
+template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int G, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_bf16x3_kernel(const ConvParams p) {
+  constexpr int CC = CIN < 64 ? CIN : 64;
+  constexpr int NCH = CIN / CC;
+  constexpr int TP = 32 * NW;
+  constexpr int PLANE_B = ((STRIDE == 1) ? CC : 2 * CC) * 2;      // bytes of one plane of a pitch unit
+  constexpr int PITCH_B = 3 * PLANE_B + 16;
+  constexpr int R = NT / G;
+  static_assert(NT % G == 0, "groups must tile the channel tiles");
+  static_assert(CC % 16 == 0, "a K step is 16 channels");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int pl = lane & 31, h = lane >> 5;
+  const int F_out = p.F_out, log2f = p.log2_fout;
+  const int seg_len = F_out < TP ? F_out : TP;          // power of two
+  const int nseg = TP / seg_len;
+  const int RS = (STRIDE == 1) ? (seg_len + KF - 1) : (seg_len + (KF - 1) / 2);  // LDS rows(-pairs)/segment
+  const int LR = (STRIDE == 1) ? RS : 2 * RS;                                    // input rows staged/segment
+  const int P0 = blockIdx.x * TP;
+  const int total_pos = p.B << log2f;
+
+  const int ploc = wave * 32 + pl;
+  const int myseg = ploc / seg_len, myfl = ploc - myseg * seg_len;
+  const int lbase = (myseg * RS + myfl) * PITCH_B + 16 * h;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  const f32x4* wp = reinterpret_cast<const f32x4*>(p.wbf) + lane;      // one fragment = 8 bf16 = 16 bytes per lane
+  const int rows_total = nseg * LR;
+
+#pragma unroll 1
+  for (int t = 0; t < TT; ++t) {
+    const float* src = (TT == 2 && t == 1) ? p.src1 : p.src0;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (t + ch > 0) __syncthreads();   // all waves finished reading the previous phase
+      // ---------------- stage input rows -> LDS, split into the three planes ---------------------
+      for (int q = tid; q < rows_total * (CC / 4); q += 64 * NW) {
+        const int c4 = q % (CC / 4);
+        const int rr = q / (CC / 4);
+        const int sg = rr / LR, lr = rr - sg * LR;
+        const int pseg = P0 + sg * seg_len;
+        const int b = pseg >> log2f, f0 = pseg & (F_out - 1);
+        const int gr = STRIDE * f0 - PADL + lr;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < p.B && gr >= 0 && gr < p.F_in)
+          v = *reinterpret_cast<const f32x4*>(src + static_cast<size_t>(b) * p.sstride + static_cast<size_t>(gr) * p.src_ld + ch * CC + 4 * c4);
+        const int la = (STRIDE == 1) ? ((sg * RS + lr) * PITCH_B + 8 * c4)
+                                     : ((sg * RS + (lr >> 1)) * PITCH_B + (lr & 1) * (CC * 2) + 8 * c4);
+        u32x2 hi, mid, lo;
+        kb_split4(v, hi, mid, lo);
+        *reinterpret_cast<u32x2*>(ldsb + la) = hi;
+        *reinterpret_cast<u32x2*>(ldsb + la + PLANE_B) = mid;
+        *reinterpret_cast<u32x2*>(ldsb + la + 2 * PLANE_B) = lo;
+      }
+      __syncthreads();
+      // ---------------- MFMA over (frequency tap, K step of 16 channels) --------------------------
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf) {
+        const int koff = (STRIDE == 1) ? (kf * PITCH_B) : ((kf >> 1) * PITCH_B + (kf & 1) * (CC * 2));
+#pragma unroll
+        for (int g = 0; g < CC / 16; ++g) {
+          bf16x8 b3[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            b3[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ldsb + lbase + koff + 32 * g + q * PLANE_B));
+          bf16x8 a8[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) a8[n] = __builtin_bit_cast(bf16x8, wp[n * 64]);
+          wp += NT * 64;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[n], b3[q], acc[n], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---------------- epilogue: weight scale, bias (+ LayerNorm over the group's channels + PReLU), store ------
+  // accumulator register r of lane (pos, h) holds channel  tile*32 + 8*(r>>2) + 4*h + (r&3)
+  const int P = P0 + ploc;
+  const bool valid = P < total_pos;
+  const int b = P >> log2f, f = P & (F_out - 1);
+  const size_t soff = static_cast<size_t>(b) * p.sstride;
+  const size_t row0 = static_cast<size_t>(f) * p.row_mul + p.row_add;
+#pragma unroll
+  for (int gi = 0; gi < R; ++gi) {
+    float v[G][16];
+#pragma unroll
+    for (int tg = 0; tg < G; ++tg) {
+      const int n = gi * G + tg;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n * 32 + 8 * q + 4 * h);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.wscale + n * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[tg][4 * q + i] = acc[n][4 * q + i] * sc[i] + bb[i];
+      }
+    }
+    if (EPI_LN) {
+      constexpr float inv_n = 1.0f / (32 * G);
+      float s = 0.f;
+#pragma unroll
+      for (int tg = 0; tg < G; ++tg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[tg][r];
+      s += __shfl_xor(s, 32);
+      const float mean = s * inv_n;
+      float qv = 0.f;
+#pragma unroll
+      for (int tg = 0; tg < G; ++tg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[tg][r] -= mean;
+          qv += v[tg][r] * v[tg][r];
+        }
+      qv += __shfl_xor(qv, 32);
+      const float rstd = 1.0f / sqrtf(qv * inv_n + LN_EPS);
+#pragma unroll
+      for (int tg = 0; tg < G; ++tg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + tg * 32 + 8 * q + 4 * h);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + tg * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float y = v[tg][4 * q + i] * rstd * gm[i] + bt[i];
+            v[tg][4 * q + i] = y >= 0.f ? y : p.alpha * y;
+          }
+        }
+    }
+    if (valid) {
+      const size_t row = row0 + gi;
+#pragma unroll
+      for (int tg = 0; tg < G; ++tg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = {v[tg][4 * q], v[tg][4 * q + 1], v[tg][4 * q + 2], v[tg][4 * q + 3]};
+          const int c = tg * 32 + 8 * q + 4 * h;
+          *reinterpret_cast<f32x4*>(p.dst0 + soff + row * p.ld0 + c) = o;
+          if (p.dst1) *reinterpret_cast<f32x4*>(p.dst1 + soff + row * p.ld1 + c) = o;
+        }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 ConvShape conv_shape(ConvKind k) {
   switch (k) {
@@ -212,6 +397,17 @@ size_t conv_lds_bytes(ConvKind k, int f_out, int nw) {
   return static_cast<size_t>(nseg) * rs * pitch * sizeof(float);
 }
 
+static size_t conv_lds_bytes_bf16(ConvKind k, int f_out, int nw) {
+  const ConvShape s = conv_shape(k);
+  const int cc = s.cin < 64 ? s.cin : 64;
+  const int tp = 32 * nw;
+  const int seg_len = f_out < tp ? f_out : tp;
+  const int nseg = tp / seg_len;
+  const int pitch_b = 3 * (s.stride == 1 ? cc : 2 * cc) * 2 + 16;
+  const int rs = s.stride == 1 ? seg_len + s.kf - 1 : seg_len + (s.kf - 1) / 2;
+  return static_cast<size_t>(nseg) * rs * pitch_b;
+}
+
 int conv_pick_nw(ConvKind, int B, int f_out) {
   // 4-wave workgroups (128 positions) once there are enough positions to give every CU several
   // workgroups; single-wave workgroups otherwise so small layers spread over more CUs.
@@ -220,9 +416,32 @@ int conv_pick_nw(ConvKind, int B, int f_out) {
 
 constexpr int kMaxDevices = 64;
 
+template <class K>
+static hipError_t launch_conv_variant(K kern, size_t lds, unsigned grid, unsigned threads, const ConvParams& p, hipStream_t s) {
+  // raise the dynamic-LDS cap once per instantiation AND device (function attributes are per device)
+  static std::atomic<size_t> lds_cap[kMaxDevices] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<size_t>& cap = lds_cap[dev >= 0 && dev < kMaxDevices ? dev : 0];
+  if (lds > 64 * 1024 && (lds > cap.load(std::memory_order_relaxed) || dev >= kMaxDevices)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    cap.store(lds, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, p);
+  return hipGetLastError();
+}
+
 template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int G>
 static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) {
   const int nw = conv_pick_nw(k, p.B, p.F_out);
+  if (p.use_bf16 && p.wbf && p.wscale) {      // block mode on an int8 container: the bf16-pipe kernel
+    const size_t ldsb = conv_lds_bytes_bf16(k, p.F_out, nw);
+    const long long totalb = static_cast<long long>(p.B) * p.F_out;
+    if (nw == 4)
+      return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4>, ldsb, static_cast<unsigned>((totalb + 127) / 128), 256, p, s);
+    return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1>, ldsb, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
+  }
   const size_t lds = conv_lds_bytes(k, p.F_out, nw);
   const long long total = static_cast<long long>(p.B) * p.F_out;
   if (nw == 4) {

@@ -38,6 +38,9 @@ struct ConvParams {
   const float* src1;   // time tap 1 (current frame)
   const float* wpk;    // weights in MFMA fragment order (pack_conv_weights)
   const float* wpk16;  // the same weights in 16x16x4 fragment order (pack_conv_weights16; persistent kernel, F_out <= 16)
+  const float* wbf;    // int8 containers: the int8 weights widened to bf16 in 32x32x16 fragment order (pack_conv_weights_bf16), else null
+  const float* wscale; // ... and their per-output-channel scale, packed channel order [32*NT]
+  int use_bf16;        // launch the bf16-pipe kernel (block mode; needs wbf / wscale)
   const float* bias;   // [32*NT]  packed channel order
   const float* gamma;  // [32*G]   LayerNorm scale (EPI_LN only)
   const float* beta;   // [32*G]
@@ -243,6 +246,8 @@ std::vector<float> pack_conv_weights(const HostTensor& w, const std::vector<int>
                                      int tt, int cin, int nt);
 // Same, for v_mfma_f32_16x16x4_f32 tiles: fragment (16-channel K group g, 16-row channel tile rt), lane l
 // holds W[16 rt + (l & 15)][16 g + 4 (l >> 4) + j], j = 0..3.  Order [t][chunk][kf][g16][rt][lane][4].
+std::vector<float> pack_conv_weights_bf16(const HostTensor& w, const std::vector<int>& perm,
+                                          const std::vector<std::pair<int, int>>& taps_per_t, int tt, int cin, int nt);
 std::vector<float> pack_conv_weights16(const HostTensor& w, const std::vector<int>& perm,
                                        const std::vector<std::pair<int, int>>& taps_per_t,
                                        int tt, int cin, int nt32);

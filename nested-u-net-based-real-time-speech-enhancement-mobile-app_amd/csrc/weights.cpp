@@ -104,6 +104,40 @@ std::vector<float> pack_conv_weights(const HostTensor& w, const std::vector<int>
   return out;
 }
 
+// The int8 payload of the container widened to bf16 (exact), in the streaming order of conv_bf16x3_kernel:
+//   for t for chunk for tap for g in [0,CC/16) for nt for lane for j in [0,8):
+//     n' = nt*32 + (lane & 31),  c = chunk*CC + g*16 + 8*(lane >> 5) + j,  value = bf16(Q[perm[n']][t][tap.kw][c])
+// Returned as floats holding two bf16 each (empty if the tensor has no int8 payload).
+std::vector<float> pack_conv_weights_bf16(const HostTensor& w, const std::vector<int>& perm,
+                                          const std::vector<std::pair<int, int>>& taps_per_t, int tt, int cin, int nt) {
+  if (w.q.size() != w.data.size() || w.q.empty()) return {};
+  const int th = w.dims[1], kw = w.dims[2], wc = w.dims[3];
+  const int cc = cin < 64 ? cin : 64, nch = cin / cc, kf = static_cast<int>(taps_per_t.size());
+  std::vector<uint16_t> out(static_cast<size_t>(tt) * nch * kf * (cc / 16) * nt * 64 * 8);
+  size_t o = 0;
+  for (int t = 0; t < tt; ++t)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int k = 0; k < kf; ++k)
+        for (int g = 0; g < cc / 16; ++g)
+          for (int n = 0; n < nt; ++n)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int np = n * 32 + (lane & 31);
+                const int c = ch * cc + g * 16 + 8 * (lane >> 5) + j;
+                const int src_t = (tt == 1) ? taps_per_t[k].first : t;
+                const int src_k = taps_per_t[k].second;
+                float v = 0.f;
+                if (src_k >= 0 && np < static_cast<int>(perm.size()) && perm[np] >= 0)
+                  v = static_cast<float>(w.q[((static_cast<size_t>(perm[np]) * th + src_t) * kw + src_k) * wc + c]);
+                uint32_t bits;
+                std::memcpy(&bits, &v, 4);            // |q| <= 128: exact in bf16
+                out[o++] = static_cast<uint16_t>(bits >> 16);
+              }
+  std::vector<float> packed(out.size() / 2);
+  std::memcpy(packed.data(), out.data(), out.size() * 2);
+  return packed;
+}
+
 std::vector<float> pack_conv_weights16(const HostTensor& w, const std::vector<int>& perm,
                                        const std::vector<std::pair<int, int>>& taps_per_t,
                                        int tt, int cin, int nt32) {

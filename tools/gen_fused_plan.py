@@ -438,7 +438,9 @@ def build(variant="lstm"):
                 rows, cin = f0 >> (i - 1), o["cin"]
                 parts = []
                 r2 = 1 if o["rounds"] == 2 else 0
-                parts.append(part(S_PREV, st_off(ct, i), cin, rows, cin // 4, 0, g["row0"], 1 if r2 else la_of(rows, cin // 4), r2))
+                # (two-round image: the previous-frame tap is stored in the middle of the op; its loads are issued one op earlier -- no
+                #  same-frame hazard, it is last frame's data -- so that the second round does not wait for HBM)
+                parts.append(part(S_PREV, st_off(ct, i), cin, rows, cin // 4, 0, g["row0"], 2 if r2 else la_of(rows, cin // 4), r2))
                 if side:
                     sk = 64 if i == 1 else 32
                     parts.append(part(S_CUR, st_off(ct, i) + sk, cin, rows, sk // 4, g["tap_b"] + sk * esz(g), g["row0"], la_of(rows, sk // 4)))

@@ -7,9 +7,9 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.match(r"void nutls::conv_mfma_kernel<(.*?)>\(", name)
+    m = re.match(r"void nutls::(conv_mfma_kernel|conv_bf16x3_kernel)<(.*?)>\(", name)
     if m:
-        return "conv_mfma_kernel<%s>" % m.group(1).replace(" ", "")
+        return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
     return re.sub(r"\(.*", "", name).replace("void ", "")
 
 
