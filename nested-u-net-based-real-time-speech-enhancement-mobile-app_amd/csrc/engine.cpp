@@ -985,11 +985,12 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   return NUTLS_OK;
 }
 
-static int run_fused(Engine* e, int par, hipStream_t s, bool prof) {
+// (mag_in / mag_out: the caller's device buffers, read by the input layer and written by the last op directly -- no staging copies)
+static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* mag_in = nullptr, float* mag_out = nullptr) {
   if (!e->fz_blob) return fail(NUTLS_ERR_ARG, "fused mode is not available for this handle");
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
-  hipError_t err = (base ? launch_fused_base_step : launch_fused_step)(e->arena, static_cast<long long>(e->sstride), e->fz_blob, e->io_in,
-                                                                       e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
+  hipError_t err = (base ? launch_fused_base_step : launch_fused_step)(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
+                                                                       mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
                                                                        base ? e->d_ddb : nullptr, static_cast<int>(e->steps & 0x3fffffff), e->B, s);
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("fused step launch: ") + hipGetErrorString(err));
   if (base) e->d_step_stale = true;      // ring position of the dilated-dense history went in by value: one launch per step
@@ -1429,10 +1430,11 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = static_cast<size_t>(e->B) * NUTLS_BINS * sizeof(float);
-  if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
+  const bool direct = e->mode == 3;      // the fused kernel takes the caller's buffers as they are
+  if (!direct && mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
   const int par = e->next_parity;
   if (e->mode == 3) {
-    int rc = run_fused(e, par, s, false);
+    int rc = run_fused(e, par, s, false, mag_in, mag_out);
     if (rc) return rc;
   } else if (e->mode == 2) {
     int rc = sync_step_counter(e, s);
@@ -1447,7 +1449,7 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
     if (!rc) rc = run_plan(e, par, s);
     if (rc) return rc;
   }
-  if (mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
+  if (!direct && mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
   e->next_parity = 1 - par;
   e->steps += 1;
   return NUTLS_OK;

@@ -48,7 +48,8 @@
 // FZ_ABL: timing experiments only (tools/exp): bit mask of parts that are compiled OUT -- the results are garbage, the step time
 // tells what the part costs.  1 halo zeroing, 2 staging (HBM -> image), 4 HBM stores of the row-wise epilogue, 16 LayerNorm / PReLU
 // of the row-wise epilogue, 32 LSTM body, 64 CTFA body, 128 workgroup barriers, 256 MFMA loops of the 16x16x32 path, 512 partial-sum
-// reads of the row-wise epilogue, 2048 weight prefetch of the conv ops (MFMAs kept, on garbage), 4096 MFMA loops of the 32x32x16 path
+// reads of the row-wise epilogue, 2048 weight prefetch of the conv ops (MFMAs kept, on garbage), 4096 MFMA loops of the 32x32x16 path,
+// 8192 previous-frame tap staging of the strided convs (the upper bound of carrying that tap as a partial sum instead)
 #ifndef FZ_ABL
 #define FZ_ABL 0
 #endif
@@ -309,7 +310,7 @@ __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR
     sfor<g.nparts>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
       constexpr Part p = g.parts[K];
-      if constexpr (part_cls(p) == CLS) {
+      if constexpr (part_cls(p) == CLS && !((FZ_ABL & 8192) && p.src == S_PREV && kOps[J].kind == K_EL)) {
         constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s);
         const gcb_t src = p.src == S_PREV ? cx.sbp : (p.src == S_CUR ? cx.sbc : cx.sbs);
         const int slot = stage_slot<NTHR>(tid, part_shift(g, CLS, K, NTHR));
@@ -331,7 +332,7 @@ __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
     sfor<g.nparts>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
       constexpr Part p = g.parts[K];
-      if constexpr (part_cls(p) == CLS) {
+      if constexpr (part_cls(p) == CLS && !((FZ_ABL & 8192) && p.src == S_PREV && kOps[J].kind == K_EL)) {
         constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s);
         const int slot = stage_slot<NTHR>(tid, part_shift(g, CLS, K, NTHR));
         sfor<part_n(p, NTHR)>([&](auto ii) {

@@ -35,6 +35,22 @@ def test_block_mode_equals_golden_and_streaming(clip, max_frames):
     assert rms(got[:40], stream) < 1e-6
 
 
+def test_block_mode_bf16_pipe_equals_the_fp32_mfma_kernels(clip, monkeypatch):
+    """The block mode's convs run on the bf16 matrix pipe (conv_bf16x3_kernel: int8 weights widened to bf16, activations
+    split error-free into three bf16 pieces -- every product exact, fp32 accumulation); NUTLS_OFFLINE_FP32=1 keeps the
+    fp32-MFMA kernels.  Same function, summation order apart."""
+    off = NutlsOffline(max_frames=128)
+    got = off.process(clip["mags_in"][:128])
+    off.close()
+    monkeypatch.setenv("NUTLS_OFFLINE_FP32", "1")
+    ref = NutlsOffline(max_frames=128)
+    want = ref.process(clip["mags_in"][:128])
+    ref.close()
+    assert rms(got, want) < 1e-6
+    assert rms(got, clip["mags_out"][:128]) < 2e-5 and rms(want, clip["mags_out"][:128]) < 2e-5
+    assert not np.array_equal(got, want)        # (two different kernels did run)
+
+
 def test_state_carries_between_calls_and_reset_restarts(clip):
     off = NutlsOffline(max_frames=32)
     a = off.process(clip["mags_in"][:32])
