@@ -100,6 +100,13 @@ struct Engine {
   long long steps = 0;           // frames processed (ring position of the baseline's dilated-dense history)
   int* d_step = nullptr;         // the same counter on the device (read by the per-layer / plan-interpreter kernels)
   bool d_step_stale = false;     // fused-mode steps take `steps` by value and leave the device counter behind
+  // carried partial sums of the fused kernel's two-tap convs (S = W[tap 0] x, fused_plan.hpp OpD::ys): two blocks in every stream's
+  // arena slice; stale after the conv-input states were written from outside the fused kernel -- rebuilt before the next fused step
+  float* ysum = nullptr;
+  YsOp* d_ys_ops = nullptr;
+  float* d_ys_w = nullptr;
+  int n_ys_ops = 0;
+  bool ys_dirty = false;
   std::vector<DdbParams> ddbs;   // baseline: the 13 dilated-dense blocks (host copy, per parity identical)
   DdbParams* d_ddb = nullptr;
   struct DdbStates { int in, blk[6], out; };
@@ -958,8 +965,9 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
     ok = st.name_prev == fused_state_name(v, i) && st.buf[0] - e->arena == fused_state_off(v, i) &&
          st.buf[1] - st.buf[0] == (ring ? 0 : fused_parity_stride(v));
   }
-  const float* scratch[10] = {e->t_inlayer, e->t_y, e->t_d, e->t_up, e->upcat[0], e->upcat[1], e->upcat[2], e->upcat[3], e->upcat[4], e->upcat[5]};
-  for (int i = 0; ok && i < fused_num_scratch(v) && i < 10; ++i) ok = scratch[i] - e->arena == fused_scratch_off(v, i);
+  const float* scratch[11] = {e->t_inlayer, e->t_y, e->t_d, e->t_up, e->upcat[0], e->upcat[1], e->upcat[2], e->upcat[3], e->upcat[4], e->upcat[5], e->ysum};
+  ok = ok && fused_num_scratch(v) == 11 && e->ysum && e->ysum - e->arena == fused_ys_off(v);
+  for (int i = 0; ok && i < fused_num_scratch(v) && i < 11; ++i) ok = scratch[i] - e->arena == fused_scratch_off(v, i);
   if (ok && v == NUTLS_VARIANT_BASELINE) ok = e->d_ddb != nullptr && e->ddbs.size() == 26;
   if (!ok) return fail(NUTLS_ERR_ARG, "fused plan (tools/gen_fused_plan.py) does not match the engine's arena layout");
   std::vector<float> blob;
@@ -982,6 +990,30 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   HIP_TRY(hipMemset(q, 0, (fused_num_ops(v) * 9 + 1) * sizeof(unsigned long long)));
   e->fz_prof = static_cast<unsigned long long*>(q);
   HIP_TRY(v == NUTLS_VARIANT_BASELINE ? fused_base_step_set_attributes() : fused_step_set_attributes());
+  // the table for rebuilding the carried partial sums (ysum_refresh)
+  std::vector<YsOp> yops;
+  std::vector<float> yw;
+  if (!fused_ys_table(v, wm, &yops, &yw, &err)) return fail(NUTLS_ERR_WEIGHTS, "fused plan: " + err);
+  void* yo = nullptr;
+  HIP_TRY(hipMalloc(&yo, yops.size() * sizeof(YsOp)));
+  e->allocs.push_back(yo);
+  HIP_TRY(hipMemcpy(yo, yops.data(), yops.size() * sizeof(YsOp), hipMemcpyHostToDevice));
+  e->d_ys_ops = static_cast<YsOp*>(yo);
+  e->n_ys_ops = static_cast<int>(yops.size());
+  int rc = upload(e, yw, &e->d_ys_w);
+  if (rc) return rc;
+  return NUTLS_OK;
+}
+
+// Before a fused step: the partial sums the step reads (the block of the parity it does not write) from the conv-input states it
+// would have read as the previous frame -- if anything but the fused kernel wrote those since (ys_dirty).
+static int ysum_refresh(Engine* e, int par, hipStream_t s) {
+  if (!e->ys_dirty || !e->n_ys_ops) return NUTLS_OK;
+  const int v = e->variant;
+  const int x_block = par ? 0 : fused_parity_stride(v);                       // the `prev` parity of this step
+  const int ys_block = fused_ys_off(v) + (par ? 0 : fused_ys_block(v));       // the block this step reads
+  HIP_TRY(launch_ysum_refresh(e->arena, static_cast<long long>(e->sstride), x_block, ys_block, e->d_ys_ops, e->d_ys_w, e->n_ys_ops, e->B, s));
+  e->ys_dirty = false;
   return NUTLS_OK;
 }
 
@@ -989,6 +1021,7 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
 static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* mag_in = nullptr, float* mag_out = nullptr) {
   if (!e->fz_blob) return fail(NUTLS_ERR_ARG, "fused mode is not available for this handle");
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
+  if (int rc = ysum_refresh(e, par, s)) return rc;
   hipError_t err = (base ? launch_fused_base_step : launch_fused_step)(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
                                                                        mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
                                                                        base ? e->d_ddb : nullptr, static_cast<int>(e->steps & 0x3fffffff), e->B, s);
@@ -1137,6 +1170,7 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
   slot_reserve(e, 256 * 64, &e->t_d);
   slot_reserve(e, 256 * 128, &e->t_up);
   for (int s = 0; s < 6; ++s) slot_reserve(e, static_cast<size_t>(kDecoder[s].f0 / 2) * 128, &e->upcat[s]);
+  if (offline_frames == 0) slot_reserve(e, static_cast<size_t>(2) * fused_ys_block(variant), &e->ysum);      // (streaming handles: the fused kernel's carried partial sums)
   if ((rc = arena_commit(e))) return rc;
   build_plan(e, 0);
   build_plan(e, 1);
@@ -1437,14 +1471,17 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
     int rc = run_fused(e, par, s, false, mag_in, mag_out);
     if (rc) return rc;
   } else if (e->mode == 2) {
+    e->ys_dirty = true;      // (every mode but the fused kernel leaves its carried partial sums behind)
     int rc = sync_step_counter(e, s);
     if (!rc) rc = run_persistent(e, par, s, false);
     if (rc) return rc;
   } else if (e->mode == 1) {
+    e->ys_dirty = true;
     int rc = sync_step_counter(e, s);
     if (rc) return rc;
     HIP_TRY(hipGraphLaunch(e->gexec[par], s));
   } else {
+    e->ys_dirty = true;
     int rc = sync_step_counter(e, s);
     if (!rc) rc = run_plan(e, par, s);
     if (rc) return rc;
@@ -1578,6 +1615,7 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
   if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), const_cast<float*>(host_buf), false, 0);
+  e->ys_dirty = true;      // a conv-input state changed under the fused kernel's carried partial sums: rebuilt before its next step
   if (st->ring_d > 1) {
     std::vector<float> tmp(host_buf, host_buf + n_floats);
     rotate_ring(e, *st, tmp.data(), false);
@@ -1757,6 +1795,7 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   std::vector<hipEvent_t> ev(plan.size() + 1);
   for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
   if (int rc = sync_step_counter(e, e->stream)) return rc;
+  e->ys_dirty = true;
   HIP_TRY(hipEventRecord(ev[0], e->stream));
   for (size_t i = 0; i < plan.size(); ++i) {
     HIP_TRY(run_launch(plan[i], e->stream));
@@ -1851,6 +1890,7 @@ int nutls_profile_persistent(nutls_handle* h, double* us, int n) {
   if (n != n_ops) return fail(NUTLS_ERR_ARG, "nutls_profile_persistent: n must equal nutls_launches_per_step");
   HIP_TRY(hipSetDevice(e->device));
   int rc = sync_step_counter(e, e->stream);
+  e->ys_dirty = true;
   if (!rc) rc = run_persistent(e, par, e->stream, true);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(e->stream));

@@ -51,6 +51,11 @@ int fused_state_off(int variant, int i) { return FZ_BY_VARIANT(fused_state_off(i
 int fused_num_scratch(int variant) { return FZ_BY_VARIANT(fused_num_scratch()); }
 const char* fused_scratch_name(int variant, int i) { return FZ_BY_VARIANT(fused_scratch_name(i)); }
 int fused_scratch_off(int variant, int i) { return FZ_BY_VARIANT(fused_scratch_off(i)); }
+int fused_ys_block(int variant) { return FZ_BY_VARIANT(fused_ys_block()); }
+int fused_ys_off(int variant) { return FZ_BY_VARIANT(fused_ys_off()); }
+bool fused_ys_table(int variant, const WeightMap& wm, std::vector<YsOp>* ops, std::vector<float>* w, std::string* err) {
+  return FZ_BY_VARIANT(fused_ys_table(wm, ops, w, err));
+}
 int fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err) {
   return FZ_BY_VARIANT(fused_pack_blob(wm, out, err));
 }

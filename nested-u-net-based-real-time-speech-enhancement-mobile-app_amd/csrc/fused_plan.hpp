@@ -74,6 +74,12 @@ struct OpD {
   // ---- all -------------------------------------------------------------------------------------
   int drain;                               // every wave drains its memory counter before the op's last barrier
   int bidx;                                // T_DDB (baseline variant): which of the 13 dilated-dense bottlenecks (uses x_cols, y_b, x_pitch_b)
+  // ---- carried partial sums (two-tap convs) ------------------------------------------------------
+  int ys;                                  // 1: y_t = W[tap 1] x_t + S_{t-1} with S_t = W[tap 0] x_t: the image holds x_t only, S travels through HBM as
+                                           // P x N fp32 ([pos][packed channel], unscaled integer-weight sums), block kYsOff + parity * kYsBlock
+  int ys_off;                              // float offset of this op's sums inside a block
+  int xs_off, xs_ld;                       // the conv's input state tensor [rows][xs_ld] (written for the ABI, never read by the kernel; the
+                                           // host rebuilds S from it after nutls_state_set / a step of another mode)
 };
 constexpr int DDB_LDS_B = 64 * 1024;       // LDS scratch of a dilated-dense block op (17 920 floats), above the image it completes
 

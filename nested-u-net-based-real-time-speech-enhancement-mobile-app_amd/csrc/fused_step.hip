@@ -80,6 +80,7 @@ constexpr int THREADS = 512;
 
 struct Ctx {
   gcb_t sbp, sbc, sbs, wb;     // this stream's `prev` / `cur` state bases, arena slice base; weight blob
+  gcb_t ysr, ysw;              // carried partial sums of the two-tap convs: last frame's block (read), this frame's (written)
   gcf_t io_in;                 // this stream's 256 input magnitudes
   gf_t io_out;
   unsigned long long* prof;
@@ -216,10 +217,17 @@ constexpr int ntot(const OpD& d) { return d.N * (is_up(d) ? 2 : 1); }
 constexpr int ksl(const OpD& d) { return d.KSt * d.KSg; }                                        // K slices (X16B)
 constexpr int kgroups(const OpD& d) { return d.cin / (d.path == P_R32B ? 16 : 32); }            // K steps (one MFMA deep) per segment
 constexpr int gw(const OpD& d) { return kgroups(d) / d.KSg; }                                     // ... per wave
-constexpr int segw(const OpD& d) { return is_up(d) ? 3 : d.nseg / d.KSt; }                       // segments per wave
+// two-tap convs (d.ys): the image holds the current frame only; K segments 0..2 carry the weights of time tap 0 (their sums go
+// to the NEXT frame), 3..5 those of tap 1 (this frame).  16x16 tiles: the K slice's ks_t selects the tap (KSt 2), or a wave owns
+// both (KSt 1, two accumulator sets); 32x32 tiles: waves 0..3 own tap 0, waves 4..7 tap 1 (r32_two).
+constexpr bool r32_two(const OpD& d) { return d.path == P_R32B && d.ys != 0; }
+constexpr bool x16_both(const OpD& d) { return d.path == P_X16B && d.ys != 0 && d.KSt == 1; }
+constexpr int segw(const OpD& d) { return is_up(d) ? 3 : (r32_two(d) ? 3 : d.nseg / d.KSt); }     // segments per wave
 // weight fragments (one A operand: the 8 K values of a lane) per wave
 constexpr int conv_nf(const OpD& d) { return segw(d) * gw(d) * d.NT; }
-constexpr int ntask(const OpD& d) { return d.PG * d.CG * d.KSt * d.KSg; }
+constexpr int ntask(const OpD& d) { return d.PG * d.CG * d.KSt * d.KSg * (r32_two(d) ? 2 : 1); }
+constexpr int ex_slices(const OpD& d) { return ksl(d) * (x16_both(d) ? 2 : 1); }                  // slices of the exchange buffer (X16B)
+constexpr int ex_group(const OpD& d) { return d.ys ? ex_slices(d) / 2 : ex_slices(d); }           // ... that add up to one result
 constexpr int nparams(const OpD& d) { return 2 * ntot(d) + 2 * d.gc + 1; }      // bias | weight scale | gamma | beta | alpha
 constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 1) / 2; }             // "super-fragments": 2 int8 fragments = one dwordx4 per lane
 constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), d.path == P_R32B ? RING_SF_R32 : RING_SF); }
@@ -231,7 +239,7 @@ constexpr int part_cls(const Part& p) { return p.round2 ? (p.la == 2 ? 4 : 3) : 
 // queue behind the staging loads on the (in-order) memory counter, and the staging waves' waits cost the MFMA waves nothing.
 // Class-2 parts (loaded one op before they are stored) stay with all threads: both ops must agree on who holds what.
 constexpr int stg_threads(int i) {
-  return (i >= 0 && i < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32B && kOps[i].PG * kOps[i].CG == 4) ? 256 : THREADS;
+  return (i >= 0 && i < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32B && kOps[i].PG * kOps[i].CG == 4 && !kOps[i].ys) ? 256 : THREADS;
 }
 constexpr int part_n(const Part& p, int nthr) { return (p.rows * p.c4s + nthr - 1) / nthr; }
 constexpr int parts_regs(const Img& g, int cls, int nthr) {
@@ -248,6 +256,13 @@ constexpr int nxt_of(int i) { return (i >= 0 && i < kNumOps) ? kOps[i].nxt : -1;
 constexpr int nxt_regs(int i, int cls) { return nxt_of(i) >= 0 ? parts_regs(kOps[nxt_of(i)].img, cls, cls == 1 ? stg_threads(i) : THREADS) : 0; }
 constexpr int own_regs(int i, int cls) { return (i < kNumOps && kOps[i].type == T_CONV) ? parts_regs(kOps[i].img, cls, cls == 4 ? THREADS : stg_threads(i)) : 0; }
 constexpr int ctfa_ni(const OpD& d) { return (d.F + 31) / 32; }
+// registers of last frame's partial sums an op adds in its epilogue: row-wise epilogue: one float4 per item and pass; 32x32 tiles: the
+// accumulator layout (4 float4 per tile)
+constexpr int yp_regs(int i) {
+  if (i < 0 || i >= kNumOps || kOps[i].type != T_CONV || !kOps[i].ys) return 0;
+  const OpD& d = kOps[i];
+  return d.path == P_R32B ? d.PT * d.NT * 4 : (d.P * ntot(d) / 4 + THREADS - 1) / THREADS;
+}
 constexpr int lstm_s0(const OpD& d) { return cmax(d.din / 16, 6); }      // carry slots of the gate weights (see lstm_op)
 constexpr int carry_w(int i) {
   if (i >= kNumOps) return 0;
@@ -282,6 +297,8 @@ struct Carry {
   f32x4 w[cmax(1, carry_w(I))];
   f32x4 p[cmax(1, nxt_regs(I, 2))];
   f32x4 p4[cmax(1, own_regs(I, 4))];      // the previous-frame tap of op I's own two-round image, requested by op I-1 (all threads hold it)
+  f32x4 yp[cmax(1, yp_regs(I))];          // last frame's partial sums of op I (two-tap convs), requested two ops ahead like the weights
+  f32x4 yp2[cmax(1, yp_regs(I + 1))];
   f32x4 prm;                   // conv ops: this thread's float4 of the epilogue parameter block (bias | scale | gamma | beta | alpha)
   // the same for op I+1, already requested by op I-1: weights are fetched TWO ops ahead (a fetch that misses L2 -- the
   // state tensors stream through it all the time -- takes longer than one small op)
@@ -423,8 +440,8 @@ __device__ __forceinline__ Task conv_task(int wave) {
   if constexpr (d.path == P_R32B) {
     t.a = wave & (d.PG - 1);                    // position group
     t.b = (wave >> clog2(d.PG)) & (d.CG - 1);   // channel group
-    t.ks = 0;
-    t.wbase_f = t.b * (conv_nsf(d) * 256);
+    t.ks = r32_two(d) ? ((wave >> clog2(d.PG * d.CG)) & 1) : 0;      // two-tap conv: 1 = this frame's sums (tap 1), 0 = the next frame's
+    t.wbase_f = (t.ks * d.CG + t.b) * (conv_nsf(d) * 256);
   } else {
     // wave = ct + CG (ks + KS pg): the waves of one position group share the weights of (ct, ks)
     t.b = wave & (d.CG - 1);
@@ -509,6 +526,32 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
   }
 }
 
+// last frame's partial sums of op I ([pos][packed channel] fp32), in the layout its epilogue wants them
+template <int I, int NY>
+__device__ __forceinline__ void prefetch_y(const Ctx& cx, int tid, f32x4 (&yp)[NY]) {
+  if constexpr (yp_regs(I) > 0) {
+    constexpr OpD d = kOps[I];
+    if constexpr (d.path == P_R32B) {
+      const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const Task t = conv_task<I>(wave);
+      sfor<yp_regs(I)>([&](auto ii) {
+        constexpr int i = decltype(ii)::value, q = i & 3, n = (i >> 2) % d.NT, pt = (i >> 2) / d.NT;
+        // (32x32 tiles: the sums live in HBM in accumulator order -- [wave task][pt][n][q][lane] float4 -- so that a wave's load /
+        //  store is 1 KB contiguous; a [pos][channel] layout costs 32 partial lines per instruction)
+        yp[i] = ldb(cx.ysr, static_cast<unsigned>(d.ys_off * 4 + ((((t.a + d.PG * t.b) * d.PT + pt) * d.NT + n) * 4 + q) * 1024 + lane * 16));
+      });
+    } else {
+      constexpr int total = d.P * ntot(d) / 4;
+      sfor<yp_regs(I)>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        int item = tid + THREADS * i;
+        if ((i + 1) * THREADS > total) item = item < total ? item : total - 1;
+        yp[i] = ldb(cx.ysr, static_cast<unsigned>(d.ys_off * 4 + item * 16));
+      });
+    }
+  }
+}
+
 template <int I, int NX>
 __device__ __forceinline__ void ext_load(const Ctx& cx, int tid, f32x4 (&wx)[NX]) {
   if constexpr (ext_sf(I) > 0) {
@@ -562,10 +605,11 @@ constexpr bool feeds_x(int i) { return i + 1 < kNumOps && (kOps[i + 1].type == T
 
 // ---- row-wise epilogue of the X16B path ---------------------------------------------------------------------------
 // LPG lanes per output row (float4 each): K-slice sum + bias, LayerNorm over the row's channels, PReLU, stores.
-template <int I>
-__device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
+template <int I, int NY>
+__device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (&yp)[NY]) {
   constexpr OpD d = kOps[I];
-  constexpr int GC = d.gc, LPG = GC / 4, R = d.R, NTOT = ntot(d), KS = d.KSt * d.KSg, OPB = (NTOT + 4) * 4;
+  // (two-tap convs: slices [0, KS) of the exchange buffer hold the NEXT frame's partial sums, [KS, 2 KS) this frame's)
+  constexpr int GC = d.gc, LPG = GC / 4, R = d.R, NTOT = ntot(d), KS = ex_group(d), K0 = d.ys ? KS : 0, OPB = (NTOT + 4) * 4;
   constexpr int total = d.P * NTOT / 4, passes = (total + THREADS - 1) / THREADS;
   const int li = tid & (LPG - 1);
   const int u0 = tid >> clog2(LPG);
@@ -586,7 +630,8 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
       const int pos = u >> clog2(R);
       const int eb = d.ex_b + pos * OPB + (r * GC + 4 * li) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      sfor<(FZ_ABL & 512) ? 1 : KS>([&](auto kk) { v += lds4(eb + decltype(kk)::value * (d.P * OPB)); });
+      sfor<(FZ_ABL & 512) ? 1 : KS>([&](auto kk) { v += lds4(eb + (K0 + decltype(kk)::value) * (d.P * OPB)); });
+      if constexpr (d.ys != 0) v += yp[ps];      // W[tap 0] x_{t-1}, computed by this op one frame ago
       v = v * wsc + bias;
       if constexpr (d.ln && !(FZ_ABL & 16)) {
         const float mean = group_sum<LPG>(v[0] + v[1] + v[2] + v[3]) * (1.0f / GC);
@@ -606,6 +651,21 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid) {
       if constexpr (feeds_x(I)) lds4(XCOPY_B + (row * GC + 4 * li) * 4) = v;
     }
   });
+  if constexpr (d.ys != 0) {
+    // next frame's partial sums W[tap 0] x_t: K slices summed, stored raw ([pos][packed channel] = item order); the items are dealt
+    // from the top of the workgroup, beside the epilogue rows of the low waves
+    sfor<passes>([&](auto pp) {
+      constexpr int ps = decltype(pp)::value;
+      const int item = (THREADS - 1 - tid) + ps * THREADS;
+      if ((ps + 1) * THREADS <= total || FZ_LIKELY(item < total)) {
+        const int u = item >> clog2(LPG), l2 = item & (LPG - 1);
+        const int eb = d.ex_b + (u >> clog2(R)) * OPB + ((u & (R - 1)) * GC + 4 * l2) * 4;
+        f32x4 y = {0.f, 0.f, 0.f, 0.f};
+        sfor<KS>([&](auto kk) { y += lds4(eb + decltype(kk)::value * (d.P * OPB)); });
+        if constexpr (!(FZ_ABL & 4)) stb(cx.ysw, static_cast<unsigned>(d.ys_off * 4 + item * 16), y);
+      }
+    });
+  }
 }
 
 // ---- conv op, small layers: 16x16x32 bf16 tiles, K split over waves, LDS exchange -------------------------------------
@@ -630,11 +690,13 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
     if (pos > d.P - 1) pos = d.P - 1;
     lane_b[pt] = pos * d.img.pitch_b + 16 * h + ks_t * d.img.tap_b + ks_g * (GW * 64);
   }
-  f32x4 acc[PT][3], acco[UP ? PT : 1][3];
+  constexpr bool BOTH = x16_both(d);            // two-tap conv, the wave owns both taps: segments 0..2 (tap 0) go to the second set
+  constexpr bool TWO = UP || BOTH;
+  f32x4 acc[PT][3], acco[TWO ? PT : 1][3];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) { acc[pt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (UP) acco[pt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int pl = 0; pl < 3; ++pl) { acc[pt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (TWO) acco[pt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   if (t.active) pin_regs(c.w);
@@ -652,7 +714,7 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
             const bf16x8 b = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 64 + pl * d.img.plane_b));
-            if constexpr (UP && s == 2) acco[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acco[pt][pl], 0, 0, 0);
+            if constexpr ((UP && s == 2) || (BOTH && s < 3)) acco[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acco[pt][pl], 0, 0, 0);
             else acc[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[pt][pl], 0, 0, 0);
           }
         }
@@ -678,9 +740,10 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
     for (int pt = 0; pt < PT; ++pt) {
       const int pos = 16 * (t.a * PT + pt) + j;
       if (pos < d.P) {
-        const int eb = d.ex_b + (t.ks * d.P + pos) * OPB + (16 * t.b + 4 * h) * 4;
+        const int eb = d.ex_b + ((BOTH ? 1 : t.ks) * d.P + pos) * OPB + (16 * t.b + 4 * h) * 4;
         lds4(eb) = acc[pt][0] + (acc[pt][1] + acc[pt][2]);
         if constexpr (UP) lds4(eb + d.N * 4) = acco[pt][0] + (acco[pt][1] + acco[pt][2]);
+        if constexpr (BOTH) lds4(eb - d.P * OPB) = acco[pt][0] + (acco[pt][1] + acco[pt][2]);      // slice 0: the next frame's sums
       }
     }
   }
@@ -688,7 +751,7 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
   FZ_STAMP(I, 1);
   lds_barrier();
   FZ_STAMP(I, 2);
-  x_epilogue<I>(cx, tid);
+  x_epilogue<I>(cx, tid, c.yp);
   FZ_STAMP(I, 3);
   build_next<I>(tid, p1, c.p);
   FZ_STAMP(I, 4);
@@ -767,11 +830,35 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
   } else {
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{});
   }
+  if constexpr (r32_two(d)) {
+    // waves 0..3 of a two-tap conv: W[tap 0] x_t, the next frame's partial sums, stored raw in accumulator order (prefetch_y)
+    if (t.ks == 0) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int n = 0; n < NA; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
+            stb(cx.ysw, static_cast<unsigned>(d.ys_off * 4 + ((((t.a + d.PG * t.b) * PT + pt) * NT + n) * 4 + q) * 1024 + lane * 16), v);
+          }
+    } else {
+      // waves 4..7: this frame's sums start from what the op handed over one frame ago
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int n = 0; n < NA; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[pt][n][4 * q + e] += c.yp[(pt * NT + n) * 4 + q][e];
+    }
+  }
   if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
   FZ_STAMP(I, 1);
   lds_barrier();                      // every wave is done with this op's image; parameters are in LDS
   FZ_STAMP(I, 2);
-  if (t.active) {
+  if (t.active && (!r32_two(d) || t.ks != 0)) {
     float alpha = 0.f;
     if constexpr (d.ln) alpha = lds1(SCR_B + (2 * NTOT + 2 * d.gc) * 4);
 #pragma unroll
@@ -1078,7 +1165,10 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
 #pragma unroll
   for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
   n.prm = c.prm2;
+#pragma unroll
+  for (int k = 0; k < cmax(1, yp_regs(I + 1)); ++k) n.yp[k] = c.yp2[k];
   prefetch_w<I + 2>(cx, tid, n.w2, n.prm2);
+  prefetch_y<I + 2>(cx, tid, n.yp2);
   sched_pin();
   FZ_STAMP(I, 0);
 
@@ -1153,6 +1243,8 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.sbc = (gcb_t)(unsigned long long)(slice + (a.par ? kParityStride : 0));
   cx.sbp = (gcb_t)(unsigned long long)(slice + (a.par ? 0 : kParityStride));
   cx.wb = (gcb_t)(unsigned long long)a.blob;
+  cx.ysw = (gcb_t)(unsigned long long)(slice + kYsOff + (a.par ? kYsBlock : 0));
+  cx.ysr = (gcb_t)(unsigned long long)(slice + kYsOff + (a.par ? 0 : kYsBlock));
   cx.io_in = (gcf_t)(unsigned long long)(a.io_in + static_cast<size_t>(stream) * 256);
   cx.io_out = (gf_t)(unsigned long long)(a.io_out + static_cast<size_t>(stream) * 256);
   cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
@@ -1163,15 +1255,25 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   {
     // one pass over the 13 parameter records of the dilated-dense ops: they stay in the scalar cache for the rest of
     // the launch (ddbz_load_rec reads them with scalar loads, twice per op)
+    // (ONE statement, one destination register, the wait inside: a scalar load lands long after it was issued, and a destination the
+    //  compiler considers dead after the statement is free for re-use -- the C++ loop this replaces let late loads overwrite whatever
+    //  the allocator had put there since, harmlessly until the allocation changed: a base pointer, a memory fault)
     unsigned t;
-    for (int o = 0; o < static_cast<int>(13 * sizeof(DdbParams)); o += 64) asm volatile("s_load_dword %0, %1, %2" : "=s"(t) : "s"(cx.ddb), "s"(o));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile(
+        ".set .Lddb_warm, 0\n\t"
+        ".rept %2\n\t"
+        "s_load_dword %0, %1, .Lddb_warm\n\t"
+        ".set .Lddb_warm, .Lddb_warm + 64\n\t"
+        ".endr\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(t) : "s"(cx.ddb), "n"((13 * sizeof(DdbParams) + 63) / 64) : "memory");
   }
 #endif
   Carry<0> c0;
   {
     int tid = threadIdx.x;
     prefetch_w<1>(cx, tid, c0.w2, c0.prm2);
+    prefetch_y<1>(cx, tid, c0.yp2);
   }
   run_from<0, PROF>(cx, c0);
   if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();

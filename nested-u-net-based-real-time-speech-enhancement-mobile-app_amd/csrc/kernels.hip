@@ -810,6 +810,43 @@ hipError_t launch_incr_step(int* step, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Carried partial sums of the fused kernel's two-tap convs, rebuilt from the conv-input state tensors (rare: after nutls_state_set or
+// a step of another mode): S[pos][n] = sum over frequency taps k and channels c of W[n][tap 0][k][c] * x[stride pos - 1 + k][c],
+// rows outside the tensor are the zero padding (models/proposed.py:208-216, :240-251).  grid = (ops, streams).
+__global__ __launch_bounds__(256) void ysum_refresh_kernel(const float* arena, long long sstride, int x_block_off, int ys_block_off,
+                                                           const YsOp* ops, const float* w) {
+  const YsOp o = ops[blockIdx.x];
+  const float* slice = arena + static_cast<size_t>(blockIdx.y) * sstride;
+  const float* x = slice + x_block_off + o.xs_off;
+  float* y = const_cast<float*>(slice) + ys_block_off + o.ys_off;
+  const float* wq = w + o.w_off;
+  const int rows = o.stride * o.P;
+  for (int idx = threadIdx.x; idx < o.P * o.N; idx += 256) {
+    const int pos = idx / o.N, n = idx - pos * o.N;
+    float a = 0.f;
+    for (int k = 0; k < 3; ++k) {
+      const int row = o.stride * pos - 1 + k;
+      if (row < 0 || row >= rows) continue;
+      const float* xr = x + static_cast<size_t>(row) * o.xs_ld;
+      const float* wr = wq + (static_cast<size_t>(n) * 3 + k) * o.cin;
+      for (int c = 0; c < o.cin; ++c) a = fmaf(wr[c], xr[c], a);
+    }
+    int dst = idx;
+    if (o.r32) {      // accumulator order of the 32x32 tiles: lane (pos & 31, half h) register 4 q + e holds channel 32 T + 8 q + 4 h + e
+      const int tp = pos >> 5, j = pos & 31, T = n >> 5, c32 = n & 31;
+      const int task = tp / o.PT + o.PG * (T / o.NT);
+      dst = ((((task * o.PT + tp % o.PT) * o.NT + T % o.NT) * 4 + (c32 >> 3)) * 64 + ((c32 >> 2) & 1) * 32 + j) * 4 + (c32 & 3);
+    }
+    y[dst] = a;
+  }
+}
+
+hipError_t launch_ysum_refresh(const float* arena, long long sstride, int x_block_off, int ys_block_off, const YsOp* ops, const float* w,
+                               int n_ops, int B, hipStream_t s) {
+  hipLaunchKernelGGL(ysum_refresh_kernel, dim3(n_ops, B), dim3(256), 0, s, arena, sstride, x_block_off, ys_block_off, ops, w);
+  return hipGetLastError();
+}
+
 __global__ void set_step_kernel(int* step, int value) { *step = value; }
 
 hipError_t launch_set_step(int* step, int value, hipStream_t s) {

@@ -116,6 +116,19 @@ hipError_t launch_ddb(const DdbParams& p, hipStream_t s);
 hipError_t launch_incr_step(int* step, hipStream_t s);
 hipError_t launch_set_step(int* step, int value, hipStream_t s);   // after fused-mode steps (which take the counter by value)
 
+// Carried partial sums of the fused kernel's two-tap convs (fused_plan.hpp OpD::ys): S = W[time tap 0] x, rebuilt on the device
+// from the conv-input state tensors after those were written from outside the kernel (nutls_state_set, a step of another mode).
+struct YsOp {
+  int P, cin, N, stride;     // output positions, input channels, packed output channels, 2 (strided conv) or 1 (sub-pixel conv)
+  int xs_off, xs_ld;         // input state tensor: float offset inside a parity block of the arena, floats per row
+  int ys_off;                // the op's sums inside a block of partial sums ([pos][N])
+  int w_off;                 // weights [N][3][cin] (packed channel order, int8 values as floats) inside the table's weight array
+  int r32, PT, NT, PG;       // r32: the op runs on 32x32 tiles and keeps its sums in accumulator order, [wave task][pt][n][q][lane] float4
+                             // (task = position group + PG * channel group); else [pos][N]
+};
+hipError_t launch_ysum_refresh(const float* arena, long long sstride, int x_block_off, int ys_block_off, const YsOp* ops, const float* w,
+                               int n_ops, int B, hipStream_t s);
+
 struct CtfaParams {
   const float* x; int x_ld;      // d_D  [B,F,64]
   const float* e0; int e0_ld;    // residual [B,F,64]
@@ -280,5 +293,9 @@ int fused_state_off(int variant, int i);
 int fused_num_scratch(int variant);
 const char* fused_scratch_name(int variant, int i);
 int fused_scratch_off(int variant, int i);
+int fused_ys_block(int variant);          // floats of one block of carried partial sums; the arena's "ysum" scratch holds two
+int fused_ys_off(int variant);            // arena offset of the first block
+// the table launch_ysum_refresh needs (w: all ops' tap-0 weights, int8 values as floats); false + err if a tensor has no int8 payload
+bool fused_ys_table(int variant, const WeightMap& wm, std::vector<YsOp>* ops, std::vector<float>* w, std::string* err);
 
 }  // namespace nutls

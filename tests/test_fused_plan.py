@@ -65,9 +65,10 @@ def test_blob_packing_round_trips_the_container(variant):
         q, sc = Wq[o["wkey"] + ".w"]
         perm = _perm(o)
         G = cin // (16 if r32 else 32)
-        wt = o["CG"] if r32 else o["CG"] * o["KSt"] * o["KSg"]
+        r32two = r32 and o["ys"]          # two-tap conv on 32x32 tiles: waves 0..3 own time tap 0, waves 4..7 tap 1
+        wt = (2 * o["CG"] if r32two else o["CG"]) if r32 else o["CG"] * o["KSt"] * o["KSg"]
         GW = G // o["KSg"]
-        segw = 3 if up else o["nseg"] // o["KSt"]
+        segw = 3 if (up or r32two) else o["nseg"] // o["KSt"]
         nf = segw * GW * o["NT"]
         nsf = (nf + 1) // 2
         raw = out[o["w_off"]:o["w_off"] + wt * nsf * 256].view(np.int8).reshape(wt, nsf, 64, 16)
@@ -78,7 +79,7 @@ def test_blob_packing_round_trips_the_container(variant):
             for f in range(nf):          # the walk of conv_x16b / conv_r32b (fused_step.hip)
                 if r32:
                     nt, sgi = f % o["NT"], f // o["NT"]
-                    sg, g, T = sgi // G, sgi % G, ct * o["NT"] + nt
+                    sg, g, T = (3 * ks if r32two else 0) + sgi // G, sgi % G, ct * o["NT"] + nt
                     npk, c0 = 32 * T + (lane & 31), 16 * g + 8 * (lane >> 5)
                 else:
                     sg, g, T = ks_t * segw + f // GW, ks_g * GW + f % GW, ct

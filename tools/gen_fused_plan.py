@@ -108,6 +108,18 @@ class Arena:
                      [("upcat%d" % s, (DEC[s][2] // 2) * 128) for s in range(6)]:
             self.scratch[n] = cur
             cur += r64(sz)
+        # carried partial sums of the two-tap convs (P x N fp32 each): two blocks, one read (last frame's) and one written per frame
+        self.ys_block = 0
+        for stages in (ENC, DEC):
+            for (p, D, f0, ct, st, _rs) in stages:
+                for i in range(1, D + 1):
+                    self.ys_block += r64((f0 >> i) * 32)
+                for j in range(1, D + 1):
+                    Pj, Nj = (f0 >> D) << (j - 1), (128 if j == D else 64)
+                    if carries_sums(K_DL, Nj, Pj):
+                        self.ys_block += r64(Pj * Nj)
+        self.scratch["ysum"] = cur
+        cur += 2 * self.ys_block
         self.floats = cur
 
 
@@ -150,6 +162,16 @@ R32_TABLE = {   # (kind, N, P) -> (PT, NT, PG, CG)
 }
 
 
+def carries_sums(kind, N, P):
+    """Which two-tap convs hand their previous-frame tap over as partial sums (OpD.ys): the strided convs -- P x 32 sums replace
+    2P x cin input rows, 2-8x fewer bytes, and the image of the previous frame (with its staging: loads, splits, LDS stores) goes.
+    Not the sub-pixel convs: their sums are as many bytes as their input rows (N = 64) or twice as many (N = 128), and the
+    loads / stores of those land in the small ops around them and in front of the CTFA drain points -- measured with all of them
+    carried: +18 us over the 46 small ones, +7 us in the CTFAs; with only the six on 32x32 tiles: -5 us in those ops, +13 us in the
+    ops that request their sums."""
+    return 1 if kind == K_EL else 0
+
+
 def tiling(kind, N, P, cin, taps, rounds=1):
     """-> dict(path, PT, NT, PG, CG, KSt, KSg).  R32B: 32x32x16 bf16 tiles, PT x NT tiles per wave, PG x CG wave tasks, whole
     LayerNorm groups per wave.  X16B: 16x16x32 bf16 tiles, wave task = (position group pg, channel tile ct, K slice
@@ -173,7 +195,7 @@ def tiling(kind, N, P, cin, taps, rounds=1):
     return dict(path=P_X16B, PT=ptiles // PG, NT=1, PG=PG, CG=CT, KSt=KSt, KSg=KSg)
 
 
-def make_img(kind, P, cin, rounds=1, fmt=1, csplit=1):
+def make_img(kind, P, cin, rounds=1, fmt=1, csplit=1, cps=0):
     """LDS image geometry of a conv op: dict(fmt, plane_b, taps, tap_b, pitch_b, pair, half_b, row0, bytes, zero[], seg_b[], seg_tk[], seg_c0[]).
     fmt 1: every row holds three bf16 planes (hi | mid | lo of the fp32 activations, x = hi + mid + lo exactly) of `rowch` channels
     each, fmt 0: fp32 rows.  csplit 2 (1x1 layers only): the image holds one half of the input channels at a time (two rounds)."""
@@ -219,6 +241,12 @@ def make_img(kind, P, cin, rounds=1, fmt=1, csplit=1):
         raise ValueError(kind)
     g["fmt"] = fmt
     g["plane_b"] = plane_b if fmt else 0
+    if cps:
+        # Carried partial sums: y_t = W_cur x_t + W_prev x_{t-1}, and the second term is computed one frame EARLIER, by the op
+        # that has x_{t-1} in LDS as its current input (the same B fragments, the other time tap's weights), and handed over as
+        # P x N fp32 sums.  So the image holds the current frame only; the six K segments keep their (time tap, frequency tap)
+        # tags -- they select the weights -- and the two taps of a frequency tap read the same rows.
+        g["taps"] = 1
     one = (g.pop("one") + 255) // 256 * 256
     if csplit == 2:
         assert kind == K_IN and rounds == 2
@@ -253,6 +281,7 @@ def ddb_flops(F, c):
 def build(variant="lstm"):
     A = Arena(variant)
     W = Blob()
+    YS = Blob()         # carried partial sums of the two-tap convs: offsets inside one block (the arena holds two: read / write parity)
     ops = []
     base = variant != "lstm"
 
@@ -261,7 +290,7 @@ def build(variant="lstm"):
                  ln=0, R=1, gc=0, rounds=1, nseg=0, seg_b=[], seg_tk=[], ex_b=0, w_off=0, p_off=0,
                  d0=None, d1=None, row_mul=1, row_add=0, fwd=None, img=None, nxt=-1, parts=[],
                  din=0, dout=0, x_b=0, x_pitch_b=0, x_cols=0, y_b=0, h_off=0, c_off=0, ldst=None, lw_off=0,
-                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0, x_fmt=0, x_plane_b=0)
+                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0, x_fmt=0, x_plane_b=0, ys=0, ys_off=0, xs_off=0, xs_ld=0)
         d.update(kw)
         ops.append(d)
         return d
@@ -269,22 +298,27 @@ def build(variant="lstm"):
     def conv_op(name, wkey, kind, side, idx, D, P, d0=None, d1=None, row_mul=1, row_add=0):
         cin, N, taps, kf, stride, ln, R, gc = conv_geom(kind, side, idx, D)
         # both taps of these images do not fit LDS: one tap at a time (the previous-frame tap is staged in mid-op)
-        rounds = 2 if (kind == K_EL and P >= 64 and cin * P >= 128 * 64) else 1
+        ys = carries_sums(kind, N, P)
+        rounds = 1          # (the strided convs' images hold one time tap: nothing needs two rounds any more)
         o = new_op(type=T_CONV, name=name, wkey=wkey, kind=kind, P=P, cin=cin, N=N, taps=taps, kf=kf, stride=stride, ln=ln, R=R, gc=gc,
-                   rounds=rounds, d0=d0, d1=d1, row_mul=row_mul, row_add=row_add)
+                   rounds=rounds, d0=d0, d1=d1, row_mul=row_mul, row_add=row_add, ys=ys)
         o.update(tiling(kind, N, P, cin, taps, rounds))
         ntot = N * (2 if kind == K_UP else 1)
         x16 = o["path"] == P_X16B
         if x16:
-            ks = o["KSt"] * o["KSg"]
+            # exchange slices: K slice (time tap ks_t, channel range ks_g); a two-tap conv whose waves own both taps (KSt 1)
+            # still has two slices: 0 = next frame's partial sums, 1 = this frame's
+            ks = o["KSt"] * o["KSg"] * (2 if (ys and o["KSt"] == 1) else 1)
             ex = ks * P * (ntot + 4) * 4
             o["ex_b"] = (SCR_B - ex) // 256 * 256
+        if ys:
+            o["ys_off"] = YS.add(P * ntot, "ysum", wkey)
         lim = o["ex_b"] if x16 else SCR_B
         # the image as three bf16 planes where that fits LDS; the two largest stay fp32 and are split when they are read
-        g = make_img(kind, P, cin, rounds, fmt=1)
+        g = make_img(kind, P, cin, rounds, fmt=1, cps=ys)
         if g["bytes"] > lim:
             assert not x16, name
-            g = make_img(kind, P, cin, rounds, fmt=0)
+            g = make_img(kind, P, cin, rounds, fmt=0, cps=ys)
         o["img"] = g
         o["nseg"] = len(g["seg_b"])
         o["seg_b"] = g["seg_b"]
@@ -297,6 +331,11 @@ def build(variant="lstm"):
         if x16:
             nf = segw * (cin // 32 // o["KSg"])
             wtasks = o["CG"] * o["KSt"] * o["KSg"]
+        elif ys:
+            # 32x32 tiles of a two-tap conv: waves 0..3 own the next frame's sums (time tap 0), waves 4..7 this frame's (tap 1)
+            assert o["PG"] * o["CG"] == 4, name
+            nf = 3 * (cin // 16) * o["NT"]
+            wtasks = 2 * o["CG"]
         else:
             nf = segw * (cin // 16) * o["NT"]
             wtasks = o["CG"]
@@ -372,6 +411,7 @@ def build(variant="lstm"):
     for i, o in enumerate(ops):
         o["idx"] = i
     n_ops = len(ops)
+    assert YS.cur == A.ys_block, (YS.cur, A.ys_block)
 
     # ---- who completes whose image -----------------------------------------------------------------
     conv_idx = [o["idx"] for o in ops if o["type"] == T_CONV]
@@ -437,10 +477,7 @@ def build(variant="lstm"):
                 g = o["img"]
                 rows, cin = f0 >> (i - 1), o["cin"]
                 parts = []
-                r2 = 1 if o["rounds"] == 2 else 0
-                # (two-round image: the previous-frame tap is stored in the middle of the op; its loads are issued one op earlier -- no
-                #  same-frame hazard, it is last frame's data -- so that the second round does not wait for HBM)
-                parts.append(part(S_PREV, st_off(ct, i), cin, rows, cin // 4, 0, g["row0"], 2 if r2 else la_of(rows, cin // 4), r2))
+                o["xs_off"], o["xs_ld"] = st_off(ct, i), cin         # the conv's input state tensor [rows][cin] (nutls_state_set -> partial sums)
                 if side:
                     sk = 64 if i == 1 else 32
                     parts.append(part(S_CUR, st_off(ct, i) + sk, cin, rows, sk // 4, g["tap_b"] + sk * esz(g), g["row0"], la_of(rows, sk // 4)))
@@ -449,7 +486,10 @@ def build(variant="lstm"):
                 o = lst[D + 1 + j]
                 g = o["img"]
                 rows = o["P"]
-                parts = [part(S_PREV, st_off(stg, j), 64, rows, 16, 0, g["row0"], la_of(rows, 16))]
+                parts = []
+                o["xs_off"], o["xs_ld"] = st_off(stg, j), 64
+                if not o["ys"]:
+                    parts.append(part(S_PREV, st_off(stg, j), 64, rows, 16, 0, g["row0"], la_of(rows, 16)))
                 if j >= 2:
                     # e_{D-j+1}, written this frame by strided conv D-j+1: visible after the LSTM's drain point,
                     # i.e. its loads may be issued by sub-pixel conv 1 at the earliest
@@ -539,19 +579,21 @@ def emit(A, W, ops):
     L.append("constexpr int kParityStride = %d;      // floats between the two buffers of every state tensor" % A.PS)
     L.append("constexpr int kArenaFloats = %d;       // per-stream arena the plan addresses (engine.cpp lays it out identically)" % A.floats)
     L.append("constexpr int kBlobFloats = %d;        // weight blob in plan order" % W.cur)
+    L.append("constexpr int kYsOff = %d;             // arena offset of the two blocks of carried partial sums (block b at kYsOff + b * kYsBlock)" % A.scratch["ysum"])
+    L.append("constexpr int kYsBlock = %d;" % A.ys_block)
     L.append("constexpr OpD kOps[kNumOps] = {")
     for o in ops:
         seg_b = ",".join(str(x) for x in pad(o["seg_b"], MAX_SEG))
         ldst = o["ldst"]
         row = ("{%d, /*conv*/ %d,%d,%d,%d,%d,%d,%d, %d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, %d,{%s}, %d, %d,%d, %s, %s, %d,%d, %s, %s, %d, "
-               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d},   // %d %s") % (
+               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
             o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
             c_fwd(o["fwd"]), c_img(o), o["nxt"],
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
             1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["x_fmt"], o["x_plane_b"], o["lw_off"],
-            o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["idx"], o["name"])
+            o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["ys"], o["ys_off"], o["xs_off"], o["xs_ld"], o["idx"], o["name"])
         L.append("  " + row)
     L.append("};")
     # what the host needs to pack the blob / check the arena
