@@ -213,7 +213,7 @@ __device__ __forceinline__ void kb_split4(const f32x4& v, u32x2& hi, u32x2& mid,
   lo = u32x2{kb_top16(lb[0], lb[1]), kb_top16(lb[2], lb[3])};
 }
 
-template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int G, int NW>
+template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int G, int NW, bool ALL>
 __global__ __launch_bounds__(64 * NW) void conv_bf16x3_kernel(const ConvParams p) {
   constexpr int CC = CIN < 64 ? CIN : 64;
   constexpr int NCH = CIN / CC;
@@ -249,53 +249,98 @@ __global__ __launch_bounds__(64 * NW) void conv_bf16x3_kernel(const ConvParams p
 
   const f32x4* wp = reinterpret_cast<const f32x4*>(p.wbf) + lane;      // one fragment = 8 bf16 = 16 bytes per lane
   const int rows_total = nseg * LR;
+  constexpr int WPH = KF * (CC / 16) * NT;      // weight fragments of one (time tap, channel chunk) phase
+  constexpr int NPH = TT * NCH;
 
-#pragma unroll 1
-  for (int t = 0; t < TT; ++t) {
+  // one phase = one (time tap, 64-channel chunk): its input rows -> LDS at byte offset `lo`, split into the three planes
+  auto stage = [&](int t, int ch, int lo) {
     const float* src = (TT == 2 && t == 1) ? p.src1 : p.src0;
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-      if (t + ch > 0) __syncthreads();   // all waves finished reading the previous phase
-      // ---------------- stage input rows -> LDS, split into the three planes ---------------------
-      for (int q = tid; q < rows_total * (CC / 4); q += 64 * NW) {
+    // eight loads in flight per thread, then their splits and stores: one load per loop trip (load -> split -> store) paid a full
+    // memory round trip per trip -- a dozen trips in the 1-wave workgroups of the small layers
+    constexpr int U = 8;
+    const int n_items = rows_total * (CC / 4);
+    for (int q0 = tid; q0 < n_items; q0 += 64 * NW * U) {
+      f32x4 v[U];
+      int la[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u * 64 * NW;
         const int c4 = q % (CC / 4);
         const int rr = q / (CC / 4);
         const int sg = rr / LR, lr = rr - sg * LR;
         const int pseg = P0 + sg * seg_len;
         const int b = pseg >> log2f, f0 = pseg & (F_out - 1);
         const int gr = STRIDE * f0 - PADL + lr;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (b < p.B && gr >= 0 && gr < p.F_in)
-          v = *reinterpret_cast<const f32x4*>(src + static_cast<size_t>(b) * p.sstride + static_cast<size_t>(gr) * p.src_ld + ch * CC + 4 * c4);
-        const int la = (STRIDE == 1) ? ((sg * RS + lr) * PITCH_B + 8 * c4)
-                                     : ((sg * RS + (lr >> 1)) * PITCH_B + (lr & 1) * (CC * 2) + 8 * c4);
-        u32x2 hi, mid, lo;
-        kb_split4(v, hi, mid, lo);
-        *reinterpret_cast<u32x2*>(ldsb + la) = hi;
-        *reinterpret_cast<u32x2*>(ldsb + la + PLANE_B) = mid;
-        *reinterpret_cast<u32x2*>(ldsb + la + 2 * PLANE_B) = lo;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < n_items && b < p.B && gr >= 0 && gr < p.F_in)
+          v[u] = *reinterpret_cast<const f32x4*>(src + static_cast<size_t>(b) * p.sstride + static_cast<size_t>(gr) * p.src_ld + ch * CC + 4 * c4);
+        la[u] = q < n_items ? lo + ((STRIDE == 1) ? ((sg * RS + lr) * PITCH_B + 8 * c4)
+                                                  : ((sg * RS + (lr >> 1)) * PITCH_B + (lr & 1) * (CC * 2) + 8 * c4))
+                            : -1;
       }
-      __syncthreads();
-      // ---------------- MFMA over (frequency tap, K step of 16 channels) --------------------------
 #pragma unroll
-      for (int kf = 0; kf < KF; ++kf) {
-        const int koff = (STRIDE == 1) ? (kf * PITCH_B) : ((kf >> 1) * PITCH_B + (kf & 1) * (CC * 2));
-#pragma unroll
-        for (int g = 0; g < CC / 16; ++g) {
-          bf16x8 b3[3];
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            b3[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ldsb + lbase + koff + 32 * g + q * PLANE_B));
-          bf16x8 a8[NT];
-#pragma unroll
-          for (int n = 0; n < NT; ++n) a8[n] = __builtin_bit_cast(bf16x8, wp[n * 64]);
-          wp += NT * 64;
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[n], b3[q], acc[n], 0, 0, 0);
+      for (int u = 0; u < U; ++u) {
+        if (la[u] >= 0) {
+          u32x2 hi, mid, lo3;
+          kb_split4(v[u], hi, mid, lo3);
+          *reinterpret_cast<u32x2*>(ldsb + la[u]) = hi;
+          *reinterpret_cast<u32x2*>(ldsb + la[u] + PLANE_B) = mid;
+          *reinterpret_cast<u32x2*>(ldsb + la[u] + 2 * PLANE_B) = lo3;
         }
+      }
+    }
+  };
+  // MFMA over (frequency tap, K step of 16 channels) of one phase; wreg: its WPH weight fragments
+  auto mfma_phase = [&](int lo, const f32x4* wreg) {
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf) {
+      const int koff = lo + ((STRIDE == 1) ? (kf * PITCH_B) : ((kf >> 1) * PITCH_B + (kf & 1) * (CC * 2)));
+#pragma unroll
+      for (int g = 0; g < CC / 16; ++g) {
+        bf16x8 b3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          b3[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ldsb + lbase + koff + 32 * g + q * PLANE_B));
+        bf16x8 a8[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) a8[n] = __builtin_bit_cast(bf16x8, wreg[(kf * (CC / 16) + g) * NT + n]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[n], b3[q], acc[n], 0, 0, 0);
+      }
+    }
+  };
+
+  if constexpr (ALL) {
+    // Small layers (all phases fit LDS side by side, all weights fit the registers): everything is requested up front and there
+    // is ONE barrier -- these launches are nothing but latency (20-25 us for a few microseconds of work with a barrier pair and
+    // an L2 round trip per phase).
+    f32x4 wreg[NPH * WPH];
+#pragma unroll
+    for (int i = 0; i < NPH * WPH; ++i) wreg[i] = wp[i * 64];
+    const int phase_b = (nseg * RS * PITCH_B + 255) & ~255;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) stage(ph / NCH, ph % NCH, ph * phase_b);
+    __syncthreads();
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) mfma_phase(ph * phase_b, wreg + ph * WPH);
+  } else {
+#pragma unroll 1
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll 1
+      for (int ch = 0; ch < NCH; ++ch) {
+        // the phase's weights are requested BEFORE its input rows are staged: they do not depend on the input, and behind the
+        // barriers below every K step would wait for its own L2 round trip
+        f32x4 wreg[WPH];
+#pragma unroll
+        for (int i = 0; i < WPH; ++i) wreg[i] = wp[i * 64];
+        wp += WPH * 64;
+        if (t + ch > 0) __syncthreads();   // all waves finished reading the previous phase
+        stage(t, ch, 0);
+        __syncthreads();
+        mfma_phase(0, wreg);
       }
     }
   }
@@ -439,8 +484,15 @@ static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) 
     const size_t ldsb = conv_lds_bytes_bf16(k, p.F_out, nw);
     const long long totalb = static_cast<long long>(p.B) * p.F_out;
     if (nw == 4)
-      return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4>, ldsb, static_cast<unsigned>((totalb + 127) / 128), 256, p, s);
-    return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1>, ldsb, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
+      return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, false>, ldsb, static_cast<unsigned>((totalb + 127) / 128), 256, p, s);
+    // 1-wave workgroups (the layers with few positions): all phases at once where LDS and the registers allow it
+    constexpr int cc = CIN < 64 ? CIN : 64, nph = TT * (CIN / cc), wph = KF * (cc / 16) * NT;
+    const size_t phase_b = (ldsb + 255) & ~static_cast<size_t>(255);
+    if constexpr (nph > 1 && nph * wph <= 48) {
+      if (nph * phase_b <= 64 * 1024)
+        return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, true>, nph * phase_b, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
+    }
+    return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, false>, ldsb, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
   }
   const size_t lds = conv_lds_bytes(k, p.F_out, nw);
   const long long total = static_cast<long long>(p.B) * p.F_out;
