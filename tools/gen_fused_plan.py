@@ -155,8 +155,7 @@ def conv_geom(kind, side, i_or_j, D):
 R32_TABLE = {   # (kind, N, P) -> (PT, NT, PG, CG)
     (K_IN, 64, 256): (1, 2, 8, 1), (K_IN, 64, 128): (1, 2, 4, 1),
     (K_EL, 32, 128): (1, 1, 4, 1),
-    (K_DL, 64, 64): (1, 1, 2, 2),
-    (K_DL, 128, 128): (2, 2, 2, 2), (K_DL, 128, 64): (1, 2, 2, 2),
+    (K_DL, 128, 128): (2, 2, 2, 2),
     (K_DOWN, 64, 128): (1, 1, 4, 2), (K_DOWN, 64, 64): (1, 1, 2, 2),
     (K_UP, 128, 128): (2, 1, 2, 4), (K_UP, 128, 64): (1, 1, 2, 4), (K_UP, 128, 32): (1, 1, 1, 4),
 }
