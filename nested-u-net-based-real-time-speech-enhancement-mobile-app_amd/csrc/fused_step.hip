@@ -21,6 +21,11 @@
 //     produces go there straight from registers (split in its epilogue), everything else (previous-frame tap = the other
 //     parity of the state tensor in HBM, skip-connection channels) is loaded from HBM into registers one or two ops
 //     ahead and split + stored into the image between the two barriers of the op before;
+//   * the strided convs (OpD::ys) keep only the CURRENT frame in their image: y_t = W[tap 1] x_t + S_{t-1}, where S_t = W[tap 0] x_t is
+//     computed by the same op from the same B fragments and handed to the next frame through HBM as P x 32 fp32 sums (2-8x
+//     fewer bytes than the 2P x cin input rows, no staging of them).  Their conv-input state tensors are still written -- they are
+//     the ABI's states -- but never read here; the host rebuilds S after nutls_state_set / a step of another mode (engine.cpp
+//     ysum_refresh).  The plans of this round have no two-round image left (the machinery for one -- Part::round2 -- stays);
 //   * its A operand (int8 weights in MFMA fragment order, one blob in plan order) streams from L2 through a register
 //     ring whose first fill is issued two ops ahead, converted to bf16 pairs in the MFMA shadow;
 //   * large layers: 32x32x16 bf16 MFMA tiles, each wave owns whole LayerNorm groups, epilogue in registers;
