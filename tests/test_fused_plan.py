@@ -116,6 +116,29 @@ def test_plan_images_fit_lds_and_ops_cover_the_network(name, bottleneck):
                 assert p["la"] in (1, 2)
 
 
+@pytest.mark.parametrize("name", ["lstm", "base"])
+def test_carried_partial_sums_layout(name):
+    """The strided convs hand W[tap 0] x_t to the next frame as P x 32 fp32 sums (OpD.ys): their image holds one time tap, no part
+    of it comes from the previous frame's state, the sums of all of them tile one block exactly, the arena holds two blocks after
+    the scratch tensors, and every such op knows the state tensor the host rebuilds its sums from."""
+    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_%s.json" % name)))
+    ops = [o for o in plan["ops"] if o["type"] == 1]
+    ys = [o for o in ops if o["ys"]]
+    assert len(ys) == 52 and all(o["kind"] == 1 for o in ys) and all(o["ys"] == (o["kind"] == 1) for o in ops)
+    spans = sorted((o["ys_off"], o["ys_off"] + (o["P"] * o["N"] + 63) // 64 * 64) for o in ys)
+    assert spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    block = spans[-1][1]
+    assert plan["arena_floats"] == plan["scratch"]["ysum"] + 2 * block
+    state_off = set(plan["state_off"].values())
+    for o in ys:
+        assert o["img"]["taps"] == 1 and o["rounds"] == 1 and o["nseg"] == 6 and o["seg_b"][:3] == o["seg_b"][3:]
+        assert all(p["src"] != 0 for p in o["parts"])            # nothing staged from the `prev` parity
+        assert o["xs_off"] in state_off and o["xs_ld"] == o["cin"]
+    for o in ops:
+        if o["kind"] == 2:                                        # sub-pixel convs keep the two-tap image
+            assert o["img"]["taps"] == 2 and any(p["src"] == 0 for p in o["parts"])
+
+
 def test_malformed_containers_are_error_codes_not_crashes():
     """The container parser never trusts header fields (huge / zero dims, truncated payloads, wrapping products):
     every malformed blob comes back as NUTLS_ERR_WEIGHTS through the C ABI (host-only entry point, no GPU needed)."""
