@@ -135,13 +135,25 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// s + (the value 16 / 32 lanes away): gfx950's v_permlane16_swap / v_permlane32_swap give both halves of the exchange in two registers
+// (one VALU instruction; __shfl_xor is a ds_bpermute: an LDS-crossbar round trip in the middle of a dependent chain)
+__device__ __forceinline__ float xor16_sum(float s) {
+  const int v = __builtin_bit_cast(int, s);
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // r[0]: rows 0 0 2 2, r[1]: rows 1 1 3 3
+  return __builtin_bit_cast(float, static_cast<int>(r[0])) + __builtin_bit_cast(float, static_cast<int>(r[1]));
+}
+__device__ __forceinline__ float xor32_sum(float s) {
+  const int v = __builtin_bit_cast(int, s);
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);      // r[0]: lanes 0..31 twice, r[1]: lanes 32..63 twice
+  return __builtin_bit_cast(float, static_cast<int>(r[0])) + __builtin_bit_cast(float, static_cast<int>(r[1]));
+}
 template <int LPG>
 __device__ __forceinline__ float group_sum(float s) {      // sum over LPG consecutive lanes (aligned), result in all of them
   s += dpp_mov<0xB1>(s);                  // quad_perm [1,0,3,2]
   s += dpp_mov<0x4E>(s);                  // quad_perm [2,3,0,1]
   if (LPG >= 8) s += dpp_mov<0x141>(s);   // row_half_mirror
   if (LPG >= 16) s += dpp_mov<0x140>(s);  // row_mirror
-  if (LPG >= 32) s += __shfl_xor(s, 16);
+  if (LPG >= 32) s = xor16_sum(s);
   return s;
 }
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -766,7 +778,6 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
 // Lane (j = lane & 31, h = lane >> 5): A = weights of channel 32 T + j, B = position j, both for the 8 channels 8 h .. 8 h + 7
 // of the K step (16 channels of one segment); three MFMAs per tile and step (hi, mid, lo plane) into the tile's accumulator.
 // The two images that do not fit LDS as three planes are fp32 (img.fmt 0): their B fragments are split when they are read.
-__device__ __forceinline__ float xor32_sum(float s) { return s + __shfl_xor(s, 32); }
 
 template <int I, int N1, int N3, int NX>
 __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, const f32x4 (&p1)[N1], const f32x4 (&p3)[N3], f32x4 (&wx)[NX]) {
@@ -1059,15 +1070,16 @@ __device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1)[4], float 
     h1 += lds1(scr_b + ((qtr * 16 + i + 1) * 20 + u) * 4);
   }
   float hsum = h0 + h1;
-  hsum += __shfl_xor(hsum, 16);
-  hsum += __shfl_xor(hsum, 32);
+  hsum = xor32_sum(xor16_sum(hsum));
   const float hid = fmaxf(hsum + b1_u, 0.f);
   float a0 = b2, a1 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 16; k += 2) {
-    a0 = fmaf(w2[k >> 2][k & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hid), k)), a0);
-    a1 = fmaf(w2[(k + 1) >> 2][(k + 1) & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hid), k + 1)), a1);
-  }
+  // hidden unit k sits in lane k of every row of 16 (the sums above made the four rows equal): DPP row_share hands it to the whole
+  // row inside the FMA's operand fetch (a v_readlane per unit went through an SGPR, with its wait states)
+  sfor<8>([&](auto kk) {
+    constexpr int k = 2 * decltype(kk)::value;
+    a0 = fmaf(w2[k >> 2][k & 3], dpp_mov<0x150 + k>(hid), a0);
+    a1 = fmaf(w2[(k + 1) >> 2][(k + 1) & 3], dpp_mov<0x150 + k + 1>(hid), a1);
+  });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   return a0 + a1;
 }
@@ -1107,8 +1119,7 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    s4[e] += __shfl_xor(s4[e], 16);
-    s4[e] += __shfl_xor(s4[e], 32);
+    s4[e] = xor32_sum(xor16_sum(s4[e]));
   }
   if (lane < 16) lds4(PART + (wave * 64 + 4 * c4) * 4) = s4;
   lds_barrier();
