@@ -62,7 +62,9 @@ int nutls_destroy(nutls_handle* h);
 /* Replaces: one runner(...) call for all B streams (interpreter_proposed.py:215-350) with the
  * cur->prev echo folded in.  mag_in / mag_out: DEVICE pointers to [B, 256] float32
  * (row = stream; bins 1..256 of |STFT|).  Asynchronous on `stream` (a hipStream_t, may be NULL
- * for the default stream); state advances by one frame. */
+ * for the default stream); state advances by one frame.  In the fused mode the kernel reads mag_in and writes mag_out
+ * directly (no staging copy): both must stay valid, and mag_in unmodified, until the work queued on `stream` has run;
+ * they may be the same buffer. */
 int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* stream);
 
 /* Same with HOST buffers: H2D copy, step, D2H copy, synchronises before returning. */
