@@ -37,72 +37,91 @@ __global__ __launch_bounds__(128) void lstm_zx_kernel(const LstmParams p, float*
   }
 }
 
-// ONE wavefront walks the frames -- the recurrence is a serial chain of `frames` steps, so what counts is the latency
-// of one step: no workgroup barrier, no LDS round trip, no memory wait on the chain.
+// ONE wavefront walks the frames -- the recurrence is a serial chain of `frames` steps, so what counts is the issue
+// count and latency of one step: no workgroup barrier, no LDS round trip, no memory wait on the chain.
 //   lane 2u + p (u < 21): p = 0 owns gate columns i, f of unit u, p = 1 owns g, o (Keras column = gate * 21 + u);
-//   h_{t-1} is broadcast with 21 v_readlane (lane 2u -> SGPR), the two lanes of a unit swap their gates with one
-//   DPP quad permute, c_t / h_t live in the p = 0 lane;  zx is prefetched eight frames ahead in registers and
-//   h_t / c_t (frame t's arena slot) are fire-and-forget stores.  tanh(x) = 2 sigmoid(2x) - 1 keeps both lanes
-//   of a unit on one instruction stream.
+//   lanes 42..63 repeat lanes 40 / 41 (same values to the same addresses: no exec masking anywhere in the loop).
+//   h_{t-1} is broadcast with 21 v_readlane into 21 SGPRs up front (back to back: a readlane directly followed by
+//   its consumer costs two wait states each), the two columns of a lane advance together on v_pk_fma_f32 (21 packed
+//   FMAs instead of 42), the two lanes of a unit swap their gates with one DPP quad permute and BOTH keep c_t / h_t;
+//   the p = 0 lane stores c_t, the p = 1 lane h_t (one store instruction per frame).  zx is prefetched eight frames
+//   ahead in registers.  The loop over full 8-frame groups has no branch, so the compiler counts the stores behind a
+//   group's prefetch exactly (vmcnt is one in-order counter for loads and stores on gfx9: behind a branch it assumed
+//   no store had been issued and waited for all of them at every group).  tanh(x) = 2 sigmoid(2x) - 1 keeps both
+//   lanes of a unit on one instruction stream.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int CTRL>
 __device__ __forceinline__ float scan_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 __global__ __launch_bounds__(64) void lstm_scan_kernel(const LstmParams p, const float* __restrict__ zx, int frames) {
   constexpr int PF = 8;                         // frames of zx in flight
+  constexpr float LOG2E = 1.44269504088896341f;
   const int lane = threadIdx.x;
-  const int u = lane >> 1, pr = lane & 1;
-  const bool live = lane < 2 * U;
-  const int na = live ? (pr ? 2 * U + u : u) : 0, nb = live ? (pr ? 3 * U + u : U + u) : 0;
-  float wa[U], wb[U];
+  const int u = (lane >> 1) < U ? (lane >> 1) : U - 1, pr = lane & 1;
+  const int na = pr ? 2 * U + u : u, nb = pr ? 3 * U + u : U + u;
+  f32x2 w[U];
 #pragma unroll
-  for (int k = 0; k < U; ++k) {
-    wa[k] = p.whT[k * G4 + na];
-    wb[k] = p.whT[k * G4 + nb];
-  }
+  for (int k = 0; k < U; ++k) w[k] = f32x2{p.whT[k * G4 + na], p.whT[k * G4 + nb]};
   const float ka = pr ? 2.0f : 1.0f, da = pr ? -1.0f : 0.0f;      // column a: sigmoid (p = 0) or tanh (p = 1)
-  float h = (live && !pr) ? p.h_in[u] : 0.f;
-  float c = (live && !pr) ? p.c_in[u] : 0.f;
-  float za[PF], zb[PF], ya[PF], yb[PF];
+  const f32x2 sc = {-ka * LOG2E, -LOG2E};                          // sigmoid(k x) = 1 / (1 + 2^(-k log2e x))
+  float h = p.h_in[u], c = p.c_in[u];
+  float* __restrict__ outp = pr ? p.h_out + u : p.c_out + u;
+  const float* zp = zx + na;
+  const int dnb = nb - na;
+  f32x2 z[PF], y[PF];
+  auto step = [&](const f32x2 zt, const int t) {
+    const int hbits = __builtin_bit_cast(int, h);
+    float hs[U];
 #pragma unroll
-  for (int k = 0; k < PF; ++k) {
-    const int t = k < frames ? k : frames - 1;
-    za[k] = zx[static_cast<size_t>(t) * G4 + na];
-    zb[k] = zx[static_cast<size_t>(t) * G4 + nb];
-  }
-  for (int t0 = 0; t0 < frames; t0 += PF) {
+    for (int j = 0; j < U; ++j) hs[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(hbits, 2 * j));
+    __builtin_amdgcn_sched_barrier(0);          // all 21 broadcasts before the first FMA
+    f32x2 r0 = zt, r1 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < PF; ++k) {              // the block after this one
-      const int t = t0 + PF + k < frames ? t0 + PF + k : frames - 1;
-      ya[k] = zx[static_cast<size_t>(t) * G4 + na];
-      yb[k] = zx[static_cast<size_t>(t) * G4 + nb];
+    for (int j = 0; j < U; ++j) {
+      const f32x2 hj = {hs[j], hs[j]};
+      if (j & 1) r1 = __builtin_elementwise_fma(w[j], hj, r1);
+      else       r0 = __builtin_elementwise_fma(w[j], hj, r0);
     }
+    const f32x2 e = (r0 + r1) * sc;
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + 1.0f;
+    const float ga = fmaf(ka, __builtin_amdgcn_rcpf(d.x), da);     // i (p = 0) / g (p = 1)
+    const float gb = __builtin_amdgcn_rcpf(d.y);                   // f (p = 0) / o (p = 1)
+    const float gg = scan_dpp<0xB1>(ga), gx = scan_dpp<0xB1>(gb);  // quad_perm [1,0,3,2]: the other lane of the unit
+    const float gf = pr ? gx : gb, go = pr ? gb : gx;
+    c = fmaf(gf, c, ga * gg);
+    h = go * tanh_fast(c);
+    outp[static_cast<size_t>(t) * p.sstride] = pr ? h : c;
+  };
+  auto fetch = [&](f32x2 (&d)[PF], const int tb) {        // the group of frames tb .. tb + 7 (clamped: never past the block)
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
-      const int t = t0 + k;
-      if (t < frames) {
-        float ra0 = za[k], ra1 = 0.f, rb0 = zb[k], rb1 = 0.f;
-        const int hbits = __builtin_bit_cast(int, h);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const float hj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(hbits, 2 * j));
-          if (j & 1) { ra1 = fmaf(wa[j], hj, ra1); rb1 = fmaf(wb[j], hj, rb1); }
-          else       { ra0 = fmaf(wa[j], hj, ra0); rb0 = fmaf(wb[j], hj, rb0); }
-        }
-        const float ga = ka * sigm(ka * (ra0 + ra1)) + da;      // i (p = 0) / g (p = 1)
-        const float gb = sigm(rb0 + rb1);                       // f (p = 0) / o (p = 1)
-        const float gg = scan_dpp<0xB1>(ga), go = scan_dpp<0xB1>(gb);      // quad_perm [1,0,3,2]: the other lane of the unit
-        c = gb * c + ga * gg;
-        h = go * tanh_fast(c);
-        if (live && !pr) {
-          p.c_out[static_cast<size_t>(t) * p.sstride + u] = c;
-          p.h_out[static_cast<size_t>(t) * p.sstride + u] = h;
-        }
-      }
+      const int t = tb + k < frames ? tb + k : frames - 1;
+      d[k] = f32x2{zp[static_cast<size_t>(t) * G4], zp[static_cast<size_t>(t) * G4 + dnb]};
     }
+  };
+  // two groups per round, z and y swapping roles (no register copies: a copy deferred to the loop head waits with the
+  // preheader's count and drains the stores of the group before it)
+  // h, c (and the weights before them) resident before the loop: a load still counted as pending at the loop head
+  // would be waited for with the preheader's count on every round
+  asm volatile("; h, c resident" : "+v"(h), "+v"(c));
+  fetch(z, 0);
+  int t0 = 0;
+  for (; t0 + 2 * PF <= frames; t0 += 2 * PF) {
+    fetch(y, t0 + PF);
 #pragma unroll
-    for (int k = 0; k < PF; ++k) { za[k] = ya[k]; zb[k] = yb[k]; }
+    for (int k = 0; k < PF; ++k) step(z[k], t0 + k);
+    fetch(z, t0 + 2 * PF);
+#pragma unroll
+    for (int k = 0; k < PF; ++k) step(y[k], t0 + PF + k);
   }
+  fetch(y, t0 + PF);                            // the last frames % 16 frames
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    if (t0 + k < frames) step(z[k], t0 + k);
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    if (t0 + PF + k < frames) step(y[k], t0 + PF + k);
 }
 
 // grid = frames; 128 threads
