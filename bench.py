@@ -119,6 +119,7 @@ def bench_offline(args, rank, world, local_rank):
     t0 = time.perf_counter()
     for s in range(args.steps):
         off.process_block_device(pool[s % 4], out)
+    t_enq = time.perf_counter() - t0                  # the host's share: all launches of all blocks enqueued
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all())
@@ -130,7 +131,8 @@ def bench_offline(args, rank, world, local_rank):
                           "config": {"workload": "offline / block mode: ONE utterance, %d consecutive frames per call (SURVEY 8f.2)" % T_,
                                      "frames_per_block": T_, "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames)",
                                      "mode": "per-layer kernels, frame index as stream index, single-wavefront LSTM scan, block pipeline"},
-                          "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6)}))
+                          "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6),
+                          "host_enqueue_ms_per_block": round(1e3 * t_enq / args.steps, 4)}))
     off.close()
 
 

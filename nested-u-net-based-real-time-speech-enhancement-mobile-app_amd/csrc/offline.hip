@@ -16,9 +16,8 @@ namespace nutls {
 
 namespace {
 constexpr int U = 21, G4 = 84;
-// v_exp_f32 / v_rcp_f32 forms (as in the persistent kernel): the scan is a serial chain, IEEE expf / division are 10-30 instructions each
-__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+// (sigmoid / tanh of the scan: v_exp_f32 / v_rcp_f32 forms as in the persistent kernel -- the scan is a serial chain, IEEE expf / division are
+// 10-30 instructions each)
 }  // namespace
 
 // grid = frames; 128 threads.  zx [frames][84]
@@ -43,8 +42,8 @@ __global__ __launch_bounds__(128) void lstm_zx_kernel(const LstmParams p, float*
 //   lanes 42..63 repeat lanes 40 / 41 (same values to the same addresses: no exec masking anywhere in the loop).
 //   h_{t-1} is broadcast with 21 v_readlane into 21 SGPRs up front (back to back: a readlane directly followed by
 //   its consumer costs two wait states each), the two columns of a lane advance together on v_pk_fma_f32 (21 packed
-//   FMAs instead of 42), the two lanes of a unit swap their gates with one DPP quad permute and BOTH keep c_t / h_t;
-//   the p = 0 lane stores c_t, the p = 1 lane h_t (one store instruction per frame).  zx is prefetched eight frames
+//   FMAs instead of 42), the p = 0 lane of a unit reads the other lane's gates through DPP quad permutes and keeps
+//   c_t / h_t; it stores c_t, the p = 1 lane stores h_t (one store instruction per frame).  zx is prefetched eight frames
 //   ahead in registers.  The loop over full 8-frame groups has no branch, so the compiler counts the stores behind a
 //   group's prefetch exactly (vmcnt is one in-order counter for loads and stores on gfx9: behind a branch it assumed
 //   no store had been issued and waited for all of them at every group).  tanh(x) = 2 sigmoid(2x) - 1 keeps both
@@ -87,11 +86,13 @@ __global__ __launch_bounds__(64) void lstm_scan_kernel(const LstmParams p, const
     const f32x2 d = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + 1.0f;
     const float ga = fmaf(ka, __builtin_amdgcn_rcpf(d.x), da);     // i (p = 0) / g (p = 1)
     const float gb = __builtin_amdgcn_rcpf(d.y);                   // f (p = 0) / o (p = 1)
-    const float gg = scan_dpp<0xB1>(ga), gx = scan_dpp<0xB1>(gb);  // quad_perm [1,0,3,2]: the other lane of the unit
-    const float gf = pr ? gx : gb, go = pr ? gb : gx;
-    c = fmaf(gf, c, ga * gg);
-    h = go * tanh_fast(c);
-    outp[static_cast<size_t>(t) * p.sstride] = pr ? h : c;
+    // c_t, h_t are kept by the p = 0 lane of a unit (own f, the p = 1 lane's g and o through DPP quad_perm [1,0,3,2]);
+    // what the p = 1 lane computes beside it is never read.  Its store slot takes the h of its neighbour ([0,0,2,2]).
+    c = fmaf(gb, c, ga * scan_dpp<0xB1>(ga));
+    const float th = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(c * (2.0f * LOG2E))), -2.0f, 1.0f);
+    h = scan_dpp<0xB1>(gb) * th;
+    const float hn = scan_dpp<0xA0>(h);
+    outp[static_cast<size_t>(t) * p.sstride] = pr ? hn : c;
   };
   auto fetch = [&](f32x2 (&d)[PF], const int tb) {        // the group of frames tb .. tb + 7 (clamped: never past the block)
 #pragma unroll
