@@ -135,7 +135,7 @@ struct Engine {
   int offline = 0;       // > 0: offline / block handle for up to this many frames per call (arena slot 0 = carried state)
   std::vector<Launch> plan_off;   // plan[0] with 'previous frame' = one arena slot earlier
   bool off_bf16 = false;          // block mode: convs on the bf16 matrix pipe where the container holds int8 kernels (NUTLS_OFFLINE_FP32=1: the fp32-MFMA kernels)
-  float* zx = nullptr;   // [offline][84] LSTM input products of a block
+  float* zx = nullptr;   // [offline + kScanReadAhead][84] LSTM input products of a block
   int ctfa_causal = 0;   // offline handles: 1 = true 32-frame causal average in the CTFA frequency branch (proposed.py:143-147)
   float* ta_hist = nullptr;   // [12 stages][31 + offline][64] time-attention history (causal mode)
   // block pipeline of an offline handle: the block is cut into chunks of consecutive frames, chunk c runs on its own
@@ -1254,7 +1254,7 @@ static int build_offline_plan(Engine* e) {
   }
   if (g + 2 > Engine::kGroups) return fail(NUTLS_ERR_ARG, "offline plan: more bottlenecks than pipeline groups");      // (the last event of a chunk is its join event)
   // (the chunk streams and their events are created when a block first runs with that many chunks: ensure_chunk_streams)
-  int rc = dev_alloc(e, static_cast<size_t>(e->offline) * 84, &e->zx, true);
+  int rc = dev_alloc(e, (static_cast<size_t>(e->offline) + kScanReadAhead) * 84, &e->zx, true);
   if (rc) return rc;
   return dev_alloc(e, static_cast<size_t>(12) * (31 + e->offline) * 64, &e->ta_hist, true);
 }

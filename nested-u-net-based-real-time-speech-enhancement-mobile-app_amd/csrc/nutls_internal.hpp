@@ -92,7 +92,8 @@ struct LstmParams {
 };
 hipError_t launch_lstm(const LstmParams& p, hipStream_t s);
 // offline / block mode (offline.hip): the same cell over `frames` consecutive frames of one utterance
-hipError_t launch_lstm_block(const LstmParams& p, float* zx /* [frames][84] scratch */, int frames, hipStream_t s);
+constexpr int kScanReadAhead = 16;   // rows the scan's prefetch reads past the frames it was given (values never used): slack rows of the zx buffer
+hipError_t launch_lstm_block(const LstmParams& p, float* zx /* [frames + kScanReadAhead][84] scratch */, int frames, hipStream_t s);
 
 // Dilated-dense bottleneck of the baseline variant (see ddb_device.hpp).  Weights transposed so the
 // output channel is the fastest index (consecutive threads read consecutive floats).

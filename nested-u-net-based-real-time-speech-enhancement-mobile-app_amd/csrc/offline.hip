@@ -16,6 +16,7 @@ namespace nutls {
 
 namespace {
 constexpr int U = 21, G4 = 84;
+constexpr float kLog2e = 1.44269504088896341f;
 // (sigmoid / tanh of the scan: v_exp_f32 / v_rcp_f32 forms as in the persistent kernel -- the scan is a serial chain, IEEE expf / division are
 // 10-30 instructions each)
 }  // namespace
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(128) void lstm_zx_kernel(const LstmParams p, float*
   if (tid < G4) {
     float a = p.bias[tid];
     for (int k = 0; k < p.Din; ++k) a = fmaf(p.wxT[k * G4 + tid], v[k], a);
-    zx[static_cast<size_t>(b) * G4 + tid] = a;
+    // stored as the exponent the scan feeds to v_exp_f32: sigmoid(x) = 1 / (1 + 2^(-log2e x)), tanh(x) = 2 sigmoid(2x) - 1 (column g)
+    zx[static_cast<size_t>(b) * G4 + tid] = a * (tid >= 2 * U && tid < 3 * U ? -2.0f * kLog2e : -kLog2e);
   }
 }
 
@@ -55,19 +57,17 @@ __device__ __forceinline__ float scan_dpp(float v) {
 }
 __global__ __launch_bounds__(64) void lstm_scan_kernel(const LstmParams p, const float* __restrict__ zx, int frames) {
   constexpr int PF = 8;                         // frames of zx in flight
-  constexpr float LOG2E = 1.44269504088896341f;
   const int lane = threadIdx.x;
   const int u = (lane >> 1) < U ? (lane >> 1) : U - 1, pr = lane & 1;
   const int na = pr ? 2 * U + u : u, nb = pr ? 3 * U + u : U + u;
+  const float ka = pr ? 2.0f : 1.0f, da = pr ? -1.0f : 0.0f;      // column a: sigmoid (p = 0) or tanh (p = 1)
+  const f32x2 sc = {-ka * kLog2e, -kLog2e};                          // sigmoid(k x) = 1 / (1 + 2^(-k log2e x))
   f32x2 w[U];
 #pragma unroll
-  for (int k = 0; k < U; ++k) w[k] = f32x2{p.whT[k * G4 + na], p.whT[k * G4 + nb]};
-  const float ka = pr ? 2.0f : 1.0f, da = pr ? -1.0f : 0.0f;      // column a: sigmoid (p = 0) or tanh (p = 1)
-  const f32x2 sc = {-ka * LOG2E, -LOG2E};                          // sigmoid(k x) = 1 / (1 + 2^(-k log2e x))
+  for (int k = 0; k < U; ++k) w[k] = f32x2{p.whT[k * G4 + na], p.whT[k * G4 + nb]} * sc;      // exponent scale folded in (zx carries it too)
   float h = p.h_in[u], c = p.c_in[u];
   float* __restrict__ outp = pr ? p.h_out + u : p.c_out + u;
-  const float* zp = zx + na;
-  const int dnb = nb - na;
+  const float* zp = zx + na;                    // column b = column a + 21 for both lanes of a unit
   f32x2 z[PF], y[PF];
   auto step = [&](const f32x2 zt, const int t) {
     const int hbits = __builtin_bit_cast(int, h);
@@ -75,48 +75,48 @@ __global__ __launch_bounds__(64) void lstm_scan_kernel(const LstmParams p, const
 #pragma unroll
     for (int j = 0; j < U; ++j) hs[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(hbits, 2 * j));
     __builtin_amdgcn_sched_barrier(0);          // all 21 broadcasts before the first FMA
-    f32x2 r0 = zt, r1 = {0.f, 0.f};
+    f32x2 r0 = zt, r1 = {0.f, 0.f};             // two chains: a packed FMA that reads the one before it costs a wait state
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const f32x2 hj = {hs[j], hs[j]};
       if (j & 1) r1 = __builtin_elementwise_fma(w[j], hj, r1);
       else       r0 = __builtin_elementwise_fma(w[j], hj, r0);
     }
-    const f32x2 e = (r0 + r1) * sc;
-    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + 1.0f;
+    const f32x2 r = r0 + r1;
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(r.x), __builtin_amdgcn_exp2f(r.y)} + 1.0f;
     const float ga = fmaf(ka, __builtin_amdgcn_rcpf(d.x), da);     // i (p = 0) / g (p = 1)
     const float gb = __builtin_amdgcn_rcpf(d.y);                   // f (p = 0) / o (p = 1)
     // c_t, h_t are kept by the p = 0 lane of a unit (own f, the p = 1 lane's g and o through DPP quad_perm [1,0,3,2]);
     // what the p = 1 lane computes beside it is never read.  Its store slot takes the h of its neighbour ([0,0,2,2]).
     c = fmaf(gb, c, ga * scan_dpp<0xB1>(ga));
-    const float th = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(c * (2.0f * LOG2E))), -2.0f, 1.0f);
+    const float th = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(c * (2.0f * kLog2e))), -2.0f, 1.0f);
     h = scan_dpp<0xB1>(gb) * th;
     const float hn = scan_dpp<0xA0>(h);
     outp[static_cast<size_t>(t) * p.sstride] = pr ? hn : c;
   };
-  auto fetch = [&](f32x2 (&d)[PF], const int tb) {        // the group of frames tb .. tb + 7 (clamped: never past the block)
+  // the group of eight frames at q: 16 loads at immediate offsets from one pointer, no clamping -- the last rounds read
+  // up to 16 rows past the block (rows of the next chunk or the slack rows of the buffer: kScanReadAhead, never used)
+  auto fetch = [&](f32x2 (&d)[PF], const float* q) {
 #pragma unroll
-    for (int k = 0; k < PF; ++k) {
-      const int t = tb + k < frames ? tb + k : frames - 1;
-      d[k] = f32x2{zp[static_cast<size_t>(t) * G4], zp[static_cast<size_t>(t) * G4 + dnb]};
-    }
+    for (int k = 0; k < PF; ++k) d[k] = f32x2{q[k * G4], q[k * G4 + U]};
   };
   // two groups per round, z and y swapping roles (no register copies: a copy deferred to the loop head waits with the
   // preheader's count and drains the stores of the group before it)
   // h, c (and the weights before them) resident before the loop: a load still counted as pending at the loop head
   // would be waited for with the preheader's count on every round
   asm volatile("; h, c resident" : "+v"(h), "+v"(c));
-  fetch(z, 0);
+  fetch(z, zp);
   int t0 = 0;
   for (; t0 + 2 * PF <= frames; t0 += 2 * PF) {
-    fetch(y, t0 + PF);
+    fetch(y, zp + PF * G4);
 #pragma unroll
     for (int k = 0; k < PF; ++k) step(z[k], t0 + k);
-    fetch(z, t0 + 2 * PF);
+    fetch(z, zp + 2 * PF * G4);
+    zp += 2 * PF * G4;
 #pragma unroll
     for (int k = 0; k < PF; ++k) step(y[k], t0 + PF + k);
   }
-  fetch(y, t0 + PF);                            // the last frames % 16 frames
+  fetch(y, zp + PF * G4);                       // the last frames % 16 frames
 #pragma unroll
   for (int k = 0; k < PF; ++k)
     if (t0 + k < frames) step(z[k], t0 + k);
