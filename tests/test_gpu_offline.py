@@ -35,6 +35,26 @@ def test_block_mode_equals_golden_and_streaming(clip, max_frames):
     assert rms(got[:40], stream) < 1e-6
 
 
+def test_ragged_block_lengths_cover_every_tail_of_the_scan(clip):
+    """The LSTM scan walks 16 frames per round (two prefetch groups of eight) and finishes with guarded steps: block
+    lengths below one group, between one and two groups, one past a round ... on ONE utterance, state carried."""
+    sizes = [1, 9, 15, 16, 17, 23, 8, 31, 33, 40, 2, 14]
+    assert sum(sizes) <= len(clip["mags_in"])
+    off = NutlsOffline(max_frames=40)
+    out, t = [], 0
+    for n in sizes:
+        out.append(off.process(clip["mags_in"][t:t + n]))
+        assert out[-1].shape == (n, 256)
+        t += n
+    off.close()
+    got = np.concatenate(out)
+    assert rms(got, clip["mags_out"][:t]) < 2e-5
+    whole = NutlsOffline(max_frames=256)
+    want = whole.process(clip["mags_in"][:t])
+    whole.close()
+    assert rms(got, want) < 1e-6
+
+
 def test_block_mode_bf16_pipe_equals_the_fp32_mfma_kernels(clip, monkeypatch):
     """The block mode's convs run on the bf16 matrix pipe (conv_bf16x3_kernel: int8 weights widened to bf16, activations
     split error-free into three bf16 pieces -- every product exact, fp32 accumulation); NUTLS_OFFLINE_FP32=1 keeps the
