@@ -129,7 +129,7 @@ def bench_offline(args, rank, world, local_rank):
                           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic magnitudes 0.25*|N(0,1)|, trained weights",
                           "config": {"workload": "offline / block mode: ONE utterance, %d consecutive frames per call (SURVEY 8f.2)" % T_,
-                                     "frames_per_block": T_, "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames)",
+                                     "frames_per_block": T_, "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames, 3 from 768)",
                                      "mode": "per-layer kernels, frame index as stream index, single-wavefront LSTM scan, block pipeline"},
                           "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6),
                           "host_enqueue_ms_per_block": round(1e3 * t_enq / args.steps, 4)}))

@@ -109,11 +109,12 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
 #define NUTLS_CTFA_CAUSAL32 1
 int nutls_offline_set_ctfa_mode(nutls_handle* h, int mode);
 /* Block pipeline of an offline handle.  Only the 13 LSTM recurrences are serial over the frames of a block, and every
- * layer is causal in time, so a block is cut into `chunks` runs of consecutive frames: chunk c executes on its own HIP
- * stream one bottleneck behind chunk c-1 (it needs that chunk's last frame: previous-frame taps, h / c, time-attention
- * history), and the scans of one chunk overlap the convolutions of the others.  Results do not depend on the chunk
- * count.  chunks: 1 .. 16, or 0 (default) = chosen from the block length (2 from 256 frames on: with more than two
- * chunk streams the runtime's cross-stream dependencies cost more than the overlap gains). */
+ * layer is causal in time, so a block is cut into `chunks` runs of consecutive frames: chunk 0 executes on the caller's
+ * stream, chunk c > 0 on its own HIP stream one bottleneck behind chunk c-1 (it needs that chunk's last frame:
+ * previous-frame taps, h / c, time-attention history), and the scans of one chunk overlap the convolutions of the others.
+ * Results do not depend on the chunk count.  chunks: 1 .. 16, or 0 (default) = chosen from the block length (2 from 256
+ * frames on, 3 from 768: the GPU serves four compute queues at a time, a pipeline with more queues than that
+ * serialises -- 4 chunks need GPU_MAX_HW_QUEUES >= 8 and are no faster than 3). */
 int nutls_offline_set_pipeline(nutls_handle* h, int chunks);
 /* Same with HOST buffers (synchronises). */
 int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames);

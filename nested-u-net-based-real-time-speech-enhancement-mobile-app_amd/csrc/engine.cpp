@@ -1355,7 +1355,7 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
   const size_t bytes = static_cast<size_t>(n_frames) * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
   int C = e->ochunks;
-  if (C == 0) C = n_frames >= 256 ? 2 : 1;
+  if (C == 0) C = n_frames >= 768 ? 3 : n_frames >= 256 ? 2 : 1;      // (four compute queues are served at a time: chunk 0 rides on the caller's stream, three chunks = three queues)
   C = std::max(1, std::min({C, static_cast<int>(Engine::kMaxChunks), n_frames}));
   if (C == 1) {
     int rc = launch_block_range(e, 0, e->plan_off.size(), 0, n_frames, true, s);
@@ -1365,9 +1365,13 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
     // the previous-frame taps of all its layers, the LSTM's h / c and the time-attention history of frame t0-1 exist
     const int per = (n_frames + C - 1) / C;
     const int n_groups = e->ogroup.back() + 1;
-    if (int rc0 = ensure_chunk_streams(e, C)) return rc0;
+    // chunk 0 runs on the caller's stream, chunk c > 0 on chunk stream c-1: a block with C chunks keeps C hardware queues
+    // busy, not C + 1 with the caller's queue parked on the join -- the GPU serves four compute queues at a time, and a fifth
+    // one that holds a dependency of the others serialises the whole pipeline (4 chunks: 11.7 ms instead of < 4.5)
+    if (int rc0 = ensure_chunk_streams(e, C - 1)) return rc0;
+    auto cs = [&](int c) { return c == 0 ? s : e->ostream[c - 1]; };
     HIP_TRY(hipEventRecord(e->oev_fork, s));
-    for (int c = 0; c < C; ++c) HIP_TRY(hipStreamWaitEvent(e->ostream[c], e->oev_fork, 0));
+    for (int c = 1; c < C; ++c) HIP_TRY(hipStreamWaitEvent(cs(c), e->oev_fork, 0));
     int rc = NUTLS_OK;
     size_t first = 0;
     for (int g = 0; g < n_groups && rc == NUTLS_OK; ++g) {
@@ -1376,17 +1380,17 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
       for (int c = 0; c < C && rc == NUTLS_OK; ++c) {
         const int t0 = c * per, n = std::min(per, n_frames - t0);
         if (n <= 0) continue;
-        if (c > 0 && hipStreamWaitEvent(e->ostream[c], e->oev[(c - 1) * Engine::kGroups + g], 0) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipStreamWaitEvent");
-        if (rc == NUTLS_OK) rc = launch_block_range(e, first, last, t0, n, false, e->ostream[c]);
-        if (rc == NUTLS_OK && hipEventRecord(e->oev[c * Engine::kGroups + g], e->ostream[c]) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipEventRecord");
+        if (c > 0 && hipStreamWaitEvent(cs(c), e->oev[(c - 1) * Engine::kGroups + g], 0) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipStreamWaitEvent");
+        if (rc == NUTLS_OK) rc = launch_block_range(e, first, last, t0, n, false, cs(c));
+        if (rc == NUTLS_OK && c + 1 < C && hipEventRecord(e->oev[c * Engine::kGroups + g], cs(c)) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipEventRecord");
       }
       first = last;
     }
     // join: the caller's stream continues after every chunk stream -- also when a launch failed half way, so that
     // whatever was enqueued is ordered before the caller's next work
-    for (int c = 0; c < C; ++c) {
-      hipEvent_t done = e->oev[c * Engine::kGroups + Engine::kGroups - 1];
-      if (hipEventRecord(done, e->ostream[c]) == hipSuccess) (void)hipStreamWaitEvent(s, done, 0);
+    for (int c = 1; c < C; ++c) {
+      hipEvent_t done = e->oev[(c - 1) * Engine::kGroups + Engine::kGroups - 1];      // the spare slot of chunk stream c-1's events
+      if (hipEventRecord(done, cs(c)) == hipSuccess) (void)hipStreamWaitEvent(s, done, 0);
     }
     if (rc) return rc;
     if (e->ctfa_causal)
