@@ -142,7 +142,7 @@ struct Engine {
   // HIP stream one bottleneck behind chunk c-1 (every layer is causal in time: frame t needs frames <= t only)
   static constexpr int kMaxChunks = 16, kGroups = 16;
   std::vector<hipStream_t> ostream;
-  std::vector<hipEvent_t> oev;          // [chunk][group]: chunk's launches up to and including the group's LSTM are enqueued
+  std::vector<hipEvent_t> oev;          // [chunk stream][2 * kGroups]: slot g = the chunk's conv-like launches of group g are enqueued, kGroups + g = its LSTM of group g
   hipEvent_t oev_fork = nullptr;
   int ochunks = 0;                      // 0 = chosen from the block length
   std::vector<int> ogroup;              // launch index of plan_off -> group (a group ends with an LSTM)
@@ -1324,7 +1324,7 @@ static int ensure_chunk_streams(Engine* e, int chunks) {
     hipStream_t st = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     e->ostream.push_back(st);
-    for (int k = 0; k < Engine::kGroups; ++k) {
+    for (int k = 0; k < 2 * Engine::kGroups; ++k) {      // per group: convs done, LSTM done
       hipEvent_t ev = nullptr;
       HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       e->oev.push_back(ev);
@@ -1377,19 +1377,31 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
     for (int g = 0; g < n_groups && rc == NUTLS_OK; ++g) {
       size_t last = first;
       while (last < e->plan_off.size() && e->ogroup[last] == g) ++last;
+      // a group = its conv-like layers, then its LSTM (input products, scan, Dense) if it has one: two dependencies per
+      // group -- chunk c's convs start when chunk c-1's convs of the group are done (previous-frame taps, time-attention
+      // history), its scan when that chunk's scan is (h / c); the convs do not wait for a scan they do not read
+      size_t mid = last;
+      for (size_t i = first; i < last; ++i)
+        if (e->plan_off[i].kind == Launch::LSTM) { mid = i; break; }
+      constexpr int EV = 2 * Engine::kGroups;
       for (int c = 0; c < C && rc == NUTLS_OK; ++c) {
         const int t0 = c * per, n = std::min(per, n_frames - t0);
         if (n <= 0) continue;
-        if (c > 0 && hipStreamWaitEvent(cs(c), e->oev[(c - 1) * Engine::kGroups + g], 0) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipStreamWaitEvent");
-        if (rc == NUTLS_OK) rc = launch_block_range(e, first, last, t0, n, false, cs(c));
-        if (rc == NUTLS_OK && c + 1 < C && hipEventRecord(e->oev[c * Engine::kGroups + g], cs(c)) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipEventRecord");
+        for (int half = 0; half < 2 && rc == NUTLS_OK; ++half) {
+          const size_t a = half ? mid : first, b = half ? last : mid;
+          if (a == b) continue;
+          const int slot = half * Engine::kGroups + g;
+          if (c > 0 && hipStreamWaitEvent(cs(c), e->oev[(c - 1) * EV + slot], 0) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipStreamWaitEvent");
+          if (rc == NUTLS_OK) rc = launch_block_range(e, a, b, t0, n, false, cs(c));
+          if (rc == NUTLS_OK && c + 1 < C && hipEventRecord(e->oev[c * EV + slot], cs(c)) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipEventRecord");
+        }
       }
       first = last;
     }
     // join: the caller's stream continues after every chunk stream -- also when a launch failed half way, so that
     // whatever was enqueued is ordered before the caller's next work
     for (int c = 1; c < C; ++c) {
-      hipEvent_t done = e->oev[(c - 1) * Engine::kGroups + Engine::kGroups - 1];      // the spare slot of chunk stream c-1's events
+      hipEvent_t done = e->oev[(c - 1) * 2 * Engine::kGroups + Engine::kGroups - 1];      // a spare slot of chunk stream c-1's events (groups end at kGroups - 2)
       if (hipEventRecord(done, cs(c)) == hipSuccess) (void)hipStreamWaitEvent(s, done, 0);
     }
     if (rc) return rc;
