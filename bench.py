@@ -110,30 +110,40 @@ def bench_offline(args, rank, world, local_rank):
     import torch
     import nunet_amd
     T_ = args.offline
-    off = nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, pipeline=args.offline_chunks)
+    U = max(1, args.offline_utterances)      # independent utterances, one handle and one torch stream each
+    offs = [nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, pipeline=args.offline_chunks) for _ in range(U)]
     pool = torch.from_numpy(synthetic_pool(T_, 4, 1234 + rank)).cuda()
-    out = torch.empty(T_, 256, device="cuda")
-    for s in range(max(2, args.warmup // 8)):
-        off.process_block_device(pool[s % 4], out)
+    outs = [torch.empty(T_, 256, device="cuda") for _ in range(U)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(U - 1)]
+    out = outs[0]
+
+    def blocks(n):
+        for s in range(n):
+            for u in range(U):
+                with torch.cuda.stream(streams[u]):
+                    offs[u].process_block_device(pool[(s + u) % 4], outs[u])
+
+    torch.cuda.synchronize()
+    blocks(max(2, args.warmup // 8))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        off.process_block_device(pool[s % 4], out)
+    blocks(args.steps)
     t_enq = time.perf_counter() - t0                  # the host's share: all launches of all blocks enqueued
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all())
     if rank == 0:
-        print(json.dumps({"metric": "STFT frames/sec (512-pt, 50% hop) through the NUNet-TLS frame step", "value": round(T_ * args.steps / dt, 1),
+        print(json.dumps({"metric": "STFT frames/sec (512-pt, 50% hop) through the NUNet-TLS frame step", "value": round(U * T_ * args.steps / dt, 1),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup // 8),
                           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic magnitudes 0.25*|N(0,1)|, trained weights",
-                          "config": {"workload": "offline / block mode: ONE utterance, %d consecutive frames per call (SURVEY 8f.2)" % T_,
-                                     "frames_per_block": T_, "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames, 3 from 768)",
+                          "config": {"workload": "offline / block mode: %s, %d consecutive frames per call (SURVEY 8f.2)" % ("ONE utterance" if U == 1 else "%d utterances side by side" % U, T_),
+                                     "frames_per_block": T_, "utterances": U, "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames, 3 from 768)",
                                      "mode": "per-layer kernels, frame index as stream index, single-wavefront LSTM scan, block pipeline"},
                           "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6),
                           "host_enqueue_ms_per_block": round(1e3 * t_enq / args.steps, 4)}))
-    off.close()
+    for off in offs:
+        off.close()
 
 
 def parity_check(eng_cls, pool, n_streams=4, steps=6):
@@ -194,6 +204,7 @@ def main():
     ap.add_argument("--offline", type=int, default=0, metavar="T",
                     help="offline / block mode: ONE utterance, a step = one block of T consecutive frames (frames/s of that utterance)")
     ap.add_argument("--offline-chunks", type=int, default=0, help="offline mode: chunks of the block pipeline (0 = library default)")
+    ap.add_argument("--offline-utterances", type=int, default=1, help="offline mode: independent utterances processed side by side, one handle and stream each (value = their total frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default="", help="write the per-op timeline here")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
