@@ -217,7 +217,11 @@ template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int
 __global__ __launch_bounds__(64 * NW) void conv_bf16x3_kernel(const ConvParams p) {
   constexpr int CC = CIN < 64 ? CIN : 64;
   constexpr int NCH = CIN / CC;
-  constexpr int TP = 32 * NW;
+  // ALL with four waves = K split: the four waves share ONE tile of 32 positions, wave w runs K steps w, w + 4, ... of all phases
+  // (a quarter of the weights and of the MFMAs each, 256 threads stage the rows), the partial sums meet in LDS and wave 0
+  // runs the epilogue -- the small layers are one latency chain per wave, this shortens the chain instead of widening the tile
+  constexpr bool KS = ALL && NW == 4;
+  constexpr int TP = KS ? 32 : 32 * NW;
   constexpr int PLANE_B = ((STRIDE == 1) ? CC : 2 * CC) * 2;      // bytes of one plane of a pitch unit
   constexpr int PITCH_B = 3 * PLANE_B + 16;
   constexpr int R = NT / G;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(64 * NW) void conv_bf16x3_kernel(const ConvParams p
   const int P0 = blockIdx.x * TP;
   const int total_pos = p.B << log2f;
 
-  const int ploc = wave * 32 + pl;
+  const int ploc = KS ? pl : wave * 32 + pl;
   const int myseg = ploc / seg_len, myfl = ploc - myseg * seg_len;
   const int lbase = (myseg * RS + myfl) * PITCH_B + 16 * h;
 
@@ -313,7 +317,55 @@ __global__ __launch_bounds__(64 * NW) void conv_bf16x3_kernel(const ConvParams p
     }
   };
 
-  if constexpr (ALL) {
+  if constexpr (KS) {
+    constexpr int SPP = KF * (CC / 16);          // K steps per phase
+    constexpr int S = NPH * SPP;
+    static_assert(S % 4 == 0, "K steps must deal evenly to four waves");
+    f32x4 wreg[(S / 4) * NT];
+#pragma unroll
+    for (int j = 0; j < S / 4; ++j)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wreg[j * NT + n] = wp[((4 * j + wave) * NT + n) * 64];
+    const int phase_b = (nseg * RS * PITCH_B + 255) & ~255;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) stage(ph / NCH, ph % NCH, ph * phase_b);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < S / 4; ++j) {
+      const int st = 4 * j + wave;               // wave-uniform
+      const int ph = st / SPP, r = st - ph * SPP, kf = r / (CC / 16), g = r - kf * (CC / 16);
+      const int koff = ph * phase_b + ((STRIDE == 1) ? (kf * PITCH_B) : ((kf >> 1) * PITCH_B + (kf & 1) * (CC * 2)));
+      bf16x8 b3[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        b3[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(ldsb + lbase + koff + 32 * g + q * PLANE_B));
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[j * NT + n]), b3[q], acc[n], 0, 0, 0);
+    }
+    __syncthreads();                             // every wave has read its B rows: the image becomes the exchange buffer
+    if (wave != 0) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(ldsb + ((((wave - 1) * NT + n) * 4 + q) * 64 + lane) * 16) = f32x4{acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ldsb + (((w * NT + n) * 4 + q) * 64 + lane) * 16);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[n][4 * q + i] += v[i];
+        }
+  } else if constexpr (ALL) {
     // Small layers (all phases fit LDS side by side, all weights fit the registers): everything is requested up front and there
     // is ONE barrier -- these launches are nothing but latency (20-25 us for a few microseconds of work with a barrier pair and
     // an L2 round trip per phase).
@@ -489,8 +541,12 @@ static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) 
     constexpr int cc = CIN < 64 ? CIN : 64, nph = TT * (CIN / cc), wph = KF * (cc / 16) * NT;
     const size_t phase_b = (ldsb + 255) & ~static_cast<size_t>(255);
     if constexpr (nph > 1 && nph * wph <= 48) {
-      if (nph * phase_b <= 64 * 1024)
+      if (nph * phase_b <= 64 * 1024) {
+        static const bool ksplit = [] { const char* v = getenv("NUTLS_OFFLINE_KSPLIT"); return !v || atoi(v) != 0; }();
+        if (ksplit)        // four waves on the K steps of one 32-position tile; the exchange buffer (3 waves x NT x 4 KB) re-uses the image
+          return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, true>, std::max<size_t>(nph * phase_b, 3 * NT * 4096), static_cast<unsigned>((totalb + 31) / 32), 256, p, s);
         return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, true>, nph * phase_b, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
+      }
     }
     return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, false>, ldsb, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
   }
