@@ -540,13 +540,17 @@ static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) 
     // 1-wave workgroups (the layers with few positions): all phases at once where LDS and the registers allow it
     constexpr int cc = CIN < 64 ? CIN : 64, nph = TT * (CIN / cc), wph = KF * (cc / 16) * NT;
     const size_t phase_b = (ldsb + 255) & ~static_cast<size_t>(255);
+    // four waves on the K steps of one 32-position tile where the K steps deal evenly and a wave's quarter of the weights fits
+    // its registers; the exchange buffer (3 waves x NT x 4 KB) re-uses the image
+    static const bool ksplit = [] { const char* v = getenv("NUTLS_OFFLINE_KSPLIT"); return !v || atoi(v) != 0; }();
+    if constexpr ((nph * KF * (cc / 16)) % 4 == 0 && nph * wph <= 192) {
+      const size_t need = std::max<size_t>(nph * phase_b, 3 * NT * 4096);
+      if (ksplit && need <= 128 * 1024)
+        return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, true>, need, static_cast<unsigned>((totalb + 31) / 32), 256, p, s);
+    }
     if constexpr (nph > 1 && nph * wph <= 48) {
-      if (nph * phase_b <= 64 * 1024) {
-        static const bool ksplit = [] { const char* v = getenv("NUTLS_OFFLINE_KSPLIT"); return !v || atoi(v) != 0; }();
-        if (ksplit)        // four waves on the K steps of one 32-position tile; the exchange buffer (3 waves x NT x 4 KB) re-uses the image
-          return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, true>, std::max<size_t>(nph * phase_b, 3 * NT * 4096), static_cast<unsigned>((totalb + 31) / 32), 256, p, s);
+      if (nph * phase_b <= 64 * 1024)
         return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, true>, nph * phase_b, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
-      }
     }
     return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, false>, ldsb, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
   }

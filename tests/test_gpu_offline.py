@@ -115,7 +115,9 @@ def test_offline_handle_state_get_set_addresses_the_carried_state():
     for name, n in (("state_h", 21), ("msfe6_ee_prev1", 256 * 64), ("msfe3_dd_prev2", 2 * 64)):
         a = np.zeros(n, np.float32)
         assert lib.nutls_state_get(h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), n) == 0, lib.nutls_last_error()
-        np.testing.assert_allclose(a, eng.state_get(name).reshape(-1), rtol=1e-4, atol=1e-5, err_msg=name)
+        # (two different kernels, two summation orders of the same fp32 sums -- the block mode's small layers split K over four
+        #  waves: a LayerNorm output near zero differs by up to ~1e-5 absolute)
+        np.testing.assert_allclose(a, eng.state_get(name).reshape(-1), rtol=1e-4, atol=3e-5, err_msg=name)
     # zero one state on both and continue: still the same function
     z = np.zeros(21, np.float32)
     assert lib.nutls_state_set(h, b"state_h", z.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 21) == 0
