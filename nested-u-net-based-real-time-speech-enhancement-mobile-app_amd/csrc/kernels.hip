@@ -531,10 +531,12 @@ static hipError_t launch_conv_variant(K kern, size_t lds, unsigned grid, unsigne
 
 template <int CIN, int NT, int STRIDE, int TT, int KF, int PADL, int EPI_LN, int G>
 static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) {
-  const int nw = conv_pick_nw(k, p.B, p.F_out);
   if (p.use_bf16 && p.wbf && p.wscale) {      // block mode on an int8 container: the bf16-pipe kernel
-    const size_t ldsb = conv_lds_bytes_bf16(k, p.F_out, nw);
+    // 128-position tiles from 32 k positions per launch on, below that the K-split kernel on 32-position tiles (measured at
+    // 16 k .. 1 M positions: 293 k frames/s at 16-32 k, 288 k at 64 k and above; one 1024-frame utterance, three chunks)
     const long long totalb = static_cast<long long>(p.B) * p.F_out;
+    const int nw = totalb >= 64LL * 512 ? 4 : 1;
+    const size_t ldsb = conv_lds_bytes_bf16(k, p.F_out, nw);
     if (nw == 4)
       return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, false>, ldsb, static_cast<unsigned>((totalb + 127) / 128), 256, p, s);
     // 1-wave workgroups (the layers with few positions): all phases at once where LDS and the registers allow it
@@ -554,6 +556,7 @@ static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) 
     }
     return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, false>, ldsb, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
   }
+  const int nw = conv_pick_nw(k, p.B, p.F_out);
   const size_t lds = conv_lds_bytes(k, p.F_out, nw);
   const long long total = static_cast<long long>(p.B) * p.F_out;
   if (nw == 4) {
