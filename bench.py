@@ -78,31 +78,43 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(budget_s=12.0):
-    """SURVEY 8(d): the oracle (torch-CPU restatement of the reference's step) on this box's host cores, B = 1 and
-    B = 64, bounded sample.  Threads: min(8, cores) -- on the 2 x 64-core EPYC host of the GPU boxes more threads
-    are *slower* for these small GEMMs (measured 606 frames/s at 8 threads, 240 at 32, 75 at 64)."""
+def _time_oracle(batch, threads, budget_s, max_steps=512):
+    """frames/s of the oracle at `batch` streams on `threads` host threads, over at most `budget_s` seconds."""
     import torch
     from oracle.nutls_ref import NutlsRef
-    threads = min(8, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    res = {}
-    for sb, share in ((1, 0.35), (64, 0.65)):
-        ref = NutlsRef(batch=sb)
-        x = synthetic_pool(sb, 4, 99)
-        ref.step(x[0])                        # warm-up (allocations, thread pool)
-        t0, n = time.time(), 0
-        while True:
-            ref.step(x[n % 4])
-            n += 1
-            if time.time() - t0 > budget_s * share or n >= 512:
-                break
-        dt = time.time() - t0
-        res[sb] = (sb * n / dt, n, dt)
-    return {"value": round(res[64][0], 1), "unit": "frames/s", "cores": threads, "kind": "port",
-            "value_b1": round(res[1][0], 1), "host_cores": os.cpu_count(), "cpu": cpu_model_name(),
-            "sample": "oracle/nutls_ref.py (torch-CPU fp32): %d steps of 64 streams in %.1f s (value), %d steps of 1 stream in %.1f s (value_b1), %d threads"
-                      % (res[64][1], res[64][2], res[1][1], res[1][2], threads)}
+    ref = NutlsRef(batch=batch)
+    x = synthetic_pool(batch, 4, 99)
+    ref.step(x[0])                        # warm-up (allocations, thread pool)
+    t0, n = time.time(), 0
+    while True:
+        ref.step(x[n % 4])
+        n += 1
+        if time.time() - t0 > budget_s or n >= max_steps:
+            break
+    dt = time.time() - t0
+    return batch * n / dt, n, dt
+
+
+def cpu_baseline(budget_s=12.0):
+    """SURVEY 8(d): the oracle (torch-CPU restatement of the reference's step) on this box's host cores, B = 1 and
+    B = 64, bounded sample.  `value` is taken at min(8, cores) threads -- the fastest setting on the 2 x 64-core EPYC host of
+    the GPU boxes, where more threads are *slower* for these small GEMMs (thread sweep: profiles/r04_cpu_threads.txt, written
+    by tools/cpu_thread_sweep.py) -- and the figure SURVEY 8(d) prescribes, torch.set_num_threads(os.cpu_count()), is
+    reported beside it (`value_all_cores`, a short sample: it is the slow one)."""
+    import torch
+    threads = min(8, os.cpu_count() or 1)
+    all_cores = os.cpu_count() or 1
+    b1 = _time_oracle(1, threads, budget_s * 0.3)
+    b64 = _time_oracle(64, threads, budget_s * 0.5)
+    full = _time_oracle(64, all_cores, budget_s * 0.2, max_steps=64) if all_cores != threads else b64
+    torch.set_num_threads(threads)
+    return {"value": round(b64[0], 1), "unit": "frames/s", "cores": threads, "kind": "port",
+            "value_b1": round(b1[0], 1), "value_all_cores": round(full[0], 1), "all_cores": all_cores,
+            "host_cores": os.cpu_count(), "cpu": cpu_model_name(),
+            "sample": "oracle/nutls_ref.py (torch-CPU fp32): %d steps of 64 streams in %.1f s (value, %d threads), %d steps of 1 stream in %.1f s "
+                      "(value_b1, %d threads), %d steps of 64 streams in %.1f s on %d threads (value_all_cores)"
+                      % (b64[1], b64[2], threads, b1[1], b1[2], threads, full[1], full[2], all_cores)}
 
 
 def bench_offline(args, rank, world, local_rank):
@@ -144,6 +156,54 @@ def bench_offline(args, rank, world, local_rank):
                           "host_enqueue_ms_per_block": round(1e3 * t_enq / args.steps, 4)}))
     for off in offs:
         off.close()
+
+
+def other_config_records(local_rank):
+    """The other BASELINE.json configurations, each timed over its own >= 100 ms window on this GPU, so that the driver's default
+    run records them too (the headline `value` stays configs[1]): configs[2] (baseline variant, B = 256), the per-GPU size of
+    configs[3] on one GPU (B = 2048, device-resident) and configs[4] (B = 1024 streams, host buffers in and out every call).
+    `roofline` as in the main record: algorithmic bytes of one launch / launch time / 8 TB/s; for the host-I/O
+    configuration the launch time includes the two PCIe copies (it is the step latency the caller sees)."""
+    import torch
+    import nunet_amd
+    from nunet_amd.weights import synthetic_weights, write_blob
+    recs = []
+    for (tag, variant, B, host_io) in (("configs[2]: dilated-dense baseline, batch=256, device-resident", "baseline", 256, False),
+                                       ("configs[3] size on one GPU: NUNet-TLS-LSTM, batch=2048, device-resident", "lstm", 2048, False),
+                                       ("configs[4]: NUNet-TLS-LSTM streaming, batch=1024, host buffers in/out per call", "lstm", 1024, True)):
+        weights = write_blob(synthetic_weights("baseline", seed=4321), int8_convs=True) if variant == "baseline" else None
+        eng = nunet_amd.NutlsEngine(weights, batch=B, device=local_rank, mode="fused", variant=variant)
+        pool_host = synthetic_pool(B, 4, 1234)
+        pool = torch.from_numpy(pool_host).cuda()
+        out = torch.empty(B, 256, device="cuda")
+        step = (lambda i: eng.step(pool_host[i % 4])) if host_io else (lambda i: eng.step(pool[i % 4], out))
+        for i in range(8):
+            step(i)
+        torch.cuda.synchronize()
+        k = 8
+        while True:
+            t0 = time.perf_counter()
+            for i in range(k):
+                step(i)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if dt >= 0.1 or k >= 100000:
+                break
+            k = max(k + 1, int(k * 0.11 / max(dt, 1e-6)) + 1)
+        ms = 1e3 * dt / k
+        alg = ALG_BYTES_PER_FRAME[variant] * B + eng.weight_blob_bytes()
+        gbps = alg / (ms * 1e-3) / 1e9
+        rec = {"workload": tag, "variant": variant, "streams": B, "host_io": host_io, "value": round(B * k / dt, 1), "unit": "frames/s",
+               "ms_per_step": round(ms, 4), "steps": k, "window_ms": round(1e3 * dt, 2), "streams_per_workgroup": getattr(eng, "streams_per_workgroup", 1),
+               "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBS, 4),
+                            "algorithmic_bytes_per_launch": alg}}
+        if host_io:
+            rec["step_latency_ms"] = rec["ms_per_step"]
+            rec["real_time_budget_ms"] = 16.0
+        recs.append(rec)
+        eng.close()
+        del pool, out
+    return recs
 
 
 def parity_check(eng_cls, pool, n_streams=4, steps=6):
@@ -206,6 +266,7 @@ def main():
     ap.add_argument("--offline-chunks", type=int, default=0, help="offline mode: chunks of the block pipeline (0 = library default)")
     ap.add_argument("--offline-utterances", type=int, default=1, help="offline mode: independent utterances processed side by side, one handle and stream each (value = their total frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` records of the default line (configs[2], [3]-size, [4])")
     ap.add_argument("--profile-json", default="", help="write the per-op timeline here")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -317,7 +378,7 @@ def main():
                        ("NUNet-TLS dilated-dense baseline frame step, synthetic weights seed 4321, batch=%d streams per GPU (BASELINE configs[2])" % args.batch),
                        "variant": args.variant, "host_io": bool(args.host_io), "stft_istft_on_gpu": bool(args.frontend),
                        "streams_per_gpu": args.batch, "total_streams": total_frames // args.steps, "parallelism": "stream-sharded x%d" % world,
-                       "mode": mode},
+                       "mode": mode, "streams_per_workgroup": getattr(eng, "streams_per_workgroup", 1)},
             "rtf_per_stream": round(1e3 * max_elapsed / args.steps / 16.0, 5),
             # whole-job rate x SURVEY 8(d)'s 147.93 MFLOP per frame (the graph as lowered: the CTFA frequency branch as a conv over
             # all F bins); `roofline.achieved` uses the plan's own count (144.0 M: those 1x1s at their true size) -- both stated
@@ -339,6 +400,11 @@ def main():
             import nunet_amd
             line["cpu_baseline"] = cpu_baseline()
             line["parity_rms_vs_oracle"] = parity_check(nunet_amd.NutlsEngine, pool_host)
+        default_run = (not selftest and world == 1 and mode == "fused" and args.variant == "lstm" and args.batch == 256
+                       and not (args.host_io or args.frontend))
+        if default_run and not args.no_other_configs:
+            eng.close()
+            line["other_configs"] = other_config_records(local_rank)
         print(json.dumps(line))
     eng.close()
     if world > 1:
@@ -469,9 +535,20 @@ def kernel_report(args, eng, pool, out, B, mode):
         # barrier-to-barrier LDS round trip (partials out, row-wise epilogue back in: 2 x ~0.1 us) -- the streams are
         # independent, so a layer's positions cannot be spread over more than the stream's own CU
         per_stream = [v["flops"] / B for k, v in by_layer.items() if re.search(r"_en\d?_conv\d$", k)]
-        floor_ms = sum(f / 2.0 / (32.0 * 4.0) / 1.9e9 + 0.2e-6 for f in per_stream) * 1e3
+        # (the convs run on the bf16 pipe, three MFMAs per fp32 product: 512 bf16 MAC/clk/SIMD at the dense peak / 3)
+        mac_clk = PEAK_BF16_MFMA_TFLOPS * 1e12 / 2.0 / (256 * 4 * 2.4e9) / 3.0
+        floor_ms = sum(f / 2.0 / (mac_clk * 4.0) / 1.9e9 + 0.2e-6 for f in per_stream) * 1e3
         rep["encoder_conv_stack"]["floor_ms"] = round(floor_ms, 4)
-        rep["encoder_conv_stack"]["floor"] = "sum over layers of MACs / (32 MAC/clk x 4 SIMDs x 1.9 GHz) + 0.2 us (one exchange round trip between two barriers)"
+        rep["encoder_conv_stack"]["over_floor"] = round(float(enc_ms) / floor_ms, 2)
+        rep["encoder_conv_stack"]["floor"] = ("sum over layers of MACs / (%.1f fp32-equivalent MAC/clk/SIMD [bf16 MFMA peak / 3] x 4 SIMDs x 1.9 GHz) + 0.2 us "
+                                              "(one exchange round trip between two barriers)" % mac_clk)
+        # per-layer view: level-1 convs (64 -> 32 at the stage's full resolution) vs the deeper 32 -> 32 ones, whose cost is the op's
+        # latency chain whatever they compute
+        lv1 = [t for n, t in zip(names, ms) if re.search(r"_en\d?_conv1$", n.split("#")[0])]
+        deep = [t for n, t in zip(names, ms) if re.search(r"_en\d?_conv[2-9]$", n.split("#")[0])]
+        rep["encoder_conv_stack"]["level1_layers"] = {"n": len(lv1), "us": round(1e3 * float(sum(lv1)), 2)}
+        rep["encoder_conv_stack"]["deep_layers"] = {"n": len(deep), "us": round(1e3 * float(sum(deep)), 2),
+                                                   "us_each": round(1e3 * float(sum(deep)) / max(1, len(deep)), 3)}
     if args.profile_json:
         with open(args.profile_json, "w") as f:
             json.dump({"batch": B, "mode": mode, "timeline_step_ms": float(ms.sum()),

@@ -64,7 +64,12 @@ int nutls_destroy(nutls_handle* h);
  * (row = stream; bins 1..256 of |STFT|).  Asynchronous on `stream` (a hipStream_t, may be NULL
  * for the default stream); state advances by one frame.  In the fused mode the kernel reads mag_in and writes mag_out
  * directly (no staging copy): both must stay valid, and mag_in unmodified, until the work queued on `stream` has run;
- * they may be the same buffer. */
+ * they may be the same buffer.  Side effect that differs by mode: modes 0-2 compute on the library's own [B,256] buffers
+ * (nutls_io_buffers) and copy to / from the caller's, so those library buffers hold the frame afterwards; the fused mode
+ * writes ONLY the mag_out it was given.  Whatever reads the library's mag_out buffer after a step (nutls_istft_hop) therefore
+ * needs the step to have run on the library buffers (pass the pointers of nutls_io_buffers, which is what nutls_enhance_hop
+ * does) -- after nutls_step(h, user_in, user_out) in the fused mode that buffer still holds the frame of the last step that
+ * was given it. */
 int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* stream);
 
 /* Same with HOST buffers: H2D copy, step, D2H copy, synchronises before returning. */

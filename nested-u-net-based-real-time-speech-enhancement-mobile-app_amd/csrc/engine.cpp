@@ -1111,7 +1111,7 @@ static int frontend_init(Engine* e) {
 extern "C" {
 
 const char* nutls_last_error(void) { return g_last_error.c_str(); }
-const char* nutls_version(void) { return "nutls-hip 0.3 (gfx950; fused step: fp32 results on the bf16 matrix pipe)"; }
+const char* nutls_version(void) { return "nutls-hip 0.4 (gfx950; fused step: fp32 results on the bf16 matrix pipe)"; }
 
 static int build_offline_plan(Engine* e);
 

@@ -513,19 +513,22 @@ int conv_pick_nw(ConvKind, int B, int f_out) {
 
 constexpr int kMaxDevices = 64;
 
-template <class K>
-static hipError_t launch_conv_variant(K kern, size_t lds, unsigned grid, unsigned threads, const ConvParams& p, hipStream_t s) {
-  // raise the dynamic-LDS cap once per instantiation AND device (function attributes are per device)
+template <auto Kern>
+static hipError_t launch_conv_variant(size_t lds, unsigned grid, unsigned threads, const ConvParams& p, hipStream_t s) {
+  // raise the dynamic-LDS cap once per KERNEL and device (function attributes are per kernel and per device).  The kernel is a
+  // non-type template parameter: every instantiation of conv_bf16x3_kernel / conv_mfma_kernel gets its own table -- with the
+  // kernel passed as a function argument all of them shared one (they have the same pointer type), and an instantiation that
+  // needed less than the largest cap raised so far never got its own hipFuncSetAttribute.
   static std::atomic<size_t> lds_cap[kMaxDevices] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::atomic<size_t>& cap = lds_cap[dev >= 0 && dev < kMaxDevices ? dev : 0];
   if (lds > 64 * 1024 && (lds > cap.load(std::memory_order_relaxed) || dev >= kMaxDevices)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
     cap.store(lds, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, p);
+  hipLaunchKernelGGL(Kern, dim3(grid), dim3(threads), lds, s, p);
   return hipGetLastError();
 }
 
@@ -538,7 +541,7 @@ static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) 
     const int nw = totalb >= 64LL * 512 ? 4 : 1;
     const size_t ldsb = conv_lds_bytes_bf16(k, p.F_out, nw);
     if (nw == 4)
-      return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, false>, ldsb, static_cast<unsigned>((totalb + 127) / 128), 256, p, s);
+      return launch_conv_variant<conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, false>>(ldsb, static_cast<unsigned>((totalb + 127) / 128), 256, p, s);
     // 1-wave workgroups (the layers with few positions): all phases at once where LDS and the registers allow it
     constexpr int cc = CIN < 64 ? CIN : 64, nph = TT * (CIN / cc), wph = KF * (cc / 16) * NT;
     const size_t phase_b = (ldsb + 255) & ~static_cast<size_t>(255);
@@ -548,49 +551,20 @@ static hipError_t launch_conv_t(ConvKind k, const ConvParams& p, hipStream_t s) 
     if constexpr ((nph * KF * (cc / 16)) % 4 == 0 && nph * wph <= 192) {
       const size_t need = std::max<size_t>(nph * phase_b, 3 * NT * 4096);
       if (ksplit && need <= 128 * 1024)
-        return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, true>, need, static_cast<unsigned>((totalb + 31) / 32), 256, p, s);
+        return launch_conv_variant<conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4, true>>(need, static_cast<unsigned>((totalb + 31) / 32), 256, p, s);
     }
     if constexpr (nph > 1 && nph * wph <= 48) {
       if (nph * phase_b <= 64 * 1024)
-        return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, true>, nph * phase_b, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
+        return launch_conv_variant<conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, true>>(nph * phase_b, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
     }
-    return launch_conv_variant(conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, false>, ldsb, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
+    return launch_conv_variant<conv_bf16x3_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1, false>>(ldsb, static_cast<unsigned>((totalb + 31) / 32), 64, p, s);
   }
   const int nw = conv_pick_nw(k, p.B, p.F_out);
   const size_t lds = conv_lds_bytes(k, p.F_out, nw);
   const long long total = static_cast<long long>(p.B) * p.F_out;
-  if (nw == 4) {
-    auto kern = conv_mfma_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4>;
-    // raise the dynamic-LDS cap once per instantiation AND device (function attributes are per device; handles on
-    // several GPUs share this process-wide cache)
-    static std::atomic<size_t> lds_cap[kMaxDevices] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::atomic<size_t>& cap = lds_cap[dev >= 0 && dev < kMaxDevices ? dev : 0];
-    if (lds > 64 * 1024 && (lds > cap.load(std::memory_order_relaxed) || dev >= kMaxDevices)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return e;
-      cap.store(lds, std::memory_order_relaxed);
-    }
-    const unsigned grid = static_cast<unsigned>((total + 127) / 128);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
-  } else {
-    auto kern = conv_mfma_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1>;
-    // raise the dynamic-LDS cap once per instantiation AND device (function attributes are per device; handles on
-    // several GPUs share this process-wide cache)
-    static std::atomic<size_t> lds_cap[kMaxDevices] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::atomic<size_t>& cap = lds_cap[dev >= 0 && dev < kMaxDevices ? dev : 0];
-    if (lds > 64 * 1024 && (lds > cap.load(std::memory_order_relaxed) || dev >= kMaxDevices)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return e;
-      cap.store(lds, std::memory_order_relaxed);
-    }
-    const unsigned grid = static_cast<unsigned>((total + 31) / 32);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, p);
-  }
-  return hipGetLastError();
+  if (nw == 4)
+    return launch_conv_variant<conv_mfma_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 4>>(lds, static_cast<unsigned>((total + 127) / 128), 256, p, s);
+  return launch_conv_variant<conv_mfma_kernel<CIN, NT, STRIDE, TT, KF, PADL, EPI_LN, G, 1>>(lds, static_cast<unsigned>((total + 31) / 32), 64, p, s);
 }
 
 hipError_t launch_conv(ConvKind k, const ConvParams& p, hipStream_t s) {

@@ -20,10 +20,13 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import topology as T
-from .weights import DEFAULT_WEIGHTS, read_blob
+from .weights import DEFAULT_WEIGHTS, parse_blob, read_blob
 
-# NUTLS_LIB: developer knob -- another build of the SAME library (tools/exp: timing experiments on the step kernel)
-_LIB_PATH = os.environ.get("NUTLS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnutls_hip.so")
+_HERE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnutls_hip.so")
+# NUTLS_LIB: developer knob -- another build of the SAME library (tools/exp: timing experiments on the step kernel).  Honoured only
+# together with NUTLS_DEV=1, and the library must report the version string this wrapper was written against (load_library).
+_LIB_PATH = (os.environ.get("NUTLS_LIB") if os.environ.get("NUTLS_DEV") == "1" else None) or _HERE_LIB
+ABI_VERSION_PREFIX = b"nutls-hip 0.4"
 _lib = None
 
 NUTLS_ERR_ARG = -1
@@ -56,6 +59,11 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
             "(there is no CPU fallback for the model step)" % p)
     lib = ctypes.CDLL(p)
     c = ctypes
+    lib.nutls_version.restype = c.c_char_p
+    ver = lib.nutls_version()
+    if not ver.startswith(ABI_VERSION_PREFIX):
+        raise RuntimeError("%s reports %r, this wrapper binds %r: rebuild the library (python -m nunet_amd.build)"
+                           % (p, ver, ABI_VERSION_PREFIX))
     fp = c.POINTER(c.c_float)
     lib.nutls_create.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
     lib.nutls_destroy.argtypes = [c.c_void_p]
@@ -140,6 +148,8 @@ class NutlsEngine:
         buf = ctypes.create_string_buffer(blob, len(blob))
         _check(self._lib, self._lib.nutls_create(buf, len(blob), self.VARIANTS[variant], int(batch), int(device),
                                                  ctypes.byref(self._h)))
+        # fp32 bytes of the container's tensors: what the modes that de-quantise on load (0-2) keep on the device
+        self._fp32_weight_bytes = 4 * sum(int(np.asarray(a).size) for a in parse_blob(blob).values())
         self.batch = int(batch)
         self.device = int(device)
         pin, pout = ctypes.c_void_p(), ctypes.c_void_p()
@@ -328,7 +338,7 @@ class NutlsEngine:
         """Bytes of weights one launch reads: the fused kernel's packed blob (conv kernels int8), else the fp32 tensors."""
         if self.mode == "fused":
             return 4 * int(self._lib.nutls_fused_blob_floats(self.VARIANTS[self.variant]))
-        return 11_460_668 if self.variant == "lstm" else 11_500_000      # SURVEY.md section 8(d): fp32 weights of the graph
+        return self._fp32_weight_bytes      # (lstm: 11 460 668 B = SURVEY.md section 8(d)'s fp32 weights of the graph)
 
     def profile_fused(self) -> np.ndarray:
         """One fused-mode step with workgroup 0 time-stamping every op boundary; microseconds per op."""

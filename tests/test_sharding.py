@@ -32,8 +32,8 @@ def _worker(rank, world, port, q):
     tot, mx = reduce_throughput(frames, elapsed, dist, torch.device("cpu"))
     proof = collective_proof(frames / elapsed, dist, torch.device("cpu"))
     assert proof["ranks_reduced"] == world and proof["backend"] == "gloo"
-    assert proof["per_rank"] == [stream_range(2048 + 3, r, world)[1] * 10.0 / (1.0 + r) - stream_range(2048 + 3, r, world)[0] * 10.0 / (1.0 + r)
-                                 for r in range(world)]
+    want = [(stream_range(2048 + 3, r, world)[1] - stream_range(2048 + 3, r, world)[0]) * 10 / (1.0 + r) for r in range(world)]
+    assert proof["per_rank"] == want, (proof["per_rank"], want)      # (the same expression every rank evaluated: exact)
     q.put((rank, lo, hi, tot, mx))
     dist.destroy_process_group()
 
@@ -100,3 +100,47 @@ def test_bench_py_rank_plumbing_two_ranks_gloo(launcher):
     assert len(col["per_rank_frames_per_s"]) == 2 and all(r > 0 for r in col["per_rank_frames_per_s"])
     assert col["per_rank_frames_per_s"][0] != col["per_rank_frames_per_s"][1]
     assert j["short_window"] is True and j["timed_window_ms"] < 100.0          # 5 steps of the stand-in engine
+
+
+@pytest.mark.timeout(300)
+def test_counter_reduction_world8_gloo_ragged_totals():
+    """The width the driver will run at (`--gpus 8`): eight gloo ranks, a stream total that does not divide by eight
+    (2051 = 8 * 256 + 3: ranks 0..2 own 257 streams, the rest 256), SUM / MAX reductions and the all-gathered proof."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(8))
+    assert res[0][1] == 0 and res[-1][2] == 2051 and all(res[i][2] == res[i + 1][1] for i in range(7))
+    assert [r[2] - r[1] for r in res] == [257, 257, 257, 256, 256, 256, 256, 256]
+    assert all(r[3] == 2051 * 10 for r in res)          # whole-job frames on every rank
+    assert all(r[4] == 8.0 for r in res)                # max over ranks: rank 7 took 1 + 7 s
+
+
+@pytest.mark.timeout(300)
+def test_bench_py_rank_plumbing_eight_ranks_gloo():
+    """bench.py exactly as the driver starts it for the 8-GPU scaling point (torch.distributed.run, 8 ranks, 127.0.0.1), on CPU
+    over gloo with the stand-in engine: one JSON line, `collective.ranks_reduced == 8`, eight per-rank rates, weak scaling."""
+    import json
+    import subprocess
+    args = ["--gpus", "8", "--steps", "4", "--warmup", "1", "--batch", "5", "--selftest-launcher", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak"
+    assert j["config"]["streams_per_gpu"] == 5 and j["config"]["total_streams"] == 40
+    col = j["collective"]
+    assert col["ranks_reduced"] == 8 and col["backend"] == "gloo" and len(col["per_rank_frames_per_s"]) == 8
+    assert "other_configs" not in j and "cpu_baseline" not in j          # N > 1: only the sharded workload is run

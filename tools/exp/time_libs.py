@@ -35,6 +35,7 @@ eng.close()
 for name in sys.argv[1:]:
     env = dict(os.environ, EXP_NAME=name)
     if name != "main":
+        env["NUTLS_DEV"] = "1"
         env["NUTLS_LIB"] = os.path.join(PKG, "build", "exp", "libnutls_%s.so" % name)
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=600)
     sys.stdout.write(r.stdout if r.returncode == 0 else "%-16s FAILED: %s\n" % (name, r.stderr[-400:]))
