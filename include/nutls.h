@@ -167,6 +167,11 @@ int nutls_reset(nutls_handle* h, int stream_idx);
 int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
 
 int nutls_batch(nutls_handle* h);
+/* Streams one workgroup of the fused kernel steps (mode 3): 1, or -- handles of at least two streams per CU, LSTM variant -- 2: the packed
+ * plan (csrc/fused_step_g2.hip: the layers whose LDS images fit twice run both streams side by side on one position axis, sharing
+ * the weight fetch and conversion).  A stream's results do not depend on its slot or partner.  NUTLS_FUSED_STREAMS=1 at creation
+ * keeps the one-stream plan.  No reference counterpart (the reference steps one stream: interpreter_proposed.py:215). */
+int nutls_streams_per_workgroup(nutls_handle* h);
 int nutls_launches_per_step(nutls_handle* h);
 
 /* Introspection of the per-frame launch plan (nutls_launches_per_step entries, in issue order):
@@ -196,6 +201,10 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n);
  * nutls_fused_blob_floats(variant). */
 int nutls_fused_blob_floats(int variant);
 int nutls_fused_pack_blob(const void* weights, size_t n_bytes, int variant, float* out, size_t n_floats);
+/* The same for the plan with `streams` streams per workgroup (1: the two entries above; 2: the packed plan of the LSTM variant, whose
+ * tilings -- hence fragment order -- differ); nutls_fused_plan_blob_floats is 0 where no such plan exists. */
+int nutls_fused_plan_blob_floats(int variant, int streams);
+int nutls_fused_pack_blob_plan(const void* weights, size_t n_bytes, int variant, int streams, float* out, size_t n_floats);
 
 const char* nutls_last_error(void);
 const char* nutls_version(void);

@@ -150,6 +150,7 @@ struct Engine {
   int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel (plan interpreter),
                          // 3 fused kernel (statically scheduled; both variants)
   float* fz_blob = nullptr;              // weight blob of the fused kernel (plan order)
+  int fz_streams = 1;                    // streams per workgroup of the fused plan this handle runs (packed plan: 2, from 512 streams on)
   std::string fz_reason;                 // why there is none (what the packer said), for nutls_set_mode(3)
   unsigned long long* fz_prof = nullptr; // op boundary stamps of workgroup 0 (profiling build)
   CompactOp* dplan[2] = {nullptr, nullptr};
@@ -970,9 +971,19 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   for (int i = 0; ok && i < fused_num_scratch(v) && i < 11; ++i) ok = scratch[i] - e->arena == fused_scratch_off(v, i);
   if (ok && v == NUTLS_VARIANT_BASELINE) ok = e->d_ddb != nullptr && e->ddbs.size() == 26;
   if (!ok) return fail(NUTLS_ERR_ARG, "fused plan (tools/gen_fused_plan.py) does not match the engine's arena layout");
+  // Which plan: one stream per workgroup, or -- once there are at least two streams per CU -- the packed plan (two streams per workgroup:
+  // one weight fetch / conversion and one latency chain for both in the layers whose images fit LDS twice).  NUTLS_FUSED_STREAMS=1 / 2
+  // overrides (2 needs an even stream count).
+  int streams = (e->B >= 2 * e->n_cu && e->B % 2 == 0) ? 2 : 1;
+  if (const char* ev = getenv("NUTLS_FUSED_STREAMS")) streams = atoi(ev);
+  if (streams < 1 || !fused_has_plan(v, streams) || e->B % streams != 0) streams = 1;
+  if (streams > 1 && (fused_plan_arena_floats(v, streams) != fused_arena_floats(v) || fused_plan_parity_stride(v, streams) != fused_parity_stride(v) ||
+                      fused_plan_ys_off(v, streams) != fused_ys_off(v) || fused_plan_ys_block(v, streams) != fused_ys_block(v)))
+    return fail(NUTLS_ERR_ARG, "packed fused plan does not share the arena layout of the one-stream plan");
+  e->fz_streams = streams;
   std::vector<float> blob;
   std::string err;
-  if (fused_pack_blob(v, wm, &blob, &err) != FZ_PACK_OK) {
+  if (fused_pack_blob(v, wm, &blob, &err, streams) != FZ_PACK_OK) {
     // Not packable for the fused kernel -- float conv kernels (no int8 payload), only some of them int8, a scale count that
     // does not match ... -- is not an error of the handle: modes 0-2 only need the de-quantised floats, the default becomes
     // the plan-interpreter kernel (mode 2), and nutls_set_mode(3) reports the reason kept here.
@@ -989,11 +1000,11 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   e->allocs.push_back(q);
   HIP_TRY(hipMemset(q, 0, (fused_num_ops(v) * 9 + 1) * sizeof(unsigned long long)));
   e->fz_prof = static_cast<unsigned long long*>(q);
-  HIP_TRY(v == NUTLS_VARIANT_BASELINE ? fused_base_step_set_attributes() : fused_step_set_attributes());
+  HIP_TRY(v == NUTLS_VARIANT_BASELINE ? fused_base_step_set_attributes() : (streams == 2 ? fused_step_g2_set_attributes() : fused_step_set_attributes()));
   // the table for rebuilding the carried partial sums (ysum_refresh)
   std::vector<YsOp> yops;
   std::vector<float> yw;
-  if (!fused_ys_table(v, wm, &yops, &yw, &err)) return fail(NUTLS_ERR_WEIGHTS, "fused plan: " + err);
+  if (!fused_ys_table(v, wm, &yops, &yw, &err, streams)) return fail(NUTLS_ERR_WEIGHTS, "fused plan: " + err);
   void* yo = nullptr;
   HIP_TRY(hipMalloc(&yo, yops.size() * sizeof(YsOp)));
   e->allocs.push_back(yo);
@@ -1022,9 +1033,11 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* 
   if (!e->fz_blob) return fail(NUTLS_ERR_ARG, "fused mode is not available for this handle");
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
   if (int rc = ysum_refresh(e, par, s)) return rc;
-  hipError_t err = (base ? launch_fused_base_step : launch_fused_step)(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
-                                                                       mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
-                                                                       base ? e->d_ddb : nullptr, static_cast<int>(e->steps & 0x3fffffff), e->B, s);
+  if (prof && e->fz_streams != 1) return fail(NUTLS_ERR_ARG, "the packed fused plan has no profiling build (NUTLS_FUSED_STREAMS=1 selects the one-stream plan)");
+  auto launch = base ? launch_fused_base_step : (e->fz_streams == 2 ? launch_fused_step_g2 : launch_fused_step);
+  hipError_t err = launch(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
+                          mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
+                          base ? e->d_ddb : nullptr, static_cast<int>(e->steps & 0x3fffffff), e->B / e->fz_streams, s);
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("fused step launch: ") + hipGetErrorString(err));
   if (base) e->d_step_stale = true;      // ring position of the dilated-dense history went in by value: one launch per step
   return NUTLS_OK;
@@ -1180,6 +1193,7 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
     return fail(NUTLS_ERR_ARG, std::string("plan: ") + ex.what());
   }
   if (rc) return rc;
+  e->n_cu = prop.multiProcessorCount;
   if (offline_frames == 0) {
     try {
       rc = fused_setup(e, wm);
@@ -1190,7 +1204,6 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
     if (e->fz_blob) e->mode = 3;          // the default for streaming handles whose container holds int8 conv kernels
   }
   HIP_TRY(stream_step_set_attributes());      // dynamic-LDS limit of the one-launch kernels, on THIS handle's device
-  e->n_cu = prop.multiProcessorCount;
   e->debug["input_layer"] = {e->t_inlayer, 256 * 64};
   e->debug["msfe6_de.y"] = {e->t_y, 256 * 64};
   e->debug["msfe6_de.up"] = {e->t_up, 256 * 128};
@@ -1441,6 +1454,7 @@ int nutls_destroy(nutls_handle* h) {
 }
 
 int nutls_batch(nutls_handle* h) { return h ? h->eng.B : fail(NUTLS_ERR_ARG, "null handle"); }
+int nutls_streams_per_workgroup(nutls_handle* h) { return h ? (h->eng.fz_blob ? h->eng.fz_streams : 1) : fail(NUTLS_ERR_ARG, "null handle"); }
 int nutls_launches_per_step(nutls_handle* h) { return h ? static_cast<int>(h->eng.plan[0].size()) : fail(NUTLS_ERR_ARG, "null handle"); }
 
 int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out) {
@@ -1834,15 +1848,24 @@ int nutls_fused_blob_floats(int variant) { return known_variant(variant) ? fused
 
 /* Host-only (no GPU needed): the weight blob of the fused kernel for a container, for tests of the packing. */
 int nutls_fused_pack_blob(const void* weights, size_t n_bytes, int variant, float* out, size_t n_floats) {
+  return nutls_fused_pack_blob_plan(weights, n_bytes, variant, 1, out, n_floats);
+}
+
+int nutls_fused_plan_blob_floats(int variant, int streams) {
+  return (known_variant(variant) && fused_has_plan(variant, streams)) ? fused_plan_blob_floats(variant, streams) : 0;
+}
+
+int nutls_fused_pack_blob_plan(const void* weights, size_t n_bytes, int variant, int streams, float* out, size_t n_floats) {
   if (!weights || !out) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: null pointer");
   if (!known_variant(variant)) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: unknown variant");
-  if (n_floats != static_cast<size_t>(fused_blob_floats(variant))) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: n_floats must equal nutls_fused_blob_floats()");
+  if (!fused_has_plan(variant, streams)) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: no plan for that many streams per workgroup");
+  if (n_floats != static_cast<size_t>(fused_plan_blob_floats(variant, streams))) return fail(NUTLS_ERR_ARG, "nutls_fused_pack_blob: n_floats must equal nutls_fused_blob_floats()");
   WeightMap wm;
   std::string err;
   std::vector<float> blob;
   try {
     if (!parse_weight_blob(weights, n_bytes, &wm, &err)) return fail(NUTLS_ERR_WEIGHTS, err);
-    if (fused_pack_blob(variant, wm, &blob, &err) != FZ_PACK_OK) return fail(NUTLS_ERR_WEIGHTS, err);
+    if (fused_pack_blob(variant, wm, &blob, &err, streams) != FZ_PACK_OK) return fail(NUTLS_ERR_WEIGHTS, err);
   } catch (const std::exception& ex) {
     return fail(NUTLS_ERR_WEIGHTS, std::string("weight container: ") + ex.what());
   }

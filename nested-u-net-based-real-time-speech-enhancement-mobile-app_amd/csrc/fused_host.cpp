@@ -27,6 +27,15 @@ using namespace ::nutls::fz;
 #include "fused_host_impl.inc"
 }  // namespace lstm_plan
 
+// packed plan of the LSTM variant: two streams per workgroup (fused_step_g2.hip)
+namespace lstm_g2_plan {
+namespace fz {
+using namespace ::nutls::fz;
+#include "fused_plan_lstm_g2.inc"
+}  // namespace fz
+#include "fused_host_impl.inc"
+}  // namespace lstm_g2_plan
+
 namespace base_plan {
 namespace fz {
 using namespace ::nutls::fz;
@@ -53,11 +62,21 @@ const char* fused_scratch_name(int variant, int i) { return FZ_BY_VARIANT(fused_
 int fused_scratch_off(int variant, int i) { return FZ_BY_VARIANT(fused_scratch_off(i)); }
 int fused_ys_block(int variant) { return FZ_BY_VARIANT(fused_ys_block()); }
 int fused_ys_off(int variant) { return FZ_BY_VARIANT(fused_ys_off()); }
-bool fused_ys_table(int variant, const WeightMap& wm, std::vector<YsOp>* ops, std::vector<float>* w, std::string* err) {
-  return FZ_BY_VARIANT(fused_ys_table(wm, ops, w, err));
+// (packed plans -- streams per workgroup > 1, LSTM variant -- share the arena layout of the one-stream plan; what differs is the tiling,
+//  hence the blob and the layout of the carried partial sums)
+#define FZ_BY_PLAN(call) ((streams == 2 && variant == NUTLS_VARIANT_LSTM) ? lstm_g2_plan::call : FZ_BY_VARIANT(call))
+bool fused_has_plan(int variant, int streams) { return streams == 1 || (streams == 2 && variant == NUTLS_VARIANT_LSTM); }
+bool fused_ys_table(int variant, const WeightMap& wm, std::vector<YsOp>* ops, std::vector<float>* w, std::string* err, int streams) {
+  return FZ_BY_PLAN(fused_ys_table(wm, ops, w, err));
 }
-int fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err) {
-  return FZ_BY_VARIANT(fused_pack_blob(wm, out, err));
+int fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err, int streams) {
+  return FZ_BY_PLAN(fused_pack_blob(wm, out, err));
 }
+int fused_plan_blob_floats(int variant, int streams) { return FZ_BY_PLAN(fused_blob_floats()); }
+int fused_plan_arena_floats(int variant, int streams) { return FZ_BY_PLAN(fused_arena_floats()); }
+int fused_plan_parity_stride(int variant, int streams) { return FZ_BY_PLAN(fused_parity_stride()); }
+int fused_plan_ys_off(int variant, int streams) { return FZ_BY_PLAN(fused_ys_off()); }
+int fused_plan_ys_block(int variant, int streams) { return FZ_BY_PLAN(fused_ys_block()); }
+int fused_plan_num_ops(int variant, int streams) { return FZ_BY_PLAN(fused_num_ops()); }
 
 }  // namespace nutls

@@ -20,7 +20,7 @@ enum Src : int { S_PREV = 0, S_CUR = 1, S_SCRATCH = 2 };   // HBM base a float o
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int SCR_BYTES = 8192;                      // LSTM / CTFA scratch at the top of LDS
 constexpr int SCR_B = LDS_BYTES - SCR_BYTES;
-constexpr int MAX_PARTS = 4, MAX_ZERO = 12, MAX_SEG = 6;
+constexpr int MAX_PARTS = 6, MAX_ZERO = 12, MAX_SEG = 6;
 constexpr int RING_SF_R32 = 6;                       // ... of the large layers (their K steps are 5x shorter than the fp32 MFMA's were)
 constexpr int XCOPY_B = SCR_B + 7168;                // fp32 copy of the rows an LSTM / dilated-dense op reads (<= 256 floats), written by the conv op before it
 constexpr int RING_SF = 3;                           // weight ring of a wave: 3 x (dwordx4 per lane = 16 int8 weights: 4 fp32-MFMA or 2 bf16-MFMA fragments), first fill by the previous op
@@ -33,6 +33,9 @@ struct Part {
   int row0;              // image row of block row 0
   int la;                // 1: loads issued by the op that builds the image, 2: one op earlier
   int round2;            // belongs to the second round of a two-round image
+  // packed plans (several streams per workgroup): the block exists once per stream g0 .. g0 + ng - 1 of the workgroup -- in HBM one
+  // arena slice apart, in LDS gstride_b bytes apart (the sub-images of the streams).  One-stream plans: 0, 1, 0.
+  int g0, ng, gstride_b;
 };
 struct Zero { int lds_b, n4; };   // halo: n4 float4 of zeros
 
@@ -43,12 +46,15 @@ struct Zero { int lds_b, n4; };   // halo: n4 float4 of zeros
 struct Img {
   int fmt, plane_b;
   int taps, tap_b, pitch_b, pair, half_b, row0, bytes;
+  int gstride_b;         // packed plans: LDS bytes between the sub-images of consecutive streams of the op (0: one stream)
   int nparts; Part parts[MAX_PARTS];
   int nzero; Zero zero[MAX_ZERO];
 };
 
 // Where an op's output rows go inside the LDS image of the op that consumes them next.
-struct Fwd { int on, base_b, pitch_b, pair, half_b, row0, fmt, plane_b; };
+// Packed plans: the rows of the op's stream i (0 <= i < OpD::gs) go to base_b + i * gstride_b if bit i of `mask` is set; the other streams'
+// rows reach their consumer through HBM (a staged part of its image).
+struct Fwd { int on, base_b, pitch_b, pair, half_b, row0, fmt, plane_b, gstride_b, mask; };
 
 struct OpD {
   int type;
@@ -80,6 +86,17 @@ struct OpD {
   int ys_off;                              // float offset of this op's sums inside a block
   int xs_off, xs_ld;                       // the conv's input state tensor [rows][xs_ld] (written for the ABI, never read by the kernel; the
                                            // host rebuilds S from it after nutls_state_set / a step of another mode)
+  // ---- packed plans: several streams per workgroup (kStreams > 1) ---------------------------------
+  // The op computes streams g0 .. g0 + gs - 1 of the workgroup's kStreams: gs = kStreams -- "side by side", the streams' positions are
+  // one virtual position axis of gs * P (the weights are fetched and converted once for all of them, every stream has its own
+  // sub-image, Img::gstride_b apart) -- or gs = 1: one instance of the layer per stream, one after the other (the layers whose
+  // images do not fit LDS gs times).  One-stream plans: gs = 1, g0 = 0.
+  int gs, g0;
+  int scr_b;                               // LSTM / CTFA scratch of stream i at scr_b + i * scr_gstride_b (one-stream plans: SCR_B, 0)
+  int scr_gstride_b;
+  int xcopy_b;                             // fp32 copy of the rows an LSTM / dilated-dense op reads, stream i at xcopy_b + i * 1024 (one-stream plans: XCOPY_B)
+  int x_gstride_b;                         // LSTM: LDS bytes between the sub-images (of the conv that follows) it writes its streams' rows into
+  int layer;                               // index of the layer (= op index of the one-stream plan) this op is an instance of
 };
 constexpr int DDB_LDS_B = 64 * 1024;       // LDS scratch of a dilated-dense block op (17 920 floats), above the image it completes
 

@@ -58,15 +58,29 @@
 #ifndef FZ_ABL
 #define FZ_ABL 0
 #endif
+// FZ_STREAMS = 2 / 4: the packed builds (fused_step_g2.hip / _g4.hip, plans fused_plan_lstm_g2.inc / _g4.inc): a workgroup owns that many
+// consecutive streams -- the layers whose images fit LDS that often run them side by side on one virtual position axis (one weight
+// fetch and conversion for all of them, full 16-position tiles in the deep layers), the others once per stream (fused_plan.hpp OpD::gs)
+#ifndef FZ_STREAMS
+#define FZ_STREAMS 1
+#endif
+#if FZ_BASE && FZ_STREAMS != 1
+#error "packed plans exist for the LSTM variant only"
+#endif
 
 namespace nutls {
 namespace fz {
 
 #if FZ_BASE
 #include "fused_plan_base.inc"
+#elif FZ_STREAMS == 2
+#include "fused_plan_lstm_g2.inc"
+#elif FZ_STREAMS == 4
+#include "fused_plan_lstm_g4.inc"
 #else
 #include "fused_plan_lstm.inc"
 #endif
+static_assert(kStreams == FZ_STREAMS, "plan and build disagree on the streams per workgroup");
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -82,16 +96,25 @@ typedef float __attribute__((address_space(1))) * gf_t;
 
 constexpr int THREADS = 512;
 #define FZ_LN_EPS 1e-8f
+// Packed plans (kStreams > 1, fused_plan.hpp OpD::gs / g0): a workgroup owns kStreams consecutive streams.  Everything below is written
+// over "stream slot g of the workgroup"; in a one-stream plan every such term is the constant 0 and folds away.
+constexpr int NSTREAMS = kStreams;
 
 struct Ctx {
-  gcb_t sbp, sbc, sbs, wb;     // this stream's `prev` / `cur` state bases, arena slice base; weight blob
+  gcb_t sbp, sbc, sbs, wb;     // `prev` / `cur` state bases and arena slice base of the workgroup's FIRST stream; weight blob
   gcb_t ysr, ysw;              // carried partial sums of the two-tap convs: last frame's block (read), this frame's (written)
-  gcf_t io_in;                 // this stream's 256 input magnitudes
+  gcf_t io_in;                 // the first stream's 256 input magnitudes (stream g: + 256 g floats)
   gf_t io_out;
+  unsigned sstride_b;          // packed plans: bytes between the arena slices of consecutive streams
   unsigned long long* prof;
   const DdbParams* ddb;        // baseline variant: the 13 dilated-dense blocks of this step's parity
   int stream, step;            // step: frame counter (position in the dilated-dense history rings)
 };
+// byte offset of stream slot g's arena slice relative to the workgroup's first stream (added to the 32-bit offset of a load / store)
+__device__ __forceinline__ unsigned gofs(const Ctx& cx, int g) {
+  if constexpr (NSTREAMS == 1) return 0u;
+  else return static_cast<unsigned>(g) * cx.sstride_b;
+}
 
 // profiling build: phase stamps inside an op (wave 0 of workgroup 0), slot k of op I at prof[kNumOps + 1 + 8 I + k]
 #define FZ_STAMP(I, k) do { if (FZ_PROF && cx.prof && tid == 0) cx.prof[kNumOps + 1 + 8 * (I) + (k)] = wall_clock64(); } while (0)
@@ -258,7 +281,8 @@ constexpr int part_cls(const Part& p) { return p.round2 ? (p.la == 2 ? 4 : 3) : 
 constexpr int stg_threads(int i) {
   return (i >= 0 && i < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32B && kOps[i].PG * kOps[i].CG == 4 && !kOps[i].ys) ? 256 : THREADS;
 }
-constexpr int part_n(const Part& p, int nthr) { return (p.rows * p.c4s + nthr - 1) / nthr; }
+constexpr int part_items(const Part& p) { return p.ng * p.rows * p.c4s; }      // (packed plans: the block once per stream)
+constexpr int part_n(const Part& p, int nthr) { return (part_items(p) + nthr - 1) / nthr; }
 constexpr int parts_regs(const Img& g, int cls, int nthr) {
   int n = 0;
   for (int k = 0; k < g.nparts; ++k) if (part_cls(g.parts[k]) == cls) n += part_n(g.parts[k], nthr);
@@ -278,15 +302,15 @@ constexpr int ctfa_ni(const OpD& d) { return (d.F + 31) / 32; }
 constexpr int yp_regs(int i) {
   if (i < 0 || i >= kNumOps || kOps[i].type != T_CONV || !kOps[i].ys) return 0;
   const OpD& d = kOps[i];
-  return d.path == P_R32B ? d.PT * d.NT * 4 : (d.P * ntot(d) / 4 + THREADS - 1) / THREADS;
+  return d.path == P_R32B ? d.PT * d.NT * 4 : (d.gs * d.P * ntot(d) / 4 + THREADS - 1) / THREADS;
 }
 constexpr int lstm_s0(const OpD& d) { return cmax(d.din / 16, 6); }      // carry slots of the gate weights (see lstm_op)
 constexpr int carry_w(int i) {
   if (i >= kNumOps) return 0;
   const OpD& d = kOps[i];
   if (d.type == T_CONV) return ring_sf(d);
-  if (d.type == T_LSTM) return lstm_s0(d) + 10;
-  if (d.type == T_CTFA) return ctfa_ni(d) + 2;
+  if (d.type == T_LSTM) return lstm_s0(d) + 10 + 3 * (d.gs - 1);      // (packed plans: h (2 slots) and c (1) of every further stream)
+  if (d.type == T_CTFA) return d.gs * ctfa_ni(d) + 2;
 #if FZ_BASE
   if (d.type == T_DDB) {
     if (d.x_cols == 64) return DdbzCarry<THREADS, 32, 4>::N;
@@ -332,7 +356,7 @@ struct Carry {
 constexpr int part_shift(const Img& g, int cls, int k, int nthr) {
   int sh = 0;
   for (int kk = 0; kk < k; ++kk)
-    if (part_cls(g.parts[kk]) == cls) sh += (cmin(g.parts[kk].rows * g.parts[kk].c4s, nthr) + 63) / 64 * 64;
+    if (part_cls(g.parts[kk]) == cls) sh += (cmin(part_items(g.parts[kk]), nthr) + 63) / 64 * 64;
   return sh % nthr;
 }
 template <int NTHR>
@@ -345,15 +369,17 @@ __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR
       constexpr int K = decltype(kk)::value;
       constexpr Part p = g.parts[K];
       if constexpr (part_cls(p) == CLS && !((FZ_ABL & 8192) && p.src == S_PREV && kOps[J].kind == K_EL)) {
-        constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s);
+        constexpr int items = part_items(p), per = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s), NG = p.ng, PG0 = p.g0;
         const gcb_t src = p.src == S_PREV ? cx.sbp : (p.src == S_CUR ? cx.sbc : cx.sbs);
         const int slot = stage_slot<NTHR>(tid, part_shift(g, CLS, K, NTHR));
         sfor<part_n(p, NTHR)>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
           int q = slot + NTHR * i;
           if ((i + 1) * NTHR > items) q = q < items ? q : items - 1;      // lanes past the end re-load the last item
+          const int gi = NG > 1 ? q >> clog2(per) : 0;                     // stream of the item (packed plans)
+          if constexpr (NG > 1) q &= per - 1;
           const int row = q >> cs, c4 = q & (p.c4s - 1);
-          r[base + i] = ldb(src, static_cast<unsigned>(p.off * 4 + row * (p.ld * 4) + c4 * 16));
+          r[base + i] = ldb(src, static_cast<unsigned>(p.off * 4 + row * (p.ld * 4) + c4 * 16) + gofs(cx, PG0 + gi));
         });
       }
     });
@@ -367,13 +393,14 @@ __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
       constexpr int K = decltype(kk)::value;
       constexpr Part p = g.parts[K];
       if constexpr (part_cls(p) == CLS && !((FZ_ABL & 8192) && p.src == S_PREV && kOps[J].kind == K_EL)) {
-        constexpr int items = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s);
+        constexpr int items = part_items(p), per = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s), NG = p.ng;
         const int slot = stage_slot<NTHR>(tid, part_shift(g, CLS, K, NTHR));
         sfor<part_n(p, NTHR)>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
           const int q = slot + NTHR * i;
-          const int row = q >> cs, c4 = q & (p.c4s - 1);
-          const int a = p.lds_b + img_row_rt(g.pitch_b, g.pair, g.half_b, p.row0 + row) + c4 * (4 * esz_of(g.fmt));
+          const int gi = NG > 1 ? q >> clog2(per) : 0, ql = NG > 1 ? q & (per - 1) : q;
+          const int row = ql >> cs, c4 = ql & (p.c4s - 1);
+          const int a = p.lds_b + gi * p.gstride_b + img_row_rt(g.pitch_b, g.pair, g.half_b, p.row0 + row) + c4 * (4 * esz_of(g.fmt));
           if ((i + 1) * NTHR <= items || FZ_LIKELY(q < items)) img_st4<g.fmt>(a, g.plane_b, r[base + i]);
         });
       }
@@ -400,7 +427,10 @@ __device__ __forceinline__ void zero_halos(int tid) {
       float zf = 0.f;
       asm volatile("" : "+v"(zf));
       const f32x4 z = {zf, zf, zf, zf};
-      if (static_cast<unsigned>(tid - zero_first(g)) < static_cast<unsigned>(zero_total(g))) lds4(delta + tid * 16) = z;
+      if (static_cast<unsigned>(tid - zero_first(g)) < static_cast<unsigned>(zero_total(g))) {
+        lds4(delta + tid * 16) = z;
+        sfor<kOps[J].gs - 1>([&](auto gg) { lds4(delta + tid * 16 + (decltype(gg)::value + 1) * g.gstride_b) = z; });      // (packed plans: every stream's sub-image)
+      }
     }
   }
 }
@@ -510,9 +540,9 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
         w[j] = ldb(cx.wb, static_cast<unsigned>((WB + (row0 + jr) * 84 + 4 * u) * 4));
       });
       const int h0 = xs ? 0 : 6 * hs;
-      sfor<6>([&](auto jj) {
-        constexpr int j = decltype(jj)::value;
-        w[S0 + j / 4][j % 4] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + h0 + j) * 4));      // (h[21..23]: slot padding, zero)
+      sfor<6 * d.gs>([&](auto jj) {
+        constexpr int j = decltype(jj)::value % 6, gi = decltype(jj)::value / 6, SH = gi == 0 ? S0 : S0 + 10 + 3 * (gi - 1);
+        w[SH + j / 4][j % 4] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + h0 + j) * 4) + gofs(cx, d.g0 + gi));      // (h[21..23]: slot padding, zero)
       });
       const int drow = tid < d.dout ? tid : d.dout - 1;
       sfor<6>([&](auto jj) {
@@ -521,7 +551,10 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
       });
       const int u21 = tid < 21 ? tid : 20;
       w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((BIAS + 4 * u21) * 4));
-      w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4));
+      sfor<d.gs>([&](auto gg) {
+        constexpr int gi = decltype(gg)::value, SC = gi == 0 ? S0 + 9 : S0 + 10 + 3 * (gi - 1) + 2;
+        w[SC][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4) + gofs(cx, d.g0 + gi));
+      });
 #if FZ_BASE
     } else if constexpr (d.type == T_DDB) {
       ddbz_prefetch<THREADS, d.x_cols / 2, d.din / d.x_cols>(ddbz_load_rec(cx.ddb + d.bidx), cx.stream, cx.step, tid, w);
@@ -529,18 +562,41 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
     } else if constexpr (d.type == T_CTFA) {
       constexpr int NI = ctfa_ni(d);
       const int c4 = tid & 15, rg = tid >> 4;
-      sfor<NI>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
+      sfor<NI * d.gs>([&](auto ii) {
+        constexpr int i = decltype(ii)::value % NI, gi = decltype(ii)::value / NI;
         int f = rg + 32 * i;
         if (f > d.F - 1) f = d.F - 1;
-        w[i] = ldb(cx.sbc, static_cast<unsigned>((d.e0_off + f * d.e0_ld + 4 * c4) * 4));
+        w[gi * NI + i] = ldb(cx.sbc, static_cast<unsigned>((d.e0_off + f * d.e0_ld + 4 * c4) * 4) + gofs(cx, d.g0 + gi));
       });
       if constexpr (d.last) {
-        w[NI] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 4256 + 4 * c4) * 4));                     // output conv weights
-        w[NI + 1][0] = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 4320) * 4));
+        w[NI * d.gs] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 4256 + 4 * c4) * 4));                     // output conv weights
+        w[NI * d.gs + 1][0] = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 4320) * 4));
       }
     }
   }
+}
+
+// HBM byte offset (relative to a block of partial sums of the workgroup's first stream) of the float4 a lane of a 32x32-tile two-tap
+// conv keeps for (position tile pt of its task, channel tile n, accumulator quarter q) -- without the lane's own 16 bytes.  Packed
+// plans: the task's virtual position tile belongs to one stream; inside a stream the layout is that of the one-stream plan.
+template <int I>
+__device__ __forceinline__ unsigned r32_ys_off(const Ctx& cx, const Task& t, int pt, int n, int q) {
+  constexpr OpD d = kOps[I];
+  if constexpr (d.gs == 1) {
+    return static_cast<unsigned>(d.ys_off * 4 + ((((t.a + d.PG * t.b) * d.PT + pt) * d.NT + n) * 4 + q) * 1024) + gofs(cx, d.g0);
+  } else {
+    static_assert(d.CG == 1 && d.P % 32 == 0, "packed two-tap conv on 32x32 tiles: one channel group, whole tiles per stream");
+    const int vt = t.a * d.PT + pt, gi = vt >> clog2(d.P / 32), tp = vt & (d.P / 32 - 1);
+    return static_cast<unsigned>(d.ys_off * 4 + ((tp * d.NT + n) * 4 + q) * 1024) + gofs(cx, d.g0 + gi);
+  }
+}
+// the same for the row-wise epilogue's items ([virtual position][packed channel] float4)
+template <int I>
+__device__ __forceinline__ unsigned x16_ys_off(const Ctx& cx, int item) {
+  constexpr OpD d = kOps[I];
+  constexpr int per = d.P * ntot(d) / 4;
+  if constexpr (d.gs == 1) return static_cast<unsigned>(d.ys_off * 4 + item * 16) + gofs(cx, d.g0);
+  else return static_cast<unsigned>(d.ys_off * 4 + (item & (per - 1)) * 16) + gofs(cx, d.g0 + (item >> clog2(per)));
 }
 
 // last frame's partial sums of op I ([pos][packed channel] fp32), in the layout its epilogue wants them
@@ -555,15 +611,15 @@ __device__ __forceinline__ void prefetch_y(const Ctx& cx, int tid, f32x4 (&yp)[N
         constexpr int i = decltype(ii)::value, q = i & 3, n = (i >> 2) % d.NT, pt = (i >> 2) / d.NT;
         // (32x32 tiles: the sums live in HBM in accumulator order -- [wave task][pt][n][q][lane] float4 -- so that a wave's load /
         //  store is 1 KB contiguous; a [pos][channel] layout costs 32 partial lines per instruction)
-        yp[i] = ldb(cx.ysr, static_cast<unsigned>(d.ys_off * 4 + ((((t.a + d.PG * t.b) * d.PT + pt) * d.NT + n) * 4 + q) * 1024 + lane * 16));
+        yp[i] = ldb(cx.ysr, r32_ys_off<I>(cx, t, pt, n, q) + static_cast<unsigned>(lane * 16));
       });
     } else {
-      constexpr int total = d.P * ntot(d) / 4;
+      constexpr int per = d.P * ntot(d) / 4, total = d.gs * per;
       sfor<yp_regs(I)>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         int item = tid + THREADS * i;
         if ((i + 1) * THREADS > total) item = item < total ? item : total - 1;
-        yp[i] = ldb(cx.ysr, static_cast<unsigned>(d.ys_off * 4 + item * 16));
+        yp[i] = ldb(cx.ysr, x16_ys_off<I>(cx, item));
       });
     }
   }
@@ -617,6 +673,23 @@ template <int I>
 __device__ __forceinline__ void fwd_st4(int row, int c, const f32x4& v) { img_st4<kOps[I].fwd.fmt>(fwd_addr<I>(row, c), kOps[I].fwd.plane_b, v); }
 template <int I>
 __device__ __forceinline__ f32x4 fwd_ld4(int row, int c) { return img_ld4<kOps[I].fwd.fmt>(fwd_addr<I>(row, c), kOps[I].fwd.plane_b); }
+// packed plans: the same for the op's stream slot gi (its sub-image of the target is fwd.gstride_b further); fwd_has: do this slot's rows go to LDS at all?
+template <int I>
+__device__ __forceinline__ void fwd_st4g(int gi, int row, int c, const f32x4& v) {
+  img_st4<kOps[I].fwd.fmt>(fwd_addr<I>(row, c) + (kOps[I].gs > 1 ? gi * kOps[I].fwd.gstride_b : 0), kOps[I].fwd.plane_b, v);
+}
+template <int I>
+__device__ __forceinline__ f32x4 fwd_ld4g(int gi, int row, int c) {
+  return img_ld4<kOps[I].fwd.fmt>(fwd_addr<I>(row, c) + (kOps[I].gs > 1 ? gi * kOps[I].fwd.gstride_b : 0), kOps[I].fwd.plane_b);
+}
+constexpr bool fwd_all(const OpD& d) { return d.fwd.on && d.fwd.mask == (1 << d.gs) - 1; }
+template <int I>
+__device__ __forceinline__ bool fwd_has(int gi) {
+  constexpr OpD d = kOps[I];
+  if constexpr (!d.fwd.on || d.fwd.mask == 0) return false;
+  else if constexpr (fwd_all(d)) return true;
+  else return ((d.fwd.mask >> gi) & 1) != 0;
+}
 // does op I feed an LSTM / dilated-dense op (which reads its rows as fp32 from XCOPY_B)?
 constexpr bool feeds_x(int i) { return i + 1 < kNumOps && (kOps[i + 1].type == T_LSTM || kOps[i + 1].type == T_DDB); }
 
@@ -627,7 +700,8 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
   constexpr OpD d = kOps[I];
   // (two-tap convs: slices [0, KS) of the exchange buffer hold the NEXT frame's partial sums, [KS, 2 KS) this frame's)
   constexpr int GC = d.gc, LPG = GC / 4, R = d.R, NTOT = ntot(d), KS = ex_group(d), K0 = d.ys ? KS : 0, OPB = (NTOT + 4) * 4;
-  constexpr int total = d.P * NTOT / 4, passes = (total + THREADS - 1) / THREADS;
+  constexpr int VP = d.gs * d.P;      // (packed plans: the positions of the op's streams side by side)
+  constexpr int total = VP * NTOT / 4, passes = (total + THREADS - 1) / THREADS;
   const int li = tid & (LPG - 1);
   const int u0 = tid >> clog2(LPG);
   const int r = u0 & (R - 1);
@@ -644,10 +718,11 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
     constexpr int ps = decltype(pp)::value;
     const int u = u0 + ps * (THREADS / LPG);
     if ((ps + 1) * THREADS <= total || FZ_LIKELY(u * LPG < total)) {
-      const int pos = u >> clog2(R);
-      const int eb = d.ex_b + pos * OPB + (r * GC + 4 * li) * 4;
+      const int vpos = u >> clog2(R);
+      const int gi = d.gs > 1 ? vpos >> clog2(d.P) : 0, pos = d.gs > 1 ? vpos & (d.P - 1) : vpos;      // stream slot, position inside the stream
+      const int eb = d.ex_b + vpos * OPB + (r * GC + 4 * li) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      sfor<(FZ_ABL & 512) ? 1 : KS>([&](auto kk) { v += lds4(eb + (K0 + decltype(kk)::value) * (d.P * OPB)); });
+      sfor<(FZ_ABL & 512) ? 1 : KS>([&](auto kk) { v += lds4(eb + (K0 + decltype(kk)::value) * (VP * OPB)); });
       if constexpr (d.ys != 0) v += yp[ps];      // W[tap 0] x_{t-1}, computed by this op one frame ago
       v = v * wsc + bias;
       if constexpr (d.ln && !(FZ_ABL & 16)) {
@@ -662,10 +737,11 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
         }
       }
       const int row = pos * d.row_mul + d.row_add + r;
-      if constexpr (d.d0_on && !(FZ_ABL & 4)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4), v);
-      if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4), v);
-      if constexpr (d.fwd.on) fwd_st4<I>(row, 4 * li, v);
-      if constexpr (feeds_x(I)) lds4(XCOPY_B + (row * GC + 4 * li) * 4) = v;
+      const unsigned go = gofs(cx, d.g0 + gi);
+      if constexpr (d.d0_on && !(FZ_ABL & 4)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v);
+      if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v);
+      if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, 4 * li, v); }
+      if constexpr (feeds_x(I)) lds4(d.xcopy_b + gi * 1024 + (row * GC + 4 * li) * 4) = v;
     }
   });
   if constexpr (d.ys != 0) {
@@ -678,8 +754,8 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
         const int u = item >> clog2(LPG), l2 = item & (LPG - 1);
         const int eb = d.ex_b + (u >> clog2(R)) * OPB + ((u & (R - 1)) * GC + 4 * l2) * 4;
         f32x4 y = {0.f, 0.f, 0.f, 0.f};
-        sfor<KS>([&](auto kk) { y += lds4(eb + decltype(kk)::value * (d.P * OPB)); });
-        if constexpr (!(FZ_ABL & 4)) stb(cx.ysw, static_cast<unsigned>(d.ys_off * 4 + item * 16), y);
+        sfor<KS>([&](auto kk) { y += lds4(eb + decltype(kk)::value * (VP * OPB)); });
+        if constexpr (!(FZ_ABL & 4)) stb(cx.ysw, x16_ys_off<I>(cx, item), y);
       }
     });
   }
@@ -701,11 +777,13 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
   const int ks_t = t.ks >> clog2(d.KSg), ks_g = t.ks & (d.KSg - 1);
   const int j = lane & 15, h = lane >> 4;
   int lane_b[PT];
+  constexpr int VP = d.gs * d.P;      // packed plans: virtual position = stream slot * P + position
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     int pos = 16 * (t.a * PT + pt) + j;
-    if (pos > d.P - 1) pos = d.P - 1;
-    lane_b[pt] = pos * d.img.pitch_b + 16 * h + ks_t * d.img.tap_b + ks_g * (GW * 64);
+    if (pos > VP - 1) pos = VP - 1;
+    const int rowb = d.gs > 1 ? (pos >> clog2(d.P)) * d.img.gstride_b + (pos & (d.P - 1)) * d.img.pitch_b : pos * d.img.pitch_b;
+    lane_b[pt] = rowb + 16 * h + ks_t * d.img.tap_b + ks_g * (GW * 64);
   }
   constexpr bool BOTH = x16_both(d);            // two-tap conv, the wave owns both taps: segments 0..2 (tap 0) go to the second set
   constexpr bool TWO = UP || BOTH;
@@ -756,11 +834,11 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int pos = 16 * (t.a * PT + pt) + j;
-      if (pos < d.P) {
-        const int eb = d.ex_b + ((BOTH ? 1 : t.ks) * d.P + pos) * OPB + (16 * t.b + 4 * h) * 4;
+      if (pos < VP) {
+        const int eb = d.ex_b + ((BOTH ? 1 : t.ks) * VP + pos) * OPB + (16 * t.b + 4 * h) * 4;
         lds4(eb) = acc[pt][0] + (acc[pt][1] + acc[pt][2]);
         if constexpr (UP) lds4(eb + d.N * 4) = acco[pt][0] + (acco[pt][1] + acco[pt][2]);
-        if constexpr (BOTH) lds4(eb - d.P * OPB) = acco[pt][0] + (acco[pt][1] + acco[pt][2]);      // slice 0: the next frame's sums
+        if constexpr (BOTH) lds4(eb - VP * OPB) = acco[pt][0] + (acco[pt][1] + acco[pt][2]);      // slice 0: the next frame's sums
       }
     }
   }
@@ -790,8 +868,17 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
   const Task t = conv_task<I>(wave);
   const int j = lane & 31, h = lane >> 5;
   int lane_b[PT];
+  // packed plans: position tile vt of the virtual axis belongs to stream slot vt / (P / 32) (whole tiles per stream)
+  static_assert(d.gs == 1 || d.P % 32 == 0, "packed plan: 32x32 tiles do not straddle streams");
+  constexpr int TPS = d.gs > 1 ? d.P / 32 : 1;      // position tiles per stream
+  int tile_g[PT], tile_p0[PT];                            // per position tile: stream slot, first position inside the stream
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt) lane_b[pt] = (32 * (t.a * PT + pt) + j) * d.img.pitch_b + (8 * esz_of(FMT)) * h;
+  for (int pt = 0; pt < PT; ++pt) {
+    const int vt = t.a * PT + pt;
+    tile_g[pt] = d.gs > 1 ? vt >> clog2(TPS) : 0;
+    tile_p0[pt] = d.gs > 1 ? 32 * (vt & (TPS - 1)) : 32 * vt;
+    lane_b[pt] = (d.gs > 1 ? tile_g[pt] * d.img.gstride_b : 0) + (tile_p0[pt] + j) * d.img.pitch_b + (8 * esz_of(FMT)) * h;
+  }
   f32x16 acc[PT][NA];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt)
@@ -856,7 +943,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
-            stb(cx.ysw, static_cast<unsigned>(d.ys_off * 4 + ((((t.a + d.PG * t.b) * PT + pt) * NT + n) * 4 + q) * 1024 + lane * 16), v);
+            stb(cx.ysw, r32_ys_off<I>(cx, t, pt, n, q) + static_cast<unsigned>(lane * 16), v);
           }
     } else {
       // waves 4..7: this frame's sums start from what the op handed over one frame ago
@@ -879,7 +966,8 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
     if constexpr (d.ln) alpha = lds1(SCR_B + (2 * NTOT + 2 * d.gc) * 4);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int pos = 32 * (t.a * PT + pt) + j;
+      const int pos = tile_p0[pt] + j, gi = tile_g[pt];      // position inside its stream, stream slot
+      const unsigned go = gofs(cx, d.g0 + gi);
       // packed channel of accumulator element e of tile n: nb(n) + 8 (e >> 2) + 4 h + (e & 3)
       if constexpr (d.ln) {
         float s = 0.f;
@@ -936,9 +1024,9 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
           const int cc = c0 + 8 * q + 4 * h;
-          if constexpr (d.fwd.on) fwd_st4<I>(row, cc, v);
-          if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4), v);
-          if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4), v);
+          if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, cc, v); }
+          if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v);
+          if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4) + go, v);
         }
       }
     }
@@ -952,13 +1040,14 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
 template <int I>
 __device__ __forceinline__ void input_op(const Ctx& cx, int tid) {
   constexpr OpD d = kOps[I];
+  static_assert(d.gs == 1, "the input layer runs one stream at a time");
   const int c4 = tid & 15;
   const unsigned pb = static_cast<unsigned>(d.p_off * 4 + c4 * 16);
   const f32x4 w = ldb(cx.wb, pb), bb = ldb(cx.wb, pb + 256), gm = ldb(cx.wb, pb + 512), bt = ldb(cx.wb, pb + 768);
   const float alpha = ldb1(cx.wb, static_cast<unsigned>(d.p_off * 4 + 1024));
   float x[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) x[i] = cx.io_in[(tid >> 4) + 32 * i];
+  for (int i = 0; i < 8; ++i) x[i] = cx.io_in[d.g0 * 256 + (tid >> 4) + 32 * i];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int pos = (tid >> 4) + 32 * i;
@@ -983,54 +1072,70 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
   // z = [x ; h] . [Wx ; Wh] + b with the gate columns interleaved (column 4 u + g: gate g of unit u), so that one float4
   // is (i, f, g, o) of a unit.  K is cut into 16 slices of x (threads (u, slice), tid < 336) and 4 slices of h
   // (tid 336..419); every operand arrived in the carry (slot map: [0, S0) weight rows of the thread's slice,
-  // [S0, S0+2) its h values, [S0+2, S0+8) the Dense row of output tid, S0+8 the unit's bias, S0+9 its cell state).
+  // [S0, S0+2) its h values, [S0+2, S0+8) the Dense row of output tid, S0+8 the unit's bias, S0+9 its cell state; packed plans:
+  // h and c of stream slot gi >= 1 at S0 + 10 + 3 (gi - 1) + {0, 1} and + 2 -- the weights serve every stream of the op).
   constexpr OpD d = kOps[I];
-  constexpr int KN = d.din / 16, XS = clog2(d.x_cols), S0 = lstm_s0(d);
-  constexpr int PART = SCR_B, HN = SCR_B + 20 * 21 * 16;
+  constexpr int KN = d.din / 16, XS = clog2(d.x_cols), S0 = lstm_s0(d), GS = d.gs;
+  constexpr int PART = d.scr_b, HN = d.scr_b + 20 * 21 * 16, SGB = d.scr_gstride_b;      // stream slot gi: + gi * SGB
   const int u = tid % 21, sl = tid / 21;
   pin_regs(c.w);
   if (tid < 336) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a[GS];
+#pragma unroll
+    for (int gi = 0; gi < GS; ++gi) a[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < KN; ++j) {
       const int k = sl * KN + j;
-      a += c.w[j] * lds1(XCOPY_B + k * 4);        // (the conv op before left its rows here as fp32, [row][x_cols] = element k)
-    }
-    lds4(PART + (sl * 21 + u) * 16) = a;
-  } else if (tid < 420) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const float hv = c.w[S0 + j / 4][j % 4];
-      a += c.w[j] * hv;
+      for (int gi = 0; gi < GS; ++gi) a[gi] += c.w[j] * lds1(d.xcopy_b + gi * 1024 + k * 4);        // (the conv op before left its rows here as fp32, [row][x_cols] = element k)
     }
-    lds4(PART + (sl * 21 + u) * 16) = a;
+#pragma unroll
+    for (int gi = 0; gi < GS; ++gi) lds4(PART + gi * SGB + (sl * 21 + u) * 16) = a[gi];
+  } else if (tid < 420) {
+#pragma unroll
+    for (int gi = 0; gi < GS; ++gi) {
+      const int SH = gi == 0 ? S0 : S0 + 10 + 3 * (gi - 1);
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float hv = c.w[SH + j / 4][j % 4];
+        a += c.w[j] * hv;
+      }
+      lds4(PART + gi * SGB + (sl * 21 + u) * 16) = a;
+    }
   }
   lds_barrier();
   if (tid < 21) {
-    f32x4 z = c.w[S0 + 8];
 #pragma unroll
-    for (int s2 = 0; s2 < 20; ++s2) z += lds4(PART + (s2 * 21 + tid) * 16);
-    const float c_old = c.w[S0 + 9][0];
-    const float gi = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
-    const float c_new = gf * c_old + gi * gg;
-    const float h_new = go * fast_tanh(c_new);
-    stb1(cx.sbc, static_cast<unsigned>((d.c_off + tid) * 4), c_new);
-    stb1(cx.sbc, static_cast<unsigned>((d.h_off + tid) * 4), h_new);
-    lds1(HN + tid * 4) = h_new;
+    for (int gi = 0; gi < GS; ++gi) {
+      f32x4 z = c.w[S0 + 8];
+#pragma unroll
+      for (int s2 = 0; s2 < 20; ++s2) z += lds4(PART + gi * SGB + (s2 * 21 + tid) * 16);
+      const float c_old = c.w[gi == 0 ? S0 + 9 : S0 + 10 + 3 * (gi - 1) + 2][0];
+      const float gi_ = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
+      const float c_new = gf * c_old + gi_ * gg;
+      const float h_new = go * fast_tanh(c_new);
+      const unsigned so = gofs(cx, d.g0 + gi);
+      stb1(cx.sbc, static_cast<unsigned>((d.c_off + tid) * 4) + so, c_new);
+      stb1(cx.sbc, static_cast<unsigned>((d.h_off + tid) * 4) + so, h_new);
+      lds1(HN + gi * SGB + tid * 4) = h_new;
+    }
   }
   lds_barrier();
   if (tid < d.dout) {
-    float a = c.w[S0 + 2 + 5][1];          // bd
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const f32x4 h4 = lds4(HN + 16 * q), w4 = c.w[S0 + 2 + q];
-      a += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
+    for (int gi = 0; gi < GS; ++gi) {
+      float a = c.w[S0 + 2 + 5][1];          // bd
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const f32x4 h4 = lds4(HN + gi * SGB + 16 * q), w4 = c.w[S0 + 2 + q];
+        a += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
+      }
+      a = fmaf(c.w[S0 + 2 + 5][0], lds1(HN + gi * SGB + 80), a);
+      const int f = tid >> XS, cc = tid & (d.x_cols - 1);
+      img_st1<d.x_fmt>(d.y_b + gi * d.x_gstride_b + f * d.x_pitch_b + cc * esz_of(d.x_fmt), d.x_plane_b, a);
+      if constexpr (d.ldst_on) stb1(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4) + gofs(cx, d.g0 + gi), a);
     }
-    a = fmaf(c.w[S0 + 2 + 5][0], lds1(HN + 80), a);
-    const int f = tid >> XS, cc = tid & (d.x_cols - 1);
-    img_st1<d.x_fmt>(d.y_b + f * d.x_pitch_b + cc * esz_of(d.x_fmt), d.x_plane_b, a);
-    if constexpr (d.ldst_on) stb1(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4), a);
   }
 }
 
@@ -1089,14 +1194,16 @@ __device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1)[4], float 
 template <int I>
 __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
   constexpr OpD d = kOps[I];
-  constexpr int NI = ctfa_ni(d);
-  constexpr int PART = SCR_B, GATE = SCR_B + 512 * 4, MSCR = GATE + 64 * 4;
+  constexpr int NI = ctfa_ni(d), GS = d.gs, SGB = d.scr_gstride_b;
+  // scratch of stream slot gi at d.scr_b + gi * SGB: column sums of the 8 waves | gates | the perceptrons' exchange
+  constexpr int PART = d.scr_b, GATE = d.scr_b + 512 * 4, MSCR = GATE + 64 * 4;
   const int c4 = tid & 15, rg = tid >> 4, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // gate perceptrons (wave 0: lane c holds its 16 input / output weights of each of the four matrices): requested now,
-  // used after the column sums.  (In the carry they would cost every wave of the preceding sub-pixel conv 64 registers.)
+  // gate perceptrons (wave gi for stream slot gi -- wave 0 in a one-stream plan: lane c holds its 16 input / output weights of each
+  // of the four matrices): requested now, used after the column sums.  (In the carry they would cost every wave of the preceding
+  // sub-pixel conv 64 registers.)
   float b1t = 0.f, b1f = 0.f, b2t = 0.f, b2f = 0.f;
   f32x4 w1t[4], w2t[4], w1f[4], w2f[4];
-  if (wave == 0) {
+  if (wave < GS) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       w1t[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + lane * 16 + 4 * q) * 4));                  // ta w1T [64][16]
@@ -1109,41 +1216,50 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
     b1f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 1024 + (lane & 15)) * 4));
     b2f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 2064 + lane) * 4));
   }
-  const f32x4 ow = c.w[NI];
-  const float ob = c.w[NI + 1][0];
-  f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 ow = c.w[NI * GS];
+  const float ob = c.w[NI * GS + 1][0];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int f = rg + 32 * i;
-    if (f < d.F) s4 += fwd_ld4<I>(f, 4 * c4);
-  }
+  for (int gi = 0; gi < GS; ++gi) {
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    s4[e] = xor32_sum(xor16_sum(s4[e]));
+    for (int i = 0; i < NI; ++i) {
+      const int f = rg + 32 * i;
+      if (f < d.F) s4 += fwd_ld4g<I>(gi, f, 4 * c4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s4[e] = xor32_sum(xor16_sum(s4[e]));
+    }
+    if (lane < 16) lds4(PART + gi * SGB + (wave * 64 + 4 * c4) * 4) = s4;
   }
-  if (lane < 16) lds4(PART + (wave * 64 + 4 * c4) * 4) = s4;
   lds_barrier();
-  if (wave == 0) {
+  if (wave < GS) {
+    const int sb = wave * SGB;          // this wave's stream slot
     float m = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) m += lds1(PART + (r * 64 + lane) * 4);
+    for (int r = 0; r < 8; ++r) m += lds1(PART + sb + (r * 64 + lane) * 4);
     m = m * (1.0f / d.F);
-    const float ta = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t, MSCR, lane));
-    const float fa = fast_sigmoid(gate_mlp(ta * (1.0f / 32.0f), w1f, b1f, w2f, b2f, MSCR, lane));
-    lds1(GATE + lane * 4) = fa * ta;
+    const float ta = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t, MSCR + sb, lane));
+    const float fa = fast_sigmoid(gate_mlp(ta * (1.0f / 32.0f), w1f, b1f, w2f, b2f, MSCR + sb, lane));
+    lds1(GATE + sb + lane * 4) = fa * ta;
   }
   lds_barrier();
-  const f32x4 g4 = lds4(GATE + 16 * c4);
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int f = rg + 32 * i;
-    if (f < d.F) {
-      const f32x4 y = fwd_ld4<I>(f, 4 * c4) * g4 + c.w[i];      // (re-read: cheaper than 32 registers held across the gates)
-      if constexpr (d.last) {
-        const float s = group_sum<16>(y[0] * ow[0] + y[1] * ow[1] + y[2] * ow[2] + y[3] * ow[3]);
-        if (c4 == 0) cx.io_out[f] = s + ob;
-      } else {
-        fwd_st4<I>(f, 4 * c4, y);
+  for (int gi = 0; gi < GS; ++gi) {
+    const f32x4 g4 = lds4(GATE + gi * SGB + 16 * c4);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int f = rg + 32 * i;
+      if (f < d.F) {
+        const f32x4 y = fwd_ld4g<I>(gi, f, 4 * c4) * g4 + c.w[gi * NI + i];      // (re-read: cheaper than 32 registers held across the gates)
+        if constexpr (d.last) {
+          const float s = group_sum<16>(y[0] * ow[0] + y[1] * ow[1] + y[2] * ow[2] + y[3] * ow[3]);
+          if (c4 == 0) cx.io_out[(d.g0 + gi) * 256 + f] = s + ob;
+        } else {
+          fwd_st4g<I>(gi, f, 4 * c4, y);
+          // (packed plans: a consumer that is not the next op of this stream reads the rows from HBM)
+          if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + f * d.d0_ld + 4 * c4) * 4) + gofs(cx, d.g0 + gi), y);
+        }
       }
     }
   }
@@ -1202,6 +1318,12 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
 #endif
   } else {
     if constexpr (!(FZ_ABL & 64)) ctfa_op<I>(cx, tid, c);
+    if constexpr (nxt_of(I) >= 0) {
+      // packed plans: an instance of the network's last CTFA that is followed by another stream's ops completes the image of the conv
+      // after it (its loads went out in the prologue above) -- once every thread is done with the plain rows the image overlaps
+      lds_barrier();
+      build_next<I>(tid, p1, c.p);
+    }
   }
   if constexpr (d.drain && !DRAIN_FIRST) drain_vm();
   lds_barrier();
@@ -1225,7 +1347,17 @@ struct FzArgs {
 #ifndef FZ_PROF
 #define FZ_PROF 0
 #endif
-#if FZ_PROF && FZ_BASE
+#if FZ_STREAMS == 2
+#define FZ_KERNEL nutls_fused_step_g2_kernel
+#define FZ_LAUNCH launch_fused_step_g2
+#define FZ_ATTR fused_step_g2_set_attributes
+#define FZ_NO_PROF_TWIN 1
+#elif FZ_STREAMS == 4
+#define FZ_KERNEL nutls_fused_step_g4_kernel
+#define FZ_LAUNCH launch_fused_step_g4
+#define FZ_ATTR fused_step_g4_set_attributes
+#define FZ_NO_PROF_TWIN 1
+#elif FZ_PROF && FZ_BASE
 #define FZ_KERNEL nutls_fused_base_step_prof_kernel
 #define FZ_LAUNCH launch_fused_base_step_prof
 #define FZ_ATTR fused_base_step_prof_set_attributes
@@ -1251,7 +1383,8 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   // One workgroup per stream, grid = B (the hardware queues the workgroups that do not fit).  No loop over streams here:
   // everything that depends only on kernel arguments (hundreds of `blob + offset` bases) would be hoisted out of such a
   // loop to the kernel entry, spilled, and re-loaded from scratch in the op prologues -- behind a full vmcnt(0) drain.
-  const int stream = blockIdx.x;
+  // (packed plans: the workgroup owns streams kStreams * blockIdx.x .. + kStreams - 1; the host uses them only for B a multiple of kStreams)
+  const int stream = blockIdx.x * NSTREAMS;
   if (stream >= a.B) return;
   const float* slice = a.arena + static_cast<size_t>(stream) * a.sstride;
   Ctx cx;
@@ -1267,6 +1400,7 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.ddb = a.ddb ? a.ddb + a.par * 13 : nullptr;
   cx.stream = stream;
   cx.step = a.step;
+  cx.sstride_b = static_cast<unsigned>(a.sstride * 4);
 #if FZ_BASE
   {
     // one pass over the 13 parameter records of the dilated-dense ops: they stay in the scalar cache for the rest of
@@ -1301,6 +1435,18 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
 hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
                      unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s) {
   fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, prof, ddb, step};
+  hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+hipError_t FZ_ATTR() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(fz::FZ_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+}
+#elif defined(FZ_NO_PROF_TWIN)
+// packed builds: `grid` workgroups of kStreams streams each; no profiling twin (`prof` is ignored)
+hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s) {
+  (void)prof;
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr, ddb, step};
   hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
   return hipGetLastError();
 }

@@ -280,7 +280,19 @@ hipError_t launch_fused_base_step(float* arena, long long sstride, const float* 
 hipError_t fused_step_set_attributes();
 hipError_t fused_base_step_set_attributes();
 enum FusedPack : int { FZ_PACK_OK = 0, FZ_PACK_NOT_INT8 = 1, FZ_PACK_MALFORMED = 2 };
-int fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err);      // -> FusedPack
+int fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err, int streams = 1);      // -> FusedPack
+// packed plans (several streams per workgroup, fused_plan.hpp OpD::gs): the LSTM variant has one for 2 streams (fused_step_g2.hip).  Same
+// arena layout as the one-stream plan (checked in fused_setup); the blob and the layout of the carried sums are the plan's own.
+bool fused_has_plan(int variant, int streams);
+int fused_plan_blob_floats(int variant, int streams);
+int fused_plan_arena_floats(int variant, int streams);
+int fused_plan_parity_stride(int variant, int streams);
+int fused_plan_ys_off(int variant, int streams);
+int fused_plan_ys_block(int variant, int streams);
+int fused_plan_num_ops(int variant, int streams);
+hipError_t launch_fused_step_g2(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                                unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
+hipError_t fused_step_g2_set_attributes();
 int fused_blob_floats(int variant);
 int fused_num_ops(int variant);
 const char* fused_op_name(int variant, int i);
@@ -297,6 +309,6 @@ int fused_scratch_off(int variant, int i);
 int fused_ys_block(int variant);          // floats of one block of carried partial sums; the arena's "ysum" scratch holds two
 int fused_ys_off(int variant);            // arena offset of the first block
 // the table launch_ysum_refresh needs (w: all ops' tap-0 weights, int8 values as floats); false + err if a tensor has no int8 payload
-bool fused_ys_table(int variant, const WeightMap& wm, std::vector<YsOp>* ops, std::vector<float>* w, std::string* err);
+bool fused_ys_table(int variant, const WeightMap& wm, std::vector<YsOp>* ops, std::vector<float>* w, std::string* err, int streams = 1);
 
 }  // namespace nutls

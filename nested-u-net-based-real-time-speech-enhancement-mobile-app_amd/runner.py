@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
     "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all", "nutls_offline_set_ctfa_mode",
-    "nutls_offline_set_pipeline",
+    "nutls_offline_set_pipeline", "nutls_streams_per_workgroup", "nutls_fused_plan_blob_floats", "nutls_fused_pack_blob_plan",
 )
 
 
@@ -80,6 +80,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_reset.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_debug_get.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
     lib.nutls_batch.argtypes = [c.c_void_p]
+    lib.nutls_streams_per_workgroup.argtypes = [c.c_void_p]
     lib.nutls_launches_per_step.argtypes = [c.c_void_p]
     lib.nutls_launch_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
                                       c.POINTER(c.c_double), c.POINTER(c.c_double)]
@@ -99,6 +100,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_profile_fused.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
     lib.nutls_fused_blob_floats.argtypes = [c.c_int]
     lib.nutls_fused_pack_blob.argtypes = [c.c_void_p, c.c_size_t, c.c_int, fp, c.c_size_t]
+    lib.nutls_fused_plan_blob_floats.argtypes = [c.c_int, c.c_int]
+    lib.nutls_fused_pack_blob_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, fp, c.c_size_t]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:
@@ -129,14 +132,18 @@ class NutlsEngine:
     MODES = {"launches": 0, "graph": 1, "persistent": 2, "fused": 3}
     VARIANTS = {"lstm": 0, "baseline": 1}
 
-    def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: Optional[str] = None, variant: str = "lstm"):
+    def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: Optional[str] = None, variant: str = "lstm",
+                 streams_per_workgroup: Optional[int] = None):
         """``mode``: "fused" (the default when the container holds int8 conv kernels, as the reference's .tflite does:
         one launch per frame, one workgroup per stream, every op its own specialised instruction stream), "persistent"
         (the default for float containers: one launch per frame, one workgroup per stream interprets the
         device-resident plan), "graph" (one kernel per layer, hipGraph replay) or "launches" (one kernel per layer).
         ``variant``: "lstm" (NUNet-TLS-LSTM, trained weights ship in weights/) or "baseline"
         (dilated-dense bottleneck; no trained weights exist -- pass a container, e.g.
-        ``weights.write_blob(weights.synthetic_weights("baseline"), int8_convs=True)``)."""
+        ``weights.write_blob(weights.synthetic_weights("baseline"), int8_convs=True)``).
+        ``streams_per_workgroup``: which plan the fused kernel runs -- None: the library's choice (the packed plan, two streams per
+        workgroup, from two streams per CU on), 1 / 2: that plan (2 needs an even ``batch``); it is read by ``nutls_create`` from
+        the environment variable NUTLS_FUSED_STREAMS, which this sets for the duration of the call."""
         self._lib = load_library()
         if variant not in self.VARIANTS:
             raise ValueError("variant must be one of %s" % sorted(self.VARIANTS))
@@ -146,8 +153,18 @@ class NutlsEngine:
         blob = read_blob(weights if weights is not None else DEFAULT_WEIGHTS)
         self._h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(blob, len(blob))
-        _check(self._lib, self._lib.nutls_create(buf, len(blob), self.VARIANTS[variant], int(batch), int(device),
-                                                 ctypes.byref(self._h)))
+        saved = os.environ.get("NUTLS_FUSED_STREAMS")
+        if streams_per_workgroup is not None:
+            os.environ["NUTLS_FUSED_STREAMS"] = str(int(streams_per_workgroup))
+        try:
+            _check(self._lib, self._lib.nutls_create(buf, len(blob), self.VARIANTS[variant], int(batch), int(device),
+                                                     ctypes.byref(self._h)))
+        finally:
+            if streams_per_workgroup is not None:
+                if saved is None:
+                    os.environ.pop("NUTLS_FUSED_STREAMS", None)
+                else:
+                    os.environ["NUTLS_FUSED_STREAMS"] = saved
         # fp32 bytes of the container's tensors: what the modes that de-quantise on load (0-2) keep on the device
         self._fp32_weight_bytes = 4 * sum(int(np.asarray(a).size) for a in parse_blob(blob).values())
         self.batch = int(batch)
@@ -180,6 +197,11 @@ class NutlsEngine:
             raise ValueError("mode must be one of %s" % sorted(self.MODES))
         _check(self._lib, self._lib.nutls_set_mode(self._h, self.MODES[mode]))
         self.mode = mode
+
+    @property
+    def streams_per_workgroup(self) -> int:
+        """Streams one workgroup of the fused kernel steps: 1, or 2 (packed plan, handles of >= 2 streams per CU)."""
+        return int(self._lib.nutls_streams_per_workgroup(self._h))
 
     @property
     def launches_per_step(self) -> int:
@@ -337,7 +359,7 @@ class NutlsEngine:
     def weight_blob_bytes(self) -> int:
         """Bytes of weights one launch reads: the fused kernel's packed blob (conv kernels int8), else the fp32 tensors."""
         if self.mode == "fused":
-            return 4 * int(self._lib.nutls_fused_blob_floats(self.VARIANTS[self.variant]))
+            return 4 * int(self._lib.nutls_fused_plan_blob_floats(self.VARIANTS[self.variant], self.streams_per_workgroup))
         return self._fp32_weight_bytes      # (lstm: 11 460 668 B = SURVEY.md section 8(d)'s fp32 weights of the graph)
 
     def profile_fused(self) -> np.ndarray:

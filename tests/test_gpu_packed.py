@@ -1,0 +1,132 @@
+"""GPU parity of the PACKED plan of the fused kernel (two streams per workgroup, csrc/fused_step_g2.hip, BASELINE configs[3] / [4]):
+the same checks the one-stream plan passes -- goldens of the shipped graph (outputs and every state tensor), oracle B on synthetic
+streams -- plus what packing adds: a stream's results do not depend on its slot in the workgroup or on its partner, both plans
+compute the same function, and the carried partial sums survive state edits.  Reference semantics:
+/root/reference/dnn_model/converter_proposed.py:188-867 (one step of the signature), one stream per call there."""
+import os
+
+import numpy as np
+import pytest
+
+import nunet_amd.topology as T
+from conftest import GOLDEN
+from nunet_amd import NutlsEngine
+from oracle.nutls_ref import NutlsRef
+
+pytestmark = pytest.mark.gpu
+TIGHT_RMS = 2e-5          # fp32 on both sides; differences are summation order only (north-star tolerance: 1e-3)
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def clip():
+    return np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+
+
+def test_plan_choice_follows_the_stream_count():
+    """>= 2 streams per CU: the packed plan by default; fewer, an odd count, or NUTLS_FUSED_STREAMS=1: one stream per workgroup."""
+    for B, want in ((256, 1), (511, 1), (512, 2), (1024, 2)):
+        eng = NutlsEngine(batch=B)
+        assert eng.streams_per_workgroup == want, (B, eng.streams_per_workgroup)
+        eng.close()
+    eng = NutlsEngine(batch=512, streams_per_workgroup=1)
+    assert eng.streams_per_workgroup == 1
+    eng.close()
+    eng = NutlsEngine(batch=6, streams_per_workgroup=2)
+    assert eng.streams_per_workgroup == 2
+    eng.close()
+    eng = NutlsEngine(batch=5, streams_per_workgroup=2)          # odd: falls back
+    assert eng.streams_per_workgroup == 1
+    eng.close()
+
+
+def test_packed_golden_clip_and_every_state_tensor(clip):
+    """Two copies of the golden clip, half a second apart, on ONE workgroup: outputs of 64 frames and all 130 state tensors of both
+    slots against the oracle-A goldens (slot 1 runs 30 frames behind: its goldens are checked when IT has seen 3 / 64 frames)."""
+    eng = NutlsEngine(batch=2, streams_per_workgroup=2)
+    assert eng.streams_per_workgroup == 2
+    lag = 30
+    zeros = np.zeros(256, np.float32)
+    outs0, outs1 = [], []
+    for i in range(64 + lag):
+        x0 = clip["mags_in"][i] if i < 64 else zeros
+        x1 = clip["mags_in"][i - lag] if i >= lag else zeros
+        if i == lag:
+            eng.reset(1)          # slot 1 starts its clip from the all-zero state
+        out = eng.step(np.stack([x0, x1]))
+        if i < 64:
+            outs0.append(out[0])
+        if i >= lag:
+            outs1.append(out[1])
+        for slot, seen in ((0, i + 1), (1, i + 1 - lag)):
+            if seen in (3, 64):
+                st = np.load(os.path.join(GOLDEN, "state_f%d.npz" % seen))
+                for base, shp in T.state_specs():
+                    k_in = base if len(shp) == 1 else base.format("prev")
+                    k_gold = base if len(shp) == 1 else base.format("cur")
+                    got = eng.state_get(k_in)[slot].reshape(-1)
+                    np.testing.assert_allclose(got, st[k_gold].reshape(-1), rtol=1e-4, atol=1e-4, err_msg="slot %d %s" % (slot, k_gold))
+    assert rms(np.stack(outs0), clip["mags_out"][:64]) < TIGHT_RMS
+    assert rms(np.stack(outs1), clip["mags_out"][:64]) < TIGHT_RMS
+    eng.close()
+
+
+def test_packed_vs_oracle_and_slot_independence():
+    """512 synthetic streams (the smallest handle that picks the packed plan by itself), 6 frames: every output against oracle B for
+    the first 16 streams; copies of the same input stream give bit-identical results in either slot, next to any partner."""
+    B, steps = 512, 6
+    rng = np.random.default_rng(7)
+    base = (0.25 * np.abs(rng.standard_normal((steps, 16, 256)))).astype(np.float32)
+    idx = rng.integers(0, 16, size=B)
+    idx[:16] = np.arange(16)
+    idx[16:48] = np.repeat(np.arange(16), 2)[::-1]          # the same stream in both slots of a workgroup, and in slot 0 / slot 1 of others
+    eng, ref = NutlsEngine(batch=B), NutlsRef(batch=16)
+    assert eng.streams_per_workgroup == 2
+    for s in range(steps):
+        out = eng.step(np.ascontiguousarray(base[s][idx]))
+        want = ref.step(base[s]).numpy()
+        assert np.isfinite(out).all()
+        assert rms(out[:16], want) < TIGHT_RMS, s
+        for j in range(16):
+            same = out[idx == j]
+            assert np.array_equal(same, np.broadcast_to(same[0], same.shape)), (s, j)
+    for name in ("msfe6_ee_prev1", "msfe6_ee_prev2", "msfe5_de_prev1", "msfe4_dd3_prev2", "msfe3_de_prev1", "state_c", "msfe6_de_h"):
+        a, b = eng.state_get(name)[:16].reshape(16, -1), ref.state[name].numpy().reshape(16, -1)
+        assert rms(a, b) < 1e-4 * max(1.0, float(np.abs(b).max())), name
+    eng.close()
+
+
+def test_both_plans_compute_the_same_function(clip):
+    """The same 8 streams of the real clip through the one-stream plan and the packed plan: equal up to the summation order of the
+    layers whose tiling differs (K split, 32x32 instead of 16x16 tiles)."""
+    frames = clip["mags_in"]
+    a, b = NutlsEngine(batch=8, streams_per_workgroup=1), NutlsEngine(batch=8, streams_per_workgroup=2)
+    assert (a.streams_per_workgroup, b.streams_per_workgroup) == (1, 2)
+    for i in range(40):
+        x = np.stack([frames[(i + 17 * s) % 249] for s in range(8)])
+        ya, yb = a.step(x), b.step(x)
+        assert rms(ya, yb) < 2e-6, i
+    for name in ("msfe6_ed_prev6", "msfe5_ee_prev2", "msfe6_dd_prev1", "msfe3_en_h"):
+        assert rms(a.state_get(name), b.state_get(name)) < 1e-5, name
+    a.close()
+    b.close()
+
+
+def test_packed_carried_sums_follow_state_edits(clip):
+    """nutls_state_set on a conv-input state of the packed plan: the library rebuilds the carried partial sums (per-stream layout of the
+    packed tilings) before the next step -- the continuation equals that of a handle that never was interrupted."""
+    frames = clip["mags_in"]
+    a, b = NutlsEngine(batch=4, streams_per_workgroup=2), NutlsEngine(batch=4, streams_per_workgroup=2)
+    x = lambda i: np.stack([frames[(i + 31 * s) % 249] for s in range(4)])
+    for i in range(5):
+        a.step(x(i))
+        b.step(x(i))
+    for name in ("msfe6_ee_prev1", "msfe6_ee_prev2", "msfe5_ee_prev1", "msfe5_de_prev1", "msfe6_de_prev2", "msfe4_ee3_prev4"):
+        b.state_set(name, b.state_get(name))          # same values: marks the sums stale
+    for i in range(5, 9):
+        assert rms(a.step(x(i)), b.step(x(i))) < 1e-6, i          # (the rebuilt sums are added up in another order than the kernel's)
+    a.close()
+    b.close()

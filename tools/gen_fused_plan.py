@@ -25,12 +25,20 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "nested-u-net-based-real-time-speech-enhancement-mobile-app_amd")
-def inc_path(variant):
-    return os.path.join(PKG, "csrc", "fused_plan_%s.inc" % ("lstm" if variant == "lstm" else "base"))
+def plan_tag(variant, G=1):
+    return ("lstm" if variant == "lstm" else "base") + ("" if G == 1 else "_g%d" % G)
 
 
-def json_path(variant):
-    return os.path.join(ROOT, "tests", "golden", "fused_plan_%s.json" % ("lstm" if variant == "lstm" else "base"))
+def inc_path(variant, G=1):
+    return os.path.join(PKG, "csrc", "fused_plan_%s.inc" % plan_tag(variant, G))
+
+
+def json_path(variant, G=1):
+    return os.path.join(ROOT, "tests", "golden", "fused_plan_%s.json" % plan_tag(variant, G))
+
+
+# the plans that are built into the library: (variant, streams per workgroup)
+PLANS = [("lstm", 1), ("baseline", 1), ("lstm", 2), ("lstm", 4)]
 
 # (prefix, depth, f0, conv state tag, sub-pixel state tag, resample layer)   converter_proposed.py:221-727
 ENC = [("msfe6_en", 6, 256, "msfe6_ee", "msfe6_ed", "msfe6_down_sampling"),
@@ -54,7 +62,12 @@ S_PREV, S_CUR, S_SCRATCH = 0, 1, 2
 LDS_BYTES = 160 * 1024
 SCR_BYTES = 8192
 SCR_B = LDS_BYTES - SCR_BYTES
-MAX_PARTS, MAX_ZERO, MAX_SEG, CARRY_FRAGS = 4, 12, 6, 12
+MAX_PARTS, MAX_ZERO, MAX_SEG, CARRY_FRAGS = 6, 12, 6, 12
+XCOPY_B = SCR_B + 7168
+# packed plans (several streams per workgroup): scratch of an LSTM op that serves several streams (20 x 21 partial float4 + h per stream),
+# the fp32 rows it reads (1 KB per stream) -- in the middle of LDS: the images around an LSTM are a few KB, the exchange buffers sit at the top
+PK_LSTM_SCR_B, PK_LSTM_SCR_STRIDE, PK_XCOPY_B = 64 * 1024, 7168, 96 * 1024
+PK_CTFA_SCR_STRIDE = 8192
 
 
 def r64(n):
@@ -159,6 +172,10 @@ R32_TABLE = {   # (kind, N, P) -> (PT, NT, PG, CG)
     (K_DOWN, 64, 128): (1, 1, 4, 2), (K_DOWN, 64, 64): (1, 1, 2, 2),
     (K_UP, 128, 128): (2, 1, 2, 4), (K_UP, 128, 64): (1, 1, 2, 4), (K_UP, 128, 32): (1, 1, 1, 4),
 }
+# packed plans only: virtual position counts (streams side by side) no single stream has
+R32_TABLE_PACKED = {
+    (K_DL, 64, 128): (1, 1, 4, 2), (K_EL, 32, 256): (2, 1, 4, 1),
+}
 
 
 def carries_sums(kind, N, P):
@@ -171,13 +188,20 @@ def carries_sums(kind, N, P):
     return 1 if kind == K_EL else 0
 
 
-def tiling(kind, N, P, cin, taps, rounds=1):
+def tiling(kind, N, P, cin, taps, rounds=1, gs=1):
     """-> dict(path, PT, NT, PG, CG, KSt, KSg).  R32B: 32x32x16 bf16 tiles, PT x NT tiles per wave, PG x CG wave tasks, whole
     LayerNorm groups per wave.  X16B: 16x16x32 bf16 tiles, wave task = (position group pg, channel tile ct, K slice
-    (time tap ks_t, channel-group range ks_g)), PT tiles per wave; the K slices meet in the LDS exchange buffer."""
-    if (kind, N, P) in R32_TABLE:
-        PT, NT, PG, CG = R32_TABLE[(kind, N, P)]
+    (time tap ks_t, channel-group range ks_g)), PT tiles per wave; the K slices meet in the LDS exchange buffer.
+    Packed plans: `gs` streams side by side -- the tiling is that of gs * P positions (32x32 tiles: whole tiles per stream).
+    None: no tiling for that many positions (the layer then runs one stream at a time)."""
+    per_stream = P
+    P = gs * P
+    table = {**R32_TABLE, **R32_TABLE_PACKED} if gs > 1 else R32_TABLE
+    if (kind, N, P) in table and (gs == 1 or per_stream % 32 == 0):
+        PT, NT, PG, CG = table[(kind, N, P)]
         return dict(path=P_R32B, PT=PT, NT=NT, PG=PG, CG=CG, KSt=1, KSg=1)
+    if gs > 1 and P > 64:
+        return None
     assert P <= 64, (kind, N, P)
     CT = N // 16
     ptiles = (P + 15) // 16
@@ -277,20 +301,104 @@ def ddb_flops(F, c):
     return 2 * F * (6 * c * g + sum(6 * k * g + g * g for k in range(1, 7)) + 6 * g * c)
 
 
-def build(variant="lstm"):
+def build(variant="lstm", G=1):
+    """The plan of `variant` for workgroups of G streams.  G = 1: one stream per workgroup (the plan every handle can run).
+    G > 1 ("packed"): the layers whose images fit LDS G times run the G streams SIDE BY SIDE (one virtual position axis of G * P:
+    the weights are fetched and converted once, the small layers' mostly empty 16-position tiles fill up), the others run once per
+    stream, one after the other -- `layers` below is the one-stream op list, `ops` the list of op INSTANCES in execution order."""
+    if G == 1:
+        return build_for(variant, 1, {})
+    assert variant == "lstm", "packed plans exist for the LSTM variant"
+    # classification: which layers run side by side -- decided on the layer list of the one-stream plan, by LDS fit
+    _A, _W, layers = build_for(variant, 1, {})
+    cls = classify(layers, G)
+    return build_for(variant, G, cls)
+
+
+def sbs_fit(o, G, nxt_bytes=0):
+    """Can conv layer `o` (a record of the one-stream plan) run G streams side by side?  -> (tiling, image) or None."""
+    kind, N, P, cin, taps = o["kind"], o["N"], o["P"], o["cin"], o["taps"]
+    t = tiling(kind, N, P, cin, taps, 1, gs=G)
+    if t is None:
+        return None
+    ntot = N * (2 if kind == K_UP else 1)
+    lim = SCR_B
+    if t["path"] == P_X16B:
+        ks = t["KSt"] * t["KSg"] * (2 if (o["ys"] and t["KSt"] == 1) else 1)
+        lim = (SCR_B - ks * G * P * (ntot + 4) * 4) // 256 * 256
+    if t["path"] == P_R32B and o["ys"] and not (t["PG"] * t["CG"] == 4 and t["CG"] == 1):
+        return None
+    for fmt in (1, 0):
+        g = make_img(kind, P, cin, 1, fmt=fmt, cps=o["ys"])
+        if G * g["bytes"] <= lim and (fmt == 1 or t["path"] == P_R32B):
+            return t, g, lim
+    return None
+
+
+def classify(layers, G):
+    """layer name -> streams per instance (G: side by side, 1: one stream at a time)."""
+    cls = {}
+    convs = [o for o in layers if o["type"] == T_CONV]
+    for o in convs:
+        cls[o["name"]] = G if sbs_fit(o, G) else 1
+    # an op completes the image of the conv after it between its own barriers: that image set must stay clear of its exchange buffer
+    changed = True
+    while changed:
+        changed = False
+        for a, b in zip(convs, convs[1:]):
+            if cls[a["name"]] == G and cls[b["name"]] == G:
+                ta, ga, lima = sbs_fit(a, G)
+                tb, gb, limb = sbs_fit(b, G)
+                if layers[a["layer"] + 1]["type"] == T_CTFA:
+                    lima = min(lima, SCR_B - (G - 1) * PK_CTFA_SCR_STRIDE)
+                if G * gb["bytes"] > lima:
+                    # demote the one with the larger footprint
+                    cls[(a if ga["bytes"] + (SCR_B - lima) >= gb["bytes"] else b)["name"]] = 1
+                    changed = True
+        # links without an HBM copy of the rows: both ends run the same way.  (decoder) sub-pixel conv D -> CTFA -> down / up-sampling;
+        # up-sampling -> in-conv of the decoder stage; input layer -> first in-conv
+        for i, o in enumerate(layers):
+            if o["type"] == T_CTFA:
+                grp = [layers[i - 1]] + ([layers[i + 1]] if i + 1 < len(layers) else [])
+            elif o["type"] == T_CONV and o["kind"] == K_UP:
+                grp = [o, layers[i + 1]]
+            else:
+                continue
+            if any(cls[x["name"]] == 1 for x in grp) and any(cls[x["name"]] == G for x in grp):
+                for x in grp:
+                    cls[x["name"]] = 1
+                changed = True
+    for i, o in enumerate(layers):
+        if o["type"] == T_CTFA:
+            cls[o["name"]] = cls[layers[i - 1]["name"]]
+        elif o["type"] == T_LSTM:
+            cls[o["name"]] = cls[layers[i + 1]["name"]]
+            assert cls[layers[i - 1]["name"]] == cls[o["name"]] == G, ("an LSTM between layers that run differently", o["name"])
+        elif o["type"] == T_INPUT:
+            cls[o["name"]] = 1
+            assert cls[layers[i + 1]["name"]] == 1
+    return cls
+
+
+def build_for(variant, G, cls):
     A = Arena(variant)
     W = Blob()
     YS = Blob()         # carried partial sums of the two-tap convs: offsets inside one block (the arena holds two: read / write parity)
     ops = []
     base = variant != "lstm"
 
+    def gs_of(name):
+        return cls.get(name, 1)
+
     def new_op(**kw):
         d = dict(type=T_CONV, name="", kind=0, P=0, cin=0, N=0, taps=0, kf=0, stride=0, path=0, PT=1, NT=1, PG=1, CG=1, KSt=1, KSg=1,
                  ln=0, R=1, gc=0, rounds=1, nseg=0, seg_b=[], seg_tk=[], ex_b=0, w_off=0, p_off=0,
                  d0=None, d1=None, row_mul=1, row_add=0, fwd=None, img=None, nxt=-1, parts=[],
                  din=0, dout=0, x_b=0, x_pitch_b=0, x_cols=0, y_b=0, h_off=0, c_off=0, ldst=None, lw_off=0,
-                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0, x_fmt=0, x_plane_b=0, ys=0, ys_off=0, xs_off=0, xs_ld=0)
+                 F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0, x_fmt=0, x_plane_b=0, ys=0, ys_off=0, xs_off=0, xs_ld=0,
+                 gs=1, g0=0, scr_b=SCR_B, scr_gstride_b=0, xcopy_b=XCOPY_B, x_gstride_b=0, layer=-1)
         d.update(kw)
+        d["gs"] = gs_of(d["name"])
         ops.append(d)
         return d
 
@@ -301,23 +409,26 @@ def build(variant="lstm"):
         rounds = 1          # (the strided convs' images hold one time tap: nothing needs two rounds any more)
         o = new_op(type=T_CONV, name=name, wkey=wkey, kind=kind, P=P, cin=cin, N=N, taps=taps, kf=kf, stride=stride, ln=ln, R=R, gc=gc,
                    rounds=rounds, d0=d0, d1=d1, row_mul=row_mul, row_add=row_add, ys=ys)
-        o.update(tiling(kind, N, P, cin, taps, rounds))
+        gs = o["gs"]
+        VP = gs * P         # positions of the op's streams side by side
+        o.update(tiling(kind, N, P, cin, taps, rounds, gs=gs))
         ntot = N * (2 if kind == K_UP else 1)
         x16 = o["path"] == P_X16B
         if x16:
             # exchange slices: K slice (time tap ks_t, channel range ks_g); a two-tap conv whose waves own both taps (KSt 1)
             # still has two slices: 0 = next frame's partial sums, 1 = this frame's
             ks = o["KSt"] * o["KSg"] * (2 if (ys and o["KSt"] == 1) else 1)
-            ex = ks * P * (ntot + 4) * 4
+            ex = ks * VP * (ntot + 4) * 4
             o["ex_b"] = (SCR_B - ex) // 256 * 256
         if ys:
             o["ys_off"] = YS.add(P * ntot, "ysum", wkey)
         lim = o["ex_b"] if x16 else SCR_B
         # the image as three bf16 planes where that fits LDS; the two largest stay fp32 and are split when they are read
         g = make_img(kind, P, cin, rounds, fmt=1, cps=ys)
-        if g["bytes"] > lim:
+        if gs * g["bytes"] > lim:
             assert not x16, name
             g = make_img(kind, P, cin, rounds, fmt=0, cps=ys)
+        g["gstride_b"] = g["bytes"] if gs > 1 else 0
         o["img"] = g
         o["nseg"] = len(g["seg_b"])
         o["seg_b"] = g["seg_b"]
@@ -342,7 +453,7 @@ def build(variant="lstm"):
         o["p_off"] = W.add(2 * ntot + 2 * gc + 1, "conv_p", wkey)      # bias | per-channel weight scale | gamma | beta | alpha
         return o
 
-    # ---- op list --------------------------------------------------------------------------------
+    # ---- layer list (= the op list of the one-stream plan) ------------------------------------------
     inp = new_op(type=T_INPUT, name="input_layer")
     inp["p_off"] = W.add(64 * 4 + 1, "input_p", "input_layer")
 
@@ -407,65 +518,20 @@ def build(variant="lstm"):
         p, D, f0, ct, stg, rs = DEC[s]
         ups[s] = conv_op(rs, rs, K_UP, 1, 0, D, f0 // 2, row_mul=2)
         stage_ops[(1, s)] = stage(1, s)
-    for i, o in enumerate(ops):
-        o["idx"] = i
-    n_ops = len(ops)
+    layers = ops
+    for i, o in enumerate(layers):
+        o["layer"] = i
     assert YS.cur == A.ys_block, (YS.cur, A.ys_block)
 
-    # ---- who completes whose image -----------------------------------------------------------------
-    conv_idx = [o["idx"] for o in ops if o["type"] == T_CONV]
-    for a, b in zip([0] + conv_idx[:-1], conv_idx):
-        ops[a]["nxt"] = b
-    last_conv = ops[conv_idx[-1]]
-
-    def fwd_into(o, tgt, coff):
-        g = tgt["img"]
-        cur_tap = g["taps"] - 1
-        esz = 2 if g["fmt"] else 4
-        o["fwd"] = dict(on=1, base_b=cur_tap * g["tap_b"] + coff * esz, pitch_b=g["pitch_b"], pair=g["pair"], half_b=g["half_b"], row0=g["row0"],
-                        fmt=g["fmt"], plane_b=g["plane_b"])
-
-    for o in ops:
-        if o["type"] not in (T_CONV, T_INPUT) or o["nxt"] < 0:
-            continue
-        tgt = ops[o["nxt"]]
-        coff = 0
-        if o["type"] == T_CONV and o["kind"] == K_EL and tgt["kind"] == K_DL:
-            coff = 32          # e_D -> channels [32,64) of sub-pixel conv 1's input; the LSTM writes [0,32)
-        if o["type"] == T_CONV and o["kind"] == K_DOWN and tgt["kind"] == K_UP:
-            coff = 64          # z -> channels [64,128) of the first up-sampling input; the central LSTM writes [0,64)
-        fwd_into(o, tgt, coff)
-    # the last sub-pixel conv of the network feeds the last CTFA (+ output conv): plain [256][64+4] rows at LDS 0
-    last_conv["fwd"] = dict(on=1, base_b=0, pitch_b=68 * 4, pair=0, half_b=0, row0=0, fmt=0, plane_b=0)
-
-    # LSTM / CTFA work in place on the image of the conv op that follows them
-    for o in ops:
-        if o["type"] in (T_LSTM, T_DDB):
-            tgt = ops[o["idx"] + 1]
-            g = tgt["img"]
-            base = (g["taps"] - 1) * g["tap_b"] + g["row0"] * g["pitch_b"]
-            assert not g["pair"]
-            o["x_b"] = base + o["x_cols"] * (2 if g["fmt"] else 4)
-            o["y_b"] = base
-            o["x_pitch_b"] = g["pitch_b"]
-            o["x_fmt"] = g["fmt"]
-            o["x_plane_b"] = g["plane_b"]
-            if o["type"] == T_DDB:
-                assert g["bytes"] <= DDB_LDS_B and DDB_LDS_B + 17920 * 4 <= SCR_B
-        if o["type"] == T_CTFA:
-            o["fwd"] = dict(ops[o["idx"] - 1]["fwd"])
-            o["last"] = 1 if o["idx"] == n_ops - 1 else 0
-    assert ops[-1]["type"] == T_CTFA and ops[-1]["last"]
-
-    # ---- staged parts of every image --------------------------------------------------------------
+    # ---- staged parts of every layer's image (per stream; the instance list below says for which streams) ------
     def part(src, off, ld, rows, c4s, lds_b, row0, la, round2=0):
-        return dict(src=src, off=off, ld=ld, rows=rows, c4s=c4s, lds_b=lds_b, row0=row0, la=la, round2=round2)
+        return dict(src=src, off=off, ld=ld, rows=rows, c4s=c4s, lds_b=lds_b, row0=row0, la=la, round2=round2, g0=0, ng=1, gstride_b=0)
 
     def esz(g):
         return 2 if g["fmt"] else 4
 
-    def la_of(rows, c4s):
-        return 2 if (rows * c4s + 511) // 512 <= 2 else 1
+    def la_of(rows, c4s, ng=1):
+        return 2 if (ng * rows * c4s + 511) // 512 <= 2 else 1
 
     for side in (0, 1):
         for s in range(6):
@@ -479,7 +545,7 @@ def build(variant="lstm"):
                 o["xs_off"], o["xs_ld"] = st_off(ct, i), cin         # the conv's input state tensor [rows][cin] (nutls_state_set -> partial sums)
                 if side:
                     sk = 64 if i == 1 else 32
-                    parts.append(part(S_CUR, st_off(ct, i) + sk, cin, rows, sk // 4, g["tap_b"] + sk * esz(g), g["row0"], la_of(rows, sk // 4)))
+                    parts.append(part(S_CUR, st_off(ct, i) + sk, cin, rows, sk // 4, g["tap_b"] + sk * esz(g), g["row0"], la_of(rows, sk // 4, o["gs"])))
                 o["parts"] = parts
             for j in range(1, D + 1):
                 o = lst[D + 1 + j]
@@ -488,18 +554,163 @@ def build(variant="lstm"):
                 parts = []
                 o["xs_off"], o["xs_ld"] = st_off(stg, j), 64
                 if not o["ys"]:
-                    parts.append(part(S_PREV, st_off(stg, j), 64, rows, 16, 0, g["row0"], la_of(rows, 16)))
+                    parts.append(part(S_PREV, st_off(stg, j), 64, rows, 16, 0, g["row0"], la_of(rows, 16, o["gs"])))
                 if j >= 2:
                     # e_{D-j+1}, written this frame by strided conv D-j+1: visible after the LSTM's drain point,
                     # i.e. its loads may be issued by sub-pixel conv 1 at the earliest
-                    la = 1 if j == 2 else la_of(rows, 8)
+                    la = 1 if j == 2 else la_of(rows, 8, o["gs"])
                     parts.append(part(S_CUR, st_off(stg, j) + 32, 64, rows, 8, g["tap_b"] + 32 * esz(g), g["row0"], la))
                 o["parts"] = parts
             if side and s >= 1:
                 o = ups[s]
                 g = o["img"]
                 rows = o["P"]
-                o["parts"] = [part(S_SCRATCH, A.scratch["upcat%d" % s] + 64, 128, rows, 16, 64 * esz(g), g["row0"], la_of(rows, 16))]
+                o["parts"] = [part(S_SCRATCH, A.scratch["upcat%d" % s] + 64, 128, rows, 16, 64 * esz(g), g["row0"], la_of(rows, 16, o["gs"]))]
+
+    # ---- where a layer's rows land in the image of the conv layer after it (geometry; per stream) -----------------
+    conv_l = [o["layer"] for o in layers if o["type"] == T_CONV]
+    nxt_layer = {a: b for a, b in zip([0] + conv_l[:-1], conv_l)}          # input / conv layer -> the conv layer whose image it completes
+    prv_layer = {b: a for a, b in nxt_layer.items()}
+
+    def fwd_geom(o, tgt, coff):
+        g = tgt["img"]
+        cur_tap = g["taps"] - 1
+        e = 2 if g["fmt"] else 4
+        return dict(on=1, base_b=cur_tap * g["tap_b"] + coff * e, pitch_b=g["pitch_b"], pair=g["pair"], half_b=g["half_b"], row0=g["row0"],
+                    fmt=g["fmt"], plane_b=g["plane_b"], gstride_b=0, mask=1)
+
+    for o in layers:
+        if o["type"] not in (T_CONV, T_INPUT) or o["layer"] not in nxt_layer:
+            continue
+        tgt = layers[nxt_layer[o["layer"]]]
+        coff = 0
+        if o["type"] == T_CONV and o["kind"] == K_EL and tgt["kind"] == K_DL:
+            coff = 32          # e_D -> channels [32,64) of sub-pixel conv 1's input; the LSTM writes [0,32)
+        if o["type"] == T_CONV and o["kind"] == K_DOWN and tgt["kind"] == K_UP:
+            coff = 64          # z -> channels [64,128) of the first up-sampling input; the central LSTM writes [0,64)
+        o["fwd"] = fwd_geom(o, tgt, coff)
+    # the last sub-pixel conv of the network feeds the last CTFA (+ output conv): plain [256][64+4] rows at LDS 0
+    layers[conv_l[-1]]["fwd"] = dict(on=1, base_b=0, pitch_b=68 * 4, pair=0, half_b=0, row0=0, fmt=0, plane_b=0, gstride_b=0, mask=1)
+
+    # ---- op instances in execution order ------------------------------------------------------------------------
+    # a maximal run of consecutive one-stream-at-a-time layers is walked once per stream; side-by-side layers once for all
+    import copy
+    if G == 1:
+        inst = layers
+    else:
+        inst = []
+        i = 0
+        while i < len(layers):
+            if layers[i]["gs"] == G:
+                inst.append(layers[i])
+                i += 1
+                continue
+            j = i
+            while j < len(layers) and layers[j]["gs"] == 1:
+                j += 1
+            for g0 in range(G):
+                for k in range(i, j):
+                    o = copy.deepcopy(layers[k])
+                    o["g0"] = g0
+                    inst.append(o)
+            i = j
+    ops = inst
+    for i, o in enumerate(ops):
+        o["idx"] = i
+    n_ops = len(ops)
+
+    def streams(o):
+        return set(range(o["g0"], o["g0"] + o["gs"]))
+
+    # ---- who completes whose image: op I (input / conv) builds the image of the next conv instance J -- stages its parts, zeroes its halos
+    #      and forwards the rows of the streams both have, if J's layer is the one I's layer feeds ------------------------------------
+    conv_idx = [o["idx"] for o in ops if o["type"] == T_CONV]
+    # (packed plans: an instance of the network's LAST CTFA that is followed by another stream's ops builds the image after it -- the
+    #  sub-pixel conv before it forwards into the plain rows that CTFA works on, which share LDS with that image)
+    last_layer = len(layers) - 1
+    chain = [o["idx"] for o in ops if o["type"] in (T_CONV, T_INPUT) or (o["type"] == T_CTFA and o["layer"] == last_layer)]
+    for a, b in zip(chain, chain[1:]):
+        if ops[b]["type"] == T_CONV and not (ops[a]["type"] == T_CONV and ops[a]["layer"] == conv_l[-1]):
+            ops[a]["nxt"] = b          # (an input-layer instance in mid-list has no image: the op before it builds nothing)
+    last_conv = ops[conv_idx[-1]]
+    for o in ops:
+        if o["type"] not in (T_CONV, T_INPUT, T_CTFA) or o["nxt"] < 0:
+            if o["type"] in (T_CONV, T_INPUT) and o is not last_conv:
+                o["fwd"] = None
+            continue
+        J = ops[o["nxt"]]
+        gj = J["img"]
+        feeds = nxt_layer.get(o["layer"]) == J["layer"]
+        common = streams(o) & streams(J) if feeds else set()
+        f = o["fwd"]
+        if not common:
+            o["fwd"] = None
+        else:
+            f = dict(f)
+            f["gstride_b"] = gj["gstride_b"]
+            f["mask"] = sum(1 << (s - o["g0"]) for s in common)
+            f["base_b"] += (o["g0"] - J["g0"]) * gj["gstride_b"]
+            o["fwd"] = f
+        # the image of J: its layer's parts for all of J's streams, plus -- for the streams whose rows nobody forwards -- the rows of the
+        # layer before it, from the HBM tensor that layer writes them to
+        parts = []
+        for p in J["parts"]:
+            q = dict(p)
+            q["g0"], q["ng"], q["gstride_b"] = J["g0"], J["gs"], gj["gstride_b"]
+            parts.append(q)
+        missing = sorted(streams(J) - common)
+        if missing and J["layer"] in prv_layer:
+            src_l = layers[prv_layer[J["layer"]]]
+            assert missing == list(range(missing[0], missing[-1] + 1))
+            assert src_l["type"] == T_CONV and src_l["d0"] is not None, ("no HBM copy of the rows of", src_l["name"], "for", J["name"])
+            fg = src_l["fwd"] if src_l["fwd"] else None
+            # (the producer LAYER's forward geometry: recompute -- an instance's may have been cleared)
+            tgt_l = layers[J["layer"]]
+            coff = 32 if (src_l["kind"] == K_EL and tgt_l["kind"] == K_DL) else (64 if (src_l["kind"] == K_DOWN and tgt_l["kind"] == K_UP) else 0)
+            fg = fwd_geom(src_l, tgt_l, coff)
+            d0 = src_l["d0"]
+            rows, c4s = src_l["P"] * src_l["R"], src_l["gc"] // 4
+            q = part(d0[0], d0[1], d0[2], rows, c4s, fg["base_b"] + (missing[0] - J["g0"]) * gj["gstride_b"], fg["row0"], 1)
+            q["g0"], q["ng"], q["gstride_b"] = missing[0], len(missing), gj["gstride_b"]
+            q["fwdsub"] = 1
+            parts.append(q)
+        J["parts"] = parts
+    # the last sub-pixel conv instance(s) of the network feed the last CTFA
+    for o in ops:
+        if o["type"] == T_CONV and o["layer"] == conv_l[-1]:
+            o["fwd"] = dict(layers[conv_l[-1]]["fwd"])
+            o["nxt"] = o["nxt"] if o["nxt"] >= 0 else -1
+
+    # LSTM / CTFA work in place on the image of the conv op that follows them
+    for o in ops:
+        if o["type"] in (T_LSTM, T_DDB):
+            tgt = ops[o["idx"] + 1]
+            g = tgt["img"]
+            assert tgt["type"] == T_CONV and streams(tgt) == streams(o) and streams(ops[o["idx"] - 1]) == streams(o), o["name"]
+            b0 = (g["taps"] - 1) * g["tap_b"] + g["row0"] * g["pitch_b"]
+            assert not g["pair"]
+            o["x_b"] = b0 + o["x_cols"] * (2 if g["fmt"] else 4)
+            o["y_b"] = b0
+            o["x_pitch_b"] = g["pitch_b"]
+            o["x_fmt"] = g["fmt"]
+            o["x_plane_b"] = g["plane_b"]
+            o["x_gstride_b"] = g["gstride_b"]
+            if o["gs"] > 1:
+                o["scr_b"], o["scr_gstride_b"], o["xcopy_b"] = PK_LSTM_SCR_B, PK_LSTM_SCR_STRIDE, PK_XCOPY_B
+                ops[o["idx"] - 1]["xcopy_b"] = PK_XCOPY_B
+                assert o["gs"] * g["bytes"] <= PK_LSTM_SCR_B and PK_LSTM_SCR_B + o["gs"] * PK_LSTM_SCR_STRIDE <= PK_XCOPY_B
+                prev = ops[o["idx"] - 1]
+                assert prev["gs"] * prev["img"]["bytes"] <= PK_LSTM_SCR_B and prev["ex_b"] >= PK_XCOPY_B + o["gs"] * 1024, prev["name"]
+            if o["type"] == T_DDB:
+                assert g["bytes"] <= DDB_LDS_B and DDB_LDS_B + 17920 * 4 <= SCR_B
+        if o["type"] == T_CTFA:
+            prev = ops[o["idx"] - 1]
+            assert prev["type"] == T_CONV and streams(prev) == streams(o) and prev["fwd"] and prev["fwd"]["mask"] == (1 << o["gs"]) - 1, o["name"]
+            o["fwd"] = dict(prev["fwd"])
+            o["last"] = 1 if o["layer"] == len(layers) - 1 else 0
+            if o["gs"] > 1:
+                o["scr_b"], o["scr_gstride_b"] = SCR_B - (o["gs"] - 1) * PK_CTFA_SCR_STRIDE, PK_CTFA_SCR_STRIDE
+    assert ops[-1]["type"] == T_CTFA and ops[-1]["last"]
 
     # ---- checks -----------------------------------------------------------------------------------
     for o in ops:
@@ -507,60 +718,98 @@ def build(variant="lstm"):
             continue
         g = o["img"]
         lim = o["ex_b"] if o["path"] == P_X16B else SCR_B
-        assert g["bytes"] <= lim, (o["name"], g["bytes"], lim)
+        assert o["gs"] * g["bytes"] <= lim, (o["name"], g["bytes"], lim)
         if o["nxt"] >= 0:
-            assert ops[o["nxt"]]["img"]["bytes"] <= lim, (o["name"], "next image over the exchange buffer")
-        assert len(o["parts"]) <= MAX_PARTS and len(g["zero"]) <= MAX_ZERO and o["nseg"] <= MAX_SEG
+            J = ops[o["nxt"]]
+            lim_n = lim
+            if o["idx"] + 1 < n_ops and ops[o["idx"] + 1]["type"] == T_CTFA:
+                lim_n = min(lim_n, ops[o["idx"] + 1]["scr_b"])          # (the CTFA between them works in place on J's image set)
+            assert J["gs"] * J["img"]["bytes"] <= lim_n, (o["name"], "next image over the exchange buffer / scratch", J["name"])
+        assert len(o["parts"]) <= MAX_PARTS and len(g["zero"]) <= MAX_ZERO and o["nseg"] <= MAX_SEG, o["name"]
+        assert sum(z[1] for z in g["zero"]) <= 512, o["name"]
         tasks = o["PG"] * o["CG"] * o["KSt"] * o["KSg"]
         assert tasks in (1, 2, 4, 8), (o["name"], tasks)
         assert g["fmt"] == 1 or o["path"] == P_R32B, o["name"]
+        VP = o["gs"] * o["P"]
         if o["path"] == P_X16B:
-            assert o["PT"] * o["PG"] * 16 >= o["P"] and (o["cin"] // 32) % o["KSg"] == 0 and o["nseg"] % o["KSt"] == 0
+            assert o["PT"] * o["PG"] * 16 >= VP and (o["cin"] // 32) % o["KSg"] == 0 and o["nseg"] % o["KSt"] == 0
         if o["path"] == P_R32B:
-            assert o["P"] % (32 * o["PT"] * o["PG"]) == 0 and (not o["ln"] or o["NT"] * 32 == o["gc"])
-    # Same-frame HBM hand-offs (skip connections): the loads of a staged part may only be issued after a
-    # drain point (every wave has waited for its own stores) that follows the producing op.
+            assert VP % (32 * o["PT"] * o["PG"]) == 0 and (not o["ln"] or o["NT"] * 32 == o["gc"])
+            assert o["gs"] == 1 or o["P"] % 32 == 0
+    # the last CTFA's plain rows
+    # Same-frame HBM hand-offs (skip connections, and in packed plans the rows nobody forwards): the loads of a staged part may only be
+    # issued after a drain point (every wave has waited for its own stores; LSTM / CTFA ops drain when they START, conv ops flagged
+    # `drain` when they END) that follows the producing op.  Where a packed plan has none, the op before the issuing one is flagged.
     builder = {o["nxt"]: o["idx"] for o in ops if o["nxt"] >= 0}
+
+    def drained_between(prod, issue):
+        for k in range(prod, issue):
+            if ops[k]["drain"] and (k > prod or ops[k]["type"] == T_CONV):
+                return True
+        return False
+
+    def producers(src, off, ld, strm):
+        return [q["idx"] for q in ops for d in (q["d0"], q["d1"]) if d and d[0] == src and d[1] == off and d[2] == ld and strm in streams(q)]
+
     for o in ops:
         for p in o["parts"]:
             if p["src"] == S_PREV:
                 continue
-            prod = [q["idx"] for q in ops for d in (q["d0"], q["d1"]) if d and d[0] == p["src"] and d[1] == p["off"] and d[2] == p["ld"]]
-            assert len(prod) == 1, (o["name"], p)
-            issue = builder[o["idx"]] - (p["la"] - 1)
-            assert any(ops[k]["drain"] for k in range(prod[0], issue)), (o["name"], p, prod, issue)
-            p["producer"] = prod[0]
+            b_idx = builder[o["idx"]]
+            prods = []
+            for strm in range(p["g0"], p["g0"] + p["ng"]):
+                pr = [k for k in producers(p["src"], p["off"], p["ld"], strm) if k < o["idx"]]
+                assert len(pr) == 1, (o["name"], p, pr)
+                prods.append(pr[0])
+            prod = max(prods)
+            assert prod < b_idx or p.get("fwdsub"), (o["name"], p, prod, b_idx)
+            if p["la"] == 2 and not (prod < b_idx - 1 and drained_between(prod, b_idx - 1)):
+                p["la"] = 1
+            issue = b_idx - (p["la"] - 1)
+            assert prod < issue, (o["name"], "a staged part's rows are produced by the op that would load them", p, prod, issue)
+            if not drained_between(prod, issue):
+                assert G > 1, (o["name"], p, prod, issue)
+                cand = [k for k in range(prod, issue) if ops[k]["type"] == T_CONV]          # (a conv op drains at its END: its own stores included)
+                assert cand, (o["name"], "no op to drain in between", ops[prod]["name"], ops[issue]["name"])
+                ops[cand[-1]]["drain"] = 1
+            p["producer"] = prod
     # The same rule for what the kernel's weight / operand prefetch reads from THIS frame's state: a CTFA's residual rows e0
     # (fused_step.hip prefetch_w, issued TWO ops ahead of the CTFA) were written by the stage's in-conv earlier in the frame.
     for o in ops:
         if o["type"] != T_CTFA:
             continue
-        prod = [q["idx"] for q in ops for d in (q["d0"], q["d1"]) if d and d[0] == S_CUR and d[1] == o["e0_off"] and d[2] == o["e0_ld"]]
-        assert len(prod) == 1, (o["name"], "producer of the residual rows")
-        issue = o["idx"] - 2
-        assert any(ops[k]["drain"] for k in range(prod[0], issue)), (o["name"], "no drain point between", prod[0], "and the prefetch in", issue)
+        for strm in streams(o):
+            prod = [k for k in producers(S_CUR, o["e0_off"], o["e0_ld"], strm) if k < o["idx"]]
+            assert len(prod) == 1, (o["name"], "producer of the residual rows")
+            issue = o["idx"] - 2
+            assert drained_between(prod[0], issue), (o["name"], "no drain point between", prod[0], "and the prefetch in", issue)
     return A, W, ops
 
 
 # --------------------------------------------------------------------------------- emit
 def c_part(p):
-    return "{%d,%d,%d,%d,%d,%d,%d,%d,%d}" % (p["src"], p["off"], p["ld"], p["rows"], p["c4s"], p["lds_b"], p["row0"], p["la"], p["round2"])
+    return "{%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d}" % (p["src"], p["off"], p["ld"], p["rows"], p["c4s"], p["lds_b"], p["row0"], p["la"], p["round2"],
+                                                 p["g0"], p["ng"], p["gstride_b"])
+
+
+NO_PART = "{0,0,0,0,0,0,0,0,0,0,1,0}"
 
 
 def c_img(o):
     g = o["img"]
     if g is None:
-        return "{0,0,0,0,0,0,0,0,0,0,{%s},0,{%s}}" % (",".join(["{0,0,0,0,0,0,0,0,0}"] * MAX_PARTS), ",".join(["{0,0}"] * MAX_ZERO))
-    parts = [c_part(p) for p in o["parts"]] + ["{0,0,0,0,0,0,0,0,0}"] * (MAX_PARTS - len(o["parts"]))
+        return "{0,0,0,0,0,0,0,0,0,0,0,{%s},0,{%s}}" % (",".join([NO_PART] * MAX_PARTS), ",".join(["{0,0}"] * MAX_ZERO))
+    parts = [c_part(p) for p in o["parts"]] + [NO_PART] * (MAX_PARTS - len(o["parts"]))
     zs = ["{%d,%d}" % z for z in g["zero"]] + ["{0,0}"] * (MAX_ZERO - len(g["zero"]))
-    return "{%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,{%s},%d,{%s}}" % (g["fmt"], g["plane_b"], g["taps"], g["tap_b"], g["pitch_b"], g["pair"], g["half_b"], g["row0"],
-                                                             g["bytes"], len(o["parts"]), ",".join(parts), len(g["zero"]), ",".join(zs))
+    return "{%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,{%s},%d,{%s}}" % (g["fmt"], g["plane_b"], g["taps"], g["tap_b"], g["pitch_b"], g["pair"], g["half_b"], g["row0"],
+                                                                g["bytes"], g["gstride_b"], len(o["parts"]), ",".join(parts), len(g["zero"]), ",".join(zs))
 
 
 def c_fwd(f):
     if not f:
-        return "{0,0,0,0,0,0,0,0}"
-    return "{%d,%d,%d,%d,%d,%d,%d,%d}" % (f["on"], f["base_b"], f["pitch_b"], f["pair"], f["half_b"], f["row0"], f["fmt"], f["plane_b"])
+        return "{0,0,0,0,0,0,0,0,0,0}"
+    return "{%d,%d,%d,%d,%d,%d,%d,%d,%d,%d}" % (f["on"], f["base_b"], f["pitch_b"], f["pair"], f["half_b"], f["row0"], f["fmt"], f["plane_b"],
+                                           f["gstride_b"], f["mask"])
 
 
 def c_dst(d):
@@ -571,9 +820,14 @@ def pad(lst, n):
     return list(lst) + [0] * (n - len(lst))
 
 
-def emit(A, W, ops):
+def op_label(o):
+    return o["name"] + ("#s%d" % o["g0"] if o["g0"] else "")
+
+
+def emit(A, W, ops, G=1):
     L = []
     L.append("// GENERATED by tools/gen_fused_plan.py -- do not edit (tests/test_fused_plan.py checks it is current).")
+    L.append("constexpr int kStreams = %d;              // streams per workgroup (1: the plan every handle can run; > 1: packed plan, OpD::gs / g0)" % G)
     L.append("constexpr int kNumOps = %d;" % len(ops))
     L.append("constexpr int kParityStride = %d;      // floats between the two buffers of every state tensor" % A.PS)
     L.append("constexpr int kArenaFloats = %d;       // per-stream arena the plan addresses (engine.cpp lays it out identically)" % A.floats)
@@ -585,14 +839,15 @@ def emit(A, W, ops):
         seg_b = ",".join(str(x) for x in pad(o["seg_b"], MAX_SEG))
         ldst = o["ldst"]
         row = ("{%d, /*conv*/ %d,%d,%d,%d,%d,%d,%d, %d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, %d,{%s}, %d, %d,%d, %s, %s, %d,%d, %s, %s, %d, "
-               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d},   // %d %s") % (
+               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
             o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
             c_fwd(o["fwd"]), c_img(o), o["nxt"],
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
             1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["x_fmt"], o["x_plane_b"], o["lw_off"],
-            o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["ys"], o["ys_off"], o["xs_off"], o["xs_ld"], o["idx"], o["name"])
+            o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["ys"], o["ys_off"], o["xs_off"], o["xs_ld"],
+            o["gs"], o["g0"], o["scr_b"], o["scr_gstride_b"], o["xcopy_b"], o["x_gstride_b"], o["layer"], o["idx"], op_label(o))
         L.append("  " + row)
     L.append("};")
     # what the host needs to pack the blob / check the arena
@@ -624,28 +879,33 @@ def emit(A, W, ops):
     for o in ops:
         L.append("  {%s}," % ",".join(str(x) for x in pad(o["seg_tk"], MAX_SEG)))
     L.append("};")
-    L.append("static const char* const kOpNames[kNumOps] = {%s};" % ", ".join('"%s"' % o["name"] for o in ops))
+    L.append("static const char* const kOpNames[kNumOps] = {%s};" % ", ".join('"%s"' % op_label(o) for o in ops))
     L.append("static const double kOpFlops[kNumOps] = {%s};" % ", ".join("%d" % o["flops"] for o in ops))
     return "\n".join(L) + "\n"
 
 
+def plan_json(variant, G, A, W, ops):
+    return json.dumps(dict(variant=variant, streams_per_workgroup=G, parity_stride=A.PS, arena_floats=A.floats, blob_floats=W.cur, state_off=A.off,
+                           scratch=A.scratch, blob=[list(x) for x in W.items], ops=ops), indent=1, sort_keys=True)
+
+
 def main():
     stale = False
-    for variant in ("lstm", "baseline"):
-        A, W, ops = build(variant)
-        inc = emit(A, W, ops)
-        js = json.dumps(dict(variant=variant, parity_stride=A.PS, arena_floats=A.floats, blob_floats=W.cur, state_off=A.off, scratch=A.scratch,
-                             blob=[list(x) for x in W.items], ops=ops), indent=1, sort_keys=True)
+    for variant, G in PLANS:
+        A, W, ops = build(variant, G)
+        inc = emit(A, W, ops, G)
+        js = plan_json(variant, G, A, W, ops)
         if "--check" in sys.argv:
-            ok = open(inc_path(variant)).read() == inc and open(json_path(variant)).read() == js
-            print("fused plan (%s) is %s" % (variant, "current" if ok else "STALE"))
+            ok = os.path.exists(inc_path(variant, G)) and open(inc_path(variant, G)).read() == inc and open(json_path(variant, G)).read() == js
+            print("fused plan (%s) is %s" % (plan_tag(variant, G), "current" if ok else "STALE"))
             stale = stale or not ok
             continue
-        open(inc_path(variant), "w").write(inc)
-        open(json_path(variant), "w").write(js)
+        open(inc_path(variant, G), "w").write(inc)
+        open(json_path(variant, G), "w").write(js)
         r32 = [o for o in ops if o["type"] == T_CONV and o["path"] == P_R32B]
-        print("%-8s ops %d (conv %d, of which %d on 32x32 tiles), arena %d floats (parity stride %d), blob %d floats" % (
-            variant, len(ops), sum(o["type"] == T_CONV for o in ops), len(r32), A.floats, A.PS, W.cur))
+        sbs = [o for o in ops if o["gs"] > 1]
+        print("%-8s ops %d (conv %d, of which %d on 32x32 tiles; %d side by side), arena %d floats (parity stride %d), blob %d floats" % (
+            plan_tag(variant, G), len(ops), sum(o["type"] == T_CONV for o in ops), len(r32), len(sbs), A.floats, A.PS, W.cur))
     sys.exit(1 if stale else 0)
 
 
