@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnutls_hip.so")
-SOURCES = ["fused_step.hip", "fused_step_g2.hip", "fused_step_prof.hip", "fused_base.hip", "fused_base_prof.hip", "kernels.hip", "megakernel.hip", "stft.hip", "offline.hip", "weights.cpp", "fused_host.cpp", "engine.cpp"]
+SOURCES = ["fused_step.hip", "fused_step_g2.hip", "fused_step_g4.hip", "fused_step_prof.hip", "fused_base.hip", "fused_base_prof.hip", "kernels.hip", "megakernel.hip", "stft.hip", "offline.hip", "weights.cpp", "fused_host.cpp", "engine.cpp"]
 # (headers are found by scanning the #include "..." lines of every source: _deps)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -974,7 +974,7 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   // Which plan: one stream per workgroup, or -- once there are at least two streams per CU -- the packed plan (two streams per workgroup:
   // one weight fetch / conversion and one latency chain for both in the layers whose images fit LDS twice).  NUTLS_FUSED_STREAMS=1 / 2
   // overrides (2 needs an even stream count).
-  int streams = (e->B >= 2 * e->n_cu && e->B % 2 == 0) ? 2 : 1;
+  int streams = (e->B >= 4 * e->n_cu && e->B % 4 == 0) ? 4 : ((e->B >= 2 * e->n_cu && e->B % 2 == 0) ? 2 : 1);
   if (const char* ev = getenv("NUTLS_FUSED_STREAMS")) streams = atoi(ev);
   if (streams < 1 || !fused_has_plan(v, streams) || e->B % streams != 0) streams = 1;
   if (streams > 1 && (fused_plan_arena_floats(v, streams) != fused_arena_floats(v) || fused_plan_parity_stride(v, streams) != fused_parity_stride(v) ||
@@ -1000,7 +1000,8 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   e->allocs.push_back(q);
   HIP_TRY(hipMemset(q, 0, (fused_num_ops(v) * 9 + 1) * sizeof(unsigned long long)));
   e->fz_prof = static_cast<unsigned long long*>(q);
-  HIP_TRY(v == NUTLS_VARIANT_BASELINE ? fused_base_step_set_attributes() : (streams == 2 ? fused_step_g2_set_attributes() : fused_step_set_attributes()));
+  HIP_TRY(v == NUTLS_VARIANT_BASELINE ? fused_base_step_set_attributes()
+                                      : (streams == 4 ? fused_step_g4_set_attributes() : (streams == 2 ? fused_step_g2_set_attributes() : fused_step_set_attributes())));
   // the table for rebuilding the carried partial sums (ysum_refresh)
   std::vector<YsOp> yops;
   std::vector<float> yw;
@@ -1034,7 +1035,7 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* 
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
   if (int rc = ysum_refresh(e, par, s)) return rc;
   if (prof && e->fz_streams != 1) return fail(NUTLS_ERR_ARG, "the packed fused plan has no profiling build (NUTLS_FUSED_STREAMS=1 selects the one-stream plan)");
-  auto launch = base ? launch_fused_base_step : (e->fz_streams == 2 ? launch_fused_step_g2 : launch_fused_step);
+  auto launch = base ? launch_fused_base_step : (e->fz_streams == 4 ? launch_fused_step_g4 : (e->fz_streams == 2 ? launch_fused_step_g2 : launch_fused_step));
   hipError_t err = launch(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
                           mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
                           base ? e->d_ddb : nullptr, static_cast<int>(e->steps & 0x3fffffff), e->B / e->fz_streams, s);

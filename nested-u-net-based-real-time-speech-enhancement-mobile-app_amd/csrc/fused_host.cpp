@@ -36,6 +36,15 @@ using namespace ::nutls::fz;
 #include "fused_host_impl.inc"
 }  // namespace lstm_g2_plan
 
+// ... and four (fused_step_g4.hip)
+namespace lstm_g4_plan {
+namespace fz {
+using namespace ::nutls::fz;
+#include "fused_plan_lstm_g4.inc"
+}  // namespace fz
+#include "fused_host_impl.inc"
+}  // namespace lstm_g4_plan
+
 namespace base_plan {
 namespace fz {
 using namespace ::nutls::fz;
@@ -64,8 +73,9 @@ int fused_ys_block(int variant) { return FZ_BY_VARIANT(fused_ys_block()); }
 int fused_ys_off(int variant) { return FZ_BY_VARIANT(fused_ys_off()); }
 // (packed plans -- streams per workgroup > 1, LSTM variant -- share the arena layout of the one-stream plan; what differs is the tiling,
 //  hence the blob and the layout of the carried partial sums)
-#define FZ_BY_PLAN(call) ((streams == 2 && variant == NUTLS_VARIANT_LSTM) ? lstm_g2_plan::call : FZ_BY_VARIANT(call))
-bool fused_has_plan(int variant, int streams) { return streams == 1 || (streams == 2 && variant == NUTLS_VARIANT_LSTM); }
+#define FZ_BY_PLAN(call) \
+  ((streams == 2 && variant == NUTLS_VARIANT_LSTM) ? lstm_g2_plan::call : ((streams == 4 && variant == NUTLS_VARIANT_LSTM) ? lstm_g4_plan::call : FZ_BY_VARIANT(call)))
+bool fused_has_plan(int variant, int streams) { return streams == 1 || ((streams == 2 || streams == 4) && variant == NUTLS_VARIANT_LSTM); }
 bool fused_ys_table(int variant, const WeightMap& wm, std::vector<YsOp>* ops, std::vector<float>* w, std::string* err, int streams) {
   return FZ_BY_PLAN(fused_ys_table(wm, ops, w, err));
 }

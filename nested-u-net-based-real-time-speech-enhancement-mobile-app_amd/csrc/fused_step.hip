@@ -868,16 +868,16 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
   const Task t = conv_task<I>(wave);
   const int j = lane & 31, h = lane >> 5;
   int lane_b[PT];
-  // packed plans: position tile vt of the virtual axis belongs to stream slot vt / (P / 32) (whole tiles per stream)
-  static_assert(d.gs == 1 || d.P % 32 == 0, "packed plan: 32x32 tiles do not straddle streams");
-  constexpr int TPS = d.gs > 1 ? d.P / 32 : 1;      // position tiles per stream
-  int tile_g[PT], tile_p0[PT];                            // per position tile: stream slot, first position inside the stream
+  // packed plans: virtual position 32 vt + j of tile vt = stream slot * P + position (a tile may hold several streams' positions when
+  // P < 32; the two-tap convs, whose carried sums are laid out by whole tiles, always have P >= 32)
+  static_assert(d.gs == 1 || !r32_two(d) || d.P % 32 == 0, "packed plan: two-tap conv on 32x32 tiles needs whole tiles per stream");
+  int lane_g[PT], lane_p[PT];                       // per position tile: this lane's stream slot, its position inside the stream
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    const int vt = t.a * PT + pt;
-    tile_g[pt] = d.gs > 1 ? vt >> clog2(TPS) : 0;
-    tile_p0[pt] = d.gs > 1 ? 32 * (vt & (TPS - 1)) : 32 * vt;
-    lane_b[pt] = (d.gs > 1 ? tile_g[pt] * d.img.gstride_b : 0) + (tile_p0[pt] + j) * d.img.pitch_b + (8 * esz_of(FMT)) * h;
+    const int vpos = 32 * (t.a * PT + pt) + j;
+    lane_g[pt] = d.gs > 1 ? vpos >> clog2(d.P) : 0;
+    lane_p[pt] = d.gs > 1 ? vpos & (d.P - 1) : vpos;
+    lane_b[pt] = (d.gs > 1 ? lane_g[pt] * d.img.gstride_b : 0) + lane_p[pt] * d.img.pitch_b + (8 * esz_of(FMT)) * h;
   }
   f32x16 acc[PT][NA];
 #pragma unroll
@@ -966,7 +966,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
     if constexpr (d.ln) alpha = lds1(SCR_B + (2 * NTOT + 2 * d.gc) * 4);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const int pos = tile_p0[pt] + j, gi = tile_g[pt];      // position inside its stream, stream slot
+      const int pos = lane_p[pt], gi = lane_g[pt];      // position inside its stream, stream slot
       const unsigned go = gofs(cx, d.g0 + gi);
       // packed channel of accumulator element e of tile n: nb(n) + 8 (e >> 2) + 4 h + (e & 3)
       if constexpr (d.ln) {

@@ -293,6 +293,9 @@ int fused_plan_num_ops(int variant, int streams);
 hipError_t launch_fused_step_g2(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
                                 unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
 hipError_t fused_step_g2_set_attributes();
+hipError_t launch_fused_step_g4(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                                unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
+hipError_t fused_step_g4_set_attributes();
 int fused_blob_floats(int variant);
 int fused_num_ops(int variant);
 const char* fused_op_name(int variant, int i);

@@ -38,25 +38,28 @@ def _container(variant):
     return write_blob(synthetic_weights("baseline", seed=11, bias_std=0.1, affine_jitter=0.1), int8_convs=True)
 
 
-@pytest.mark.parametrize("variant", ["lstm", "baseline"])
-def test_blob_packing_round_trips_the_container(variant):
+@pytest.mark.parametrize("variant,streams", [("lstm", 1), ("baseline", 1), ("lstm", 2), ("lstm", 4)])
+def test_blob_packing_round_trips_the_container(variant, streams):
+    """(streams > 1: the packed plans -- other tilings, hence another fragment order; one blob item per LAYER, shared by its instances)"""
     import nunet_amd  # noqa: F401
     from nunet_amd.runner import load_library, _fptr
     from nunet_amd.weights import parse_blob
     lib = load_library()
     blob = _container(variant)
     v = {"lstm": 0, "baseline": 1}[variant]
-    n = lib.nutls_fused_blob_floats(v)
+    n = lib.nutls_fused_plan_blob_floats(v, streams)
+    assert n > 0 and (streams > 1 or n == lib.nutls_fused_blob_floats(v))
     out = np.zeros(n, np.float32)
     buf = ctypes.create_string_buffer(blob, len(blob))
-    assert lib.nutls_fused_pack_blob(buf, len(blob), v, _fptr(out), n) == 0, lib.nutls_last_error()
-    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_%s.json" % ("lstm" if variant == "lstm" else "base"))))
-    assert plan["blob_floats"] == n
+    assert lib.nutls_fused_pack_blob_plan(buf, len(blob), v, streams, _fptr(out), n) == 0, lib.nutls_last_error()
+    tag = ("lstm" if variant == "lstm" else "base") + ("" if streams == 1 else "_g%d" % streams)
+    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_%s.json" % tag)))
+    assert plan["blob_floats"] == n and plan["streams_per_workgroup"] == streams
     W, Wq = parse_blob(blob), parse_blob(blob, dequantize=False)
     lane = np.arange(64)
     n_conv = 0
     for o in plan["ops"]:
-        if o["type"] != 1:
+        if o["type"] != 1 or o["g0"] != 0:
             continue
         n_conv += 1
         r32, up = o["path"] == 3, o["kind"] == 4     # 3: 32x32x16 tiles, 4: 16x16x32 tiles (bf16 MFMA, 8 K values per lane and fragment)
@@ -172,3 +175,47 @@ def test_malformed_containers_are_error_codes_not_crashes():
     for b in bad:
         assert rc_of(b) == -2, lib.nutls_last_error()                      # NUTLS_ERR_WEIGHTS
     assert rc_of(good) == 0
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_packed_plans_cover_every_layer_for_every_stream(G):
+    """Packed plans (G streams per workgroup): the op instances are the layers of the one-stream plan -- each exactly once per stream,
+    side by side (gs = G) or one instance per stream (gs = 1, g0 = 0 .. G-1) --, a stream walks its layers in the order of the
+    one-stream plan, everything an op touches fits LDS, rows are forwarded only to the op right after, and every same-frame HBM
+    hand-off has a drain point between the producer and the op that issues the loads."""
+    one = json.load(open(os.path.join(GOLDEN, "fused_plan_lstm.json")))
+    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_lstm_g%d.json" % G)))
+    ops = plan["ops"]
+    assert plan["streams_per_workgroup"] == G and plan["arena_floats"] == one["arena_floats"] and plan["state_off"] == one["state_off"]
+    names = [o["name"] for o in one["ops"]]
+    for s in range(G):
+        mine = [o for o in ops if o["g0"] <= s < o["g0"] + o["gs"]]
+        assert [o["name"] for o in mine] == names, "stream %d does not walk the network in order" % s
+        assert [o["layer"] for o in mine] == list(range(len(names)))
+    assert all(o["gs"] in (1, G) and (o["gs"] == 1 or o["g0"] == 0) for o in ops)
+    assert sum(o["gs"] == G for o in ops) > len(names) // 2          # most layers run side by side
+    SCR_B = 160 * 1024 - 8192
+    for o in ops:
+        if o["type"] == 1:
+            lim = o["ex_b"] if o["path"] == 4 else SCR_B
+            assert o["gs"] * o["img"]["bytes"] <= lim, o["name"]
+            assert o["img"]["gstride_b"] == (o["img"]["bytes"] if o["gs"] > 1 else 0)
+            if o["nxt"] >= 0:
+                J = ops[o["nxt"]]
+                assert J["type"] == 1 and J["idx"] > o["idx"] and J["gs"] * J["img"]["bytes"] <= lim, (o["name"], J["name"])
+            f = o["fwd"]
+            if f and o["nxt"] >= 0:          # forwarded rows land in the image this op completes, for streams both ops have
+                J = ops[o["nxt"]]
+                for i in range(o["gs"]):
+                    if (f["mask"] >> i) & 1:
+                        assert J["g0"] <= o["g0"] + i < J["g0"] + J["gs"]
+        if o["type"] == 1 or (o["type"] == 3 and o["nxt"] >= 0):
+            for p in (ops[o["nxt"]]["parts"] if o["nxt"] >= 0 else []):
+                assert p["la"] in (1, 2) and p["ng"] >= 1 and ops[o["nxt"]]["g0"] <= p["g0"] and p["g0"] + p["ng"] <= ops[o["nxt"]]["g0"] + ops[o["nxt"]]["gs"]
+                if p["src"] != 0:
+                    issue = o["idx"] - (p["la"] - 1)
+                    prod = p["producer"]
+                    assert prod < issue
+                    assert any(ops[k]["drain"] and (k > prod or ops[k]["type"] == 1) for k in range(prod, issue)), (ops[o["nxt"]]["name"], p)
+        if o["type"] == 2:          # LSTM: side by side, its scratch in the middle of LDS
+            assert o["gs"] == G and o["scr_b"] + G * o["scr_gstride_b"] <= o["xcopy_b"] and o["xcopy_b"] + G * 1024 <= ops[o["idx"] - 1]["ex_b"]

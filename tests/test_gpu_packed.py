@@ -1,4 +1,4 @@
-"""GPU parity of the PACKED plan of the fused kernel (two streams per workgroup, csrc/fused_step_g2.hip, BASELINE configs[3] / [4]):
+"""GPU parity of the PACKED plans of the fused kernel (two / four streams per workgroup, csrc/fused_step_g2.hip / _g4.hip, BASELINE configs[3] / [4]):
 the same checks the one-stream plan passes -- goldens of the shipped graph (outputs and every state tensor), oracle B on synthetic
 streams -- plus what packing adds: a stream's results do not depend on its slot in the workgroup or on its partner, both plans
 compute the same function, and the carried partial sums survive state edits.  Reference semantics:
@@ -28,7 +28,7 @@ def clip():
 
 def test_plan_choice_follows_the_stream_count():
     """>= 2 streams per CU: the packed plan by default; fewer, an odd count, or NUTLS_FUSED_STREAMS=1: one stream per workgroup."""
-    for B, want in ((256, 1), (511, 1), (512, 2), (1024, 2)):
+    for B, want in ((256, 1), (511, 1), (512, 2), (1022, 2), (1024, 4), (2048, 4)):
         eng = NutlsEngine(batch=B)
         assert eng.streams_per_workgroup == want, (B, eng.streams_per_workgroup)
         eng.close()
@@ -41,50 +41,54 @@ def test_plan_choice_follows_the_stream_count():
     eng = NutlsEngine(batch=5, streams_per_workgroup=2)          # odd: falls back
     assert eng.streams_per_workgroup == 1
     eng.close()
+    eng = NutlsEngine(batch=8, streams_per_workgroup=4)
+    assert eng.streams_per_workgroup == 4
+    eng.close()
 
 
-def test_packed_golden_clip_and_every_state_tensor(clip):
-    """Two copies of the golden clip, half a second apart, on ONE workgroup: outputs of 64 frames and all 130 state tensors of both
-    slots against the oracle-A goldens (slot 1 runs 30 frames behind: its goldens are checked when IT has seen 3 / 64 frames)."""
-    eng = NutlsEngine(batch=2, streams_per_workgroup=2)
-    assert eng.streams_per_workgroup == 2
-    lag = 30
+@pytest.mark.parametrize("G", [2, 4])
+def test_packed_golden_clip_and_every_state_tensor(clip, G):
+    """G copies of the golden clip, a fraction of a second apart, on ONE workgroup: outputs of 64 frames and all 130 state tensors of
+    every slot against the oracle-A goldens (slot s runs 11 s frames behind: its goldens are checked when IT has seen 3 / 64 frames)."""
+    eng = NutlsEngine(batch=G, streams_per_workgroup=G)
+    assert eng.streams_per_workgroup == G
+    lag = [11 * s for s in range(G)]
     zeros = np.zeros(256, np.float32)
-    outs0, outs1 = [], []
-    for i in range(64 + lag):
-        x0 = clip["mags_in"][i] if i < 64 else zeros
-        x1 = clip["mags_in"][i - lag] if i >= lag else zeros
-        if i == lag:
-            eng.reset(1)          # slot 1 starts its clip from the all-zero state
-        out = eng.step(np.stack([x0, x1]))
-        if i < 64:
-            outs0.append(out[0])
-        if i >= lag:
-            outs1.append(out[1])
-        for slot, seen in ((0, i + 1), (1, i + 1 - lag)):
+    outs = [[] for _ in range(G)]
+    for i in range(64 + lag[-1]):
+        x = [clip["mags_in"][i - lag[s]] if 0 <= i - lag[s] < 64 else zeros for s in range(G)]
+        for s in range(1, G):
+            if i == lag[s]:
+                eng.reset(s)          # slot s starts its clip from the all-zero state
+        out = eng.step(np.stack(x))
+        for s in range(G):
+            seen = i + 1 - lag[s]
+            if 1 <= seen <= 64:
+                outs[s].append(out[s])
             if seen in (3, 64):
                 st = np.load(os.path.join(GOLDEN, "state_f%d.npz" % seen))
                 for base, shp in T.state_specs():
                     k_in = base if len(shp) == 1 else base.format("prev")
                     k_gold = base if len(shp) == 1 else base.format("cur")
-                    got = eng.state_get(k_in)[slot].reshape(-1)
-                    np.testing.assert_allclose(got, st[k_gold].reshape(-1), rtol=1e-4, atol=1e-4, err_msg="slot %d %s" % (slot, k_gold))
-    assert rms(np.stack(outs0), clip["mags_out"][:64]) < TIGHT_RMS
-    assert rms(np.stack(outs1), clip["mags_out"][:64]) < TIGHT_RMS
+                    got = eng.state_get(k_in)[s].reshape(-1)
+                    np.testing.assert_allclose(got, st[k_gold].reshape(-1), rtol=1e-4, atol=1e-4, err_msg="slot %d %s" % (s, k_gold))
+    for s in range(G):
+        assert rms(np.stack(outs[s]), clip["mags_out"][:64]) < TIGHT_RMS, s
     eng.close()
 
 
-def test_packed_vs_oracle_and_slot_independence():
-    """512 synthetic streams (the smallest handle that picks the packed plan by itself), 6 frames: every output against oracle B for
-    the first 16 streams; copies of the same input stream give bit-identical results in either slot, next to any partner."""
+@pytest.mark.parametrize("G", [2, 4])
+def test_packed_vs_oracle_and_slot_independence(G):
+    """512 synthetic streams (the smallest handle that picks a packed plan by itself), 6 frames: every output against oracle B for
+    the first 16 streams; copies of the same input stream give bit-identical results in any slot, next to any partners."""
     B, steps = 512, 6
     rng = np.random.default_rng(7)
     base = (0.25 * np.abs(rng.standard_normal((steps, 16, 256)))).astype(np.float32)
     idx = rng.integers(0, 16, size=B)
     idx[:16] = np.arange(16)
     idx[16:48] = np.repeat(np.arange(16), 2)[::-1]          # the same stream in both slots of a workgroup, and in slot 0 / slot 1 of others
-    eng, ref = NutlsEngine(batch=B), NutlsRef(batch=16)
-    assert eng.streams_per_workgroup == 2
+    eng, ref = NutlsEngine(batch=B, streams_per_workgroup=G), NutlsRef(batch=16)
+    assert eng.streams_per_workgroup == G
     for s in range(steps):
         out = eng.step(np.ascontiguousarray(base[s][idx]))
         want = ref.step(base[s]).numpy()
@@ -99,12 +103,13 @@ def test_packed_vs_oracle_and_slot_independence():
     eng.close()
 
 
-def test_both_plans_compute_the_same_function(clip):
-    """The same 8 streams of the real clip through the one-stream plan and the packed plan: equal up to the summation order of the
+@pytest.mark.parametrize("G", [2, 4])
+def test_both_plans_compute_the_same_function(clip, G):
+    """The same 8 streams of the real clip through the one-stream plan and a packed plan: equal up to the summation order of the
     layers whose tiling differs (K split, 32x32 instead of 16x16 tiles)."""
     frames = clip["mags_in"]
-    a, b = NutlsEngine(batch=8, streams_per_workgroup=1), NutlsEngine(batch=8, streams_per_workgroup=2)
-    assert (a.streams_per_workgroup, b.streams_per_workgroup) == (1, 2)
+    a, b = NutlsEngine(batch=8, streams_per_workgroup=1), NutlsEngine(batch=8, streams_per_workgroup=G)
+    assert (a.streams_per_workgroup, b.streams_per_workgroup) == (1, G)
     for i in range(40):
         x = np.stack([frames[(i + 17 * s) % 249] for s in range(8)])
         ya, yb = a.step(x), b.step(x)
@@ -115,11 +120,12 @@ def test_both_plans_compute_the_same_function(clip):
     b.close()
 
 
-def test_packed_carried_sums_follow_state_edits(clip):
+@pytest.mark.parametrize("G", [2, 4])
+def test_packed_carried_sums_follow_state_edits(clip, G):
     """nutls_state_set on a conv-input state of the packed plan: the library rebuilds the carried partial sums (per-stream layout of the
     packed tilings) before the next step -- the continuation equals that of a handle that never was interrupted."""
     frames = clip["mags_in"]
-    a, b = NutlsEngine(batch=4, streams_per_workgroup=2), NutlsEngine(batch=4, streams_per_workgroup=2)
+    a, b = NutlsEngine(batch=4, streams_per_workgroup=G), NutlsEngine(batch=4, streams_per_workgroup=G)
     x = lambda i: np.stack([frames[(i + 31 * s) % 249] for s in range(4)])
     for i in range(5):
         a.step(x(i))

@@ -197,7 +197,8 @@ def tiling(kind, N, P, cin, taps, rounds=1, gs=1):
     per_stream = P
     P = gs * P
     table = {**R32_TABLE, **R32_TABLE_PACKED} if gs > 1 else R32_TABLE
-    if (kind, N, P) in table and (gs == 1 or per_stream % 32 == 0):
+    # (32x32 tiles may hold several streams' positions -- except those of the two-tap convs, whose carried sums are laid out by whole tiles)
+    if (kind, N, P) in table and (gs == 1 or per_stream % 32 == 0 or kind != K_EL):
         PT, NT, PG, CG = table[(kind, N, P)]
         return dict(path=P_R32B, PT=PT, NT=NT, PG=PG, CG=CG, KSt=1, KSg=1)
     if gs > 1 and P > 64:
@@ -735,7 +736,7 @@ def build_for(variant, G, cls):
             assert o["PT"] * o["PG"] * 16 >= VP and (o["cin"] // 32) % o["KSg"] == 0 and o["nseg"] % o["KSt"] == 0
         if o["path"] == P_R32B:
             assert VP % (32 * o["PT"] * o["PG"]) == 0 and (not o["ln"] or o["NT"] * 32 == o["gc"])
-            assert o["gs"] == 1 or o["P"] % 32 == 0
+            assert o["gs"] == 1 or o["P"] % 32 == 0 or not o["ys"]
     # the last CTFA's plain rows
     # Same-frame HBM hand-offs (skip connections, and in packed plans the rows nobody forwards): the loads of a staged part may only be
     # issued after a drain point (every wave has waited for its own stores; LSTM / CTFA ops drain when they START, conv ops flagged
