@@ -113,6 +113,11 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
 #define NUTLS_CTFA_FRAME 0
 #define NUTLS_CTFA_CAUSAL32 1
 int nutls_offline_set_ctfa_mode(nutls_handle* h, int mode);
+/* The same choice for any handle.  Offline handles: as above.  Streaming handles (fused kernel, mode 3, only): NUTLS_CTFA_CAUSAL32 keeps
+ * the time attention of the last 32 frames of every stream and stage in the library (not a signature tensor: the reference's streaming
+ * graph has no such state) and feeds the frequency branch their mean -- streaming then equals the offline / training
+ * model's attention (proposed.py:143-147) frame by frame.  nutls_reset clears a stream's history, a mode switch everyone's. */
+int nutls_set_ctfa_mode(nutls_handle* h, int mode);
 /* Block pipeline of an offline handle.  Only the 13 LSTM recurrences are serial over the frames of a block, and every
  * layer is causal in time, so a block is cut into `chunks` runs of consecutive frames: chunk 0 executes on the caller's
  * stream, chunk c > 0 on its own HIP stream one bottleneck behind chunk c-1 (it needs that chunk's last frame:
@@ -204,6 +209,10 @@ int nutls_fused_pack_blob(const void* weights, size_t n_bytes, int variant, floa
 /* The same for the plan with `streams` streams per workgroup (1: the two entries above; 2: the packed plan of the LSTM variant, whose
  * tilings -- hence fragment order -- differ); nutls_fused_plan_blob_floats is 0 where no such plan exists. */
 int nutls_fused_plan_blob_floats(int variant, int streams);
+/* Op instances of that plan (a packed plan has one instance of a layer per group of streams that runs it side by side: "name#s2" = the
+ * instance that starts at stream slot 2) -- the count nutls_profile_fused expects for a handle on that plan. */
+int nutls_fused_plan_num_ops(int variant, int streams);
+int nutls_fused_plan_op_info(int variant, int streams, int index, const char** name, double* flops);
 int nutls_fused_pack_blob_plan(const void* weights, size_t n_bytes, int variant, int streams, float* out, size_t n_floats);
 
 const char* nutls_last_error(void);

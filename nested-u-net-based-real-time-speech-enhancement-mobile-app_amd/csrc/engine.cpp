@@ -150,7 +150,10 @@ struct Engine {
   int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel (plan interpreter),
                          // 3 fused kernel (statically scheduled; both variants)
   float* fz_blob = nullptr;              // weight blob of the fused kernel (plan order)
-  int fz_streams = 1;                    // streams per workgroup of the fused plan this handle runs (packed plan: 2, from 512 streams on)
+  int fz_streams = 1;                    // streams per workgroup of the fused plan this handle runs (packed plans: 2 from 512 streams on, 4 from 1024)
+  // CTFA frequency branch of the fused kernel (nutls_internal.hpp FzTa): fz_ta_zero = 64 zeros + a dump row (frame mode); causal32 mode of a
+  // streaming handle (nutls_set_ctfa_mode): history ring [B][12][32][64] and the per-step sums [B][12][64]
+  float *fz_ta_zero = nullptr, *fz_ta_ring = nullptr, *fz_ta_sum = nullptr;
   std::string fz_reason;                 // why there is none (what the packer said), for nutls_set_mode(3)
   unsigned long long* fz_prof = nullptr; // op boundary stamps of workgroup 0 (profiling build)
   CompactOp* dplan[2] = {nullptr, nullptr};
@@ -995,10 +998,13 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   e->allocs.push_back(p);
   HIP_TRY(hipMemcpy(p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
   e->fz_blob = static_cast<float*>(p);
+  int rcz = dev_alloc(e, 128, &e->fz_ta_zero, true);
+  if (rcz) return rcz;
   void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, (fused_num_ops(v) * 9 + 1) * sizeof(unsigned long long)));     // op starts + 8 phase stamps per op
+  const size_t n_stamps = static_cast<size_t>(fused_plan_num_ops(v, streams)) * 9 + 1;     // op starts + 8 phase stamps per op
+  HIP_TRY(hipMalloc(&q, n_stamps * sizeof(unsigned long long)));
   e->allocs.push_back(q);
-  HIP_TRY(hipMemset(q, 0, (fused_num_ops(v) * 9 + 1) * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(q, 0, n_stamps * sizeof(unsigned long long)));
   e->fz_prof = static_cast<unsigned long long*>(q);
   HIP_TRY(v == NUTLS_VARIANT_BASELINE ? fused_base_step_set_attributes()
                                       : (streams == 4 ? fused_step_g4_set_attributes() : (streams == 2 ? fused_step_g2_set_attributes() : fused_step_set_attributes())));
@@ -1034,11 +1040,19 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* 
   if (!e->fz_blob) return fail(NUTLS_ERR_ARG, "fused mode is not available for this handle");
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
   if (int rc = ysum_refresh(e, par, s)) return rc;
-  if (prof && e->fz_streams != 1) return fail(NUTLS_ERR_ARG, "the packed fused plan has no profiling build (NUTLS_FUSED_STREAMS=1 selects the one-stream plan)");
   auto launch = base ? launch_fused_base_step : (e->fz_streams == 4 ? launch_fused_step_g4 : (e->fz_streams == 2 ? launch_fused_step_g2 : launch_fused_step));
+  FzTa ta{e->fz_ta_zero, e->fz_ta_zero + 64, 0, 0, 0, 0};
+  if (e->ctfa_causal && e->fz_ta_ring) {
+    const int slot = static_cast<int>(e->steps & 31);          // this frame's row of the history: the sums leave it out, the step overwrites it
+    HIP_TRY(launch_ta_sum(e->fz_ta_ring, e->fz_ta_sum, slot, e->B, s));
+    ta = FzTa{e->fz_ta_sum, e->fz_ta_ring + slot * 64, 12 * 64, 64, 12 * 32 * 64, 32 * 64};
+  }
   hipError_t err = launch(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
                           mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
-                          base ? e->d_ddb : nullptr, static_cast<int>(e->steps & 0x3fffffff), e->B / e->fz_streams, s);
+                          base ? e->d_ddb : nullptr, static_cast<int>(e->steps & 0x3fffffff), e->B / e->fz_streams, s, ta);
+  if (err == hipErrorNotSupported && prof)
+    return fail(NUTLS_ERR_ARG, "this packed fused plan has no profiling build in the library (NUTLS_BUILD_G4_PROF=1 python -m nunet_amd.build adds the 4-stream one; "
+                               "NUTLS_FUSED_STREAMS=1 selects the one-stream plan)");
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("fused step launch: ") + hipGetErrorString(err));
   if (base) e->d_step_stale = true;      // ring position of the dilated-dense history went in by value: one launch per step
   return NUTLS_OK;
@@ -1359,6 +1373,30 @@ int nutls_offline_set_ctfa_mode(nutls_handle* h, int mode) {
   return NUTLS_OK;
 }
 
+/* Streaming handles: the same choice for the fused kernel's CTFA (mode 3).  Causal32 keeps, outside the arena, the time attention of the
+ * last 32 frames of every stream and stage; the sums over the 31 frames before the current one are formed by a small kernel in front of
+ * the step (two launches per frame in this mode), the step itself is the same kernel. */
+int nutls_set_ctfa_mode(nutls_handle* h, int mode) {
+  if (!h) return fail(NUTLS_ERR_ARG, "nutls_set_ctfa_mode: null handle");
+  if (h->eng.offline) return nutls_offline_set_ctfa_mode(h, mode);
+  if (mode != NUTLS_CTFA_FRAME && mode != NUTLS_CTFA_CAUSAL32) return fail(NUTLS_ERR_ARG, "nutls_set_ctfa_mode: unknown mode");
+  Engine* e = &h->eng;
+  if (e->ctfa_causal == (mode == NUTLS_CTFA_CAUSAL32)) return NUTLS_OK;      // already in effect: the history stays
+  if (mode == NUTLS_CTFA_CAUSAL32 && (!e->fz_blob || e->mode != 3))
+    return fail(NUTLS_ERR_ARG, "nutls_set_ctfa_mode: the causal32 CTFA of a streaming handle runs on the fused kernel (mode 3) only");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t ring = static_cast<size_t>(e->B) * 12 * 32 * 64;
+  if (mode == NUTLS_CTFA_CAUSAL32 && !e->fz_ta_ring) {
+    int rc = dev_alloc(e, ring, &e->fz_ta_ring, true);
+    if (!rc) rc = dev_alloc(e, static_cast<size_t>(e->B) * 12 * 64, &e->fz_ta_sum, true);
+    if (rc) return rc;
+  }
+  if (e->fz_ta_ring) HIP_TRY(hipMemset(e->fz_ta_ring, 0, ring * sizeof(float)));      // a mode switch starts a new history
+  e->ctfa_causal = mode == NUTLS_CTFA_CAUSAL32;
+  return NUTLS_OK;
+}
+
 int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames, void* stream) {
   if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_process_block: null pointer");
   Engine* e = &h->eng;
@@ -1483,6 +1521,8 @@ int nutls_set_mode(nutls_handle* h, int mode) {
     return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 3 (fused kernel) needs a streaming handle made from a container with int8 conv kernels" +
                                    (h->eng.fz_reason.empty() ? std::string() : " (" + h->eng.fz_reason + ")"));
   if (h->eng.offline && mode != 0) return fail(NUTLS_ERR_ARG, "nutls_set_mode: offline handles run per-layer launches (mode 0)");
+  if (mode != 3 && h->eng.ctfa_causal && !h->eng.offline)
+    return fail(NUTLS_ERR_ARG, "nutls_set_mode: the causal32 CTFA of a streaming handle runs on the fused kernel (mode 3) only");
   if (mode == 1) return nutls_use_graph(h, 1);
   h->eng.mode = mode;
   return NUTLS_OK;
@@ -1709,6 +1749,11 @@ int nutls_reset(nutls_handle* h, int stream_idx) {
   if (stream_idx < 0) HIP_TRY(hipMemset(e->arena, 0, e->sstride * sizeof(float) * e->B));
   else HIP_TRY(hipMemset(e->arena + e->sstride * stream_idx, 0, e->sstride * sizeof(float)));
   if (e->ta_hist) HIP_TRY(hipMemset(e->ta_hist, 0, static_cast<size_t>(12) * (31 + e->offline) * 64 * sizeof(float)));
+  if (e->fz_ta_ring) {      // streaming causal32 CTFA: the stream's (all streams') time-attention history
+    const size_t per = static_cast<size_t>(12) * 32 * 64;
+    if (stream_idx < 0) HIP_TRY(hipMemset(e->fz_ta_ring, 0, per * e->B * sizeof(float)));
+    else HIP_TRY(hipMemset(e->fz_ta_ring + per * stream_idx, 0, per * sizeof(float)));
+  }
   if (e->fe_tail) {   // STFT front / back end: previous hop and overlap tail
     const size_t hop = NUTLS_FRAME_STEP * sizeof(float);
     if (stream_idx < 0) {
@@ -1852,6 +1897,18 @@ int nutls_fused_pack_blob(const void* weights, size_t n_bytes, int variant, floa
   return nutls_fused_pack_blob_plan(weights, n_bytes, variant, 1, out, n_floats);
 }
 
+int nutls_fused_plan_num_ops(int variant, int streams) {
+  return (known_variant(variant) && fused_has_plan(variant, streams)) ? fused_plan_num_ops(variant, streams) : 0;
+}
+
+int nutls_fused_plan_op_info(int variant, int streams, int index, const char** name, double* flops) {
+  if (!known_variant(variant) || !fused_has_plan(variant, streams)) return fail(NUTLS_ERR_ARG, "nutls_fused_plan_op_info: no such plan");
+  if (index < 0 || index >= fused_plan_num_ops(variant, streams)) return fail(NUTLS_ERR_ARG, "nutls_fused_plan_op_info: bad index");
+  if (name) *name = fused_plan_op_name(variant, streams, index);
+  if (flops) *flops = fused_plan_op_flops(variant, streams, index);
+  return NUTLS_OK;
+}
+
 int nutls_fused_plan_blob_floats(int variant, int streams) {
   return (known_variant(variant) && fused_has_plan(variant, streams)) ? fused_plan_blob_floats(variant, streams) : 0;
 }
@@ -1885,7 +1942,8 @@ int nutls_fused_op_info(int variant, int index, const char** name, double* flops
 int nutls_profile_fused(nutls_handle* h, double* us, int n) {
   if (!h || !us) return fail(NUTLS_ERR_ARG, "nutls_profile_fused: null pointer");
   Engine* e = &h->eng;
-  if (n != fused_num_ops(e->variant)) return fail(NUTLS_ERR_ARG, "nutls_profile_fused: n must equal nutls_fused_num_ops(variant)");
+  if (n != fused_plan_num_ops(e->variant, e->fz_streams))
+    return fail(NUTLS_ERR_ARG, "nutls_profile_fused: n must equal nutls_fused_plan_num_ops(variant, nutls_streams_per_workgroup(h))");
   HIP_TRY(hipSetDevice(e->device));
   const int par = e->next_parity;
   int rc = run_fused(e, par, e->stream, true);
@@ -1904,7 +1962,7 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n) {
     HIP_TRY(hipMemcpy(sub.data(), e->fz_prof + n + 1, sub.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (FILE* f = fopen(dump, "w")) {
       for (int i = 0; i < n; ++i) {
-        fprintf(f, "%-24s total %6.2f |", fused_op_name(e->variant, i), us[i]);
+        fprintf(f, "%-24s total %6.2f |", fused_plan_op_name(e->variant, e->fz_streams, i), us[i]);
         // stamp slots in chronological order: 0 loads issued, 5 carried weights arrived, 6 MFMA loop done (4x4 path),
         // 1 partials / parameters written, 2 past barrier 1, 3 epilogue done, 4 next image built
         const int order[7] = {0, 5, 6, 1, 2, 3, 4};

@@ -88,5 +88,7 @@ int fused_plan_parity_stride(int variant, int streams) { return FZ_BY_PLAN(fused
 int fused_plan_ys_off(int variant, int streams) { return FZ_BY_PLAN(fused_ys_off()); }
 int fused_plan_ys_block(int variant, int streams) { return FZ_BY_PLAN(fused_ys_block()); }
 int fused_plan_num_ops(int variant, int streams) { return FZ_BY_PLAN(fused_num_ops()); }
+const char* fused_plan_op_name(int variant, int streams, int i) { return FZ_BY_PLAN(fused_op_name(i)); }
+double fused_plan_op_flops(int variant, int streams, int i) { return FZ_BY_PLAN(fused_op_flops(i)); }
 
 }  // namespace nutls

@@ -79,7 +79,8 @@ struct OpD {
   int F, e0_off, e0_ld, last, cw_off;      // operates in place on fwd-described rows; cw: ta(w1T,b1,w2,b2) | fa(...)
   // ---- all -------------------------------------------------------------------------------------
   int drain;                               // every wave drains its memory counter before the op's last barrier
-  int bidx;                                // T_DDB (baseline variant): which of the 13 dilated-dense bottlenecks (uses x_cols, y_b, x_pitch_b)
+  int bidx;                                // T_DDB (baseline variant): which of the 13 dilated-dense bottlenecks (uses x_cols, y_b, x_pitch_b);
+                                           // T_CTFA: which of the 12 CTFAs (encoder stages 0..5, decoder stages 6..11): row of FzTa::sum / ring
   // ---- carried partial sums (two-tap convs) ------------------------------------------------------
   int ys;                                  // 1: y_t = W[tap 1] x_t + S_{t-1} with S_t = W[tap 0] x_t: the image holds x_t only, S travels through HBM as
                                            // P x N fp32 ([pos][packed channel], unscaled integer-weight sums), block kYsOff + parity * kYsBlock

@@ -106,6 +106,9 @@ struct Ctx {
   gcf_t io_in;                 // the first stream's 256 input magnitudes (stream g: + 256 g floats)
   gf_t io_out;
   unsigned sstride_b;          // packed plans: bytes between the arena slices of consecutive streams
+  // CTFA frequency branch (FzTa): what is added to the frame's time attention before the / 32, and where the time attention goes
+  gcb_t ta_sum, ta_ring;
+  int ta_sum_sstride, ta_sum_gstride, ta_ring_sstride, ta_ring_gstride;
   unsigned long long* prof;
   const DdbParams* ddb;        // baseline variant: the 13 dilated-dense blocks of this step's parity
   int stream, step;            // step: frame counter (position in the dilated-dense history rings)
@@ -1201,7 +1204,7 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
   // gate perceptrons (wave gi for stream slot gi -- wave 0 in a one-stream plan: lane c holds its 16 input / output weights of each
   // of the four matrices): requested now, used after the column sums.  (In the carry they would cost every wave of the preceding
   // sub-pixel conv 64 registers.)
-  float b1t = 0.f, b1f = 0.f, b2t = 0.f, b2f = 0.f;
+  float b1t = 0.f, b1f = 0.f, b2t = 0.f, b2f = 0.f, ta_prev = 0.f;
   f32x4 w1t[4], w2t[4], w1f[4], w2f[4];
   if (wave < GS) {
 #pragma unroll
@@ -1215,6 +1218,9 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
     b2t = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2064 + lane) * 4));
     b1f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 1024 + (lane & 15)) * 4));
     b2f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 2064 + lane) * 4));
+    // frequency branch: the sum of the time attention over the 31 frames before this one (causal32 mode; a vector of zeros in the
+    // default frame mode, where the branch sees TA / 32 -- SURVEY F7), stage d.bidx of this wave's stream
+    ta_prev = ldb1(cx.ta_sum, static_cast<unsigned>(((cx.stream + d.g0 + wave) * cx.ta_sum_sstride + d.bidx * cx.ta_sum_gstride + lane) * 4));
   }
   const f32x4 ow = c.w[NI * GS];
   const float ob = c.w[NI * GS + 1][0];
@@ -1240,7 +1246,10 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
     for (int r = 0; r < 8; ++r) m += lds1(PART + sb + (r * 64 + lane) * 4);
     m = m * (1.0f / d.F);
     const float ta = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t, MSCR + sb, lane));
-    const float fa = fast_sigmoid(gate_mlp(ta * (1.0f / 32.0f), w1f, b1f, w2f, b2f, MSCR + sb, lane));
+    // (frame mode: ta_prev = 0 and the ring is one dump row -- proposed.py:179-183 with T = 1; causal32: the offline model's 32-frame
+    //  average, proposed.py:143-147, the history in a ring of 32 rows per stage outside the arena, engine.cpp nutls_set_ctfa_mode)
+    const float fa = fast_sigmoid(gate_mlp((ta_prev + ta) * (1.0f / 32.0f), w1f, b1f, w2f, b2f, MSCR + sb, lane));
+    stb1(cx.ta_ring, static_cast<unsigned>(((cx.stream + d.g0 + wave) * cx.ta_ring_sstride + d.bidx * cx.ta_ring_gstride + lane) * 4), ta);
     lds1(GATE + sb + lane * 4) = fa * ta;
   }
   lds_barrier();
@@ -1342,6 +1351,7 @@ struct FzArgs {
   float* arena; long long sstride; const float* blob; const float* io_in; float* io_out; int B, par; unsigned long long* prof;
   const DdbParams* ddb;      // baseline variant: table [2 parities][13] (engine.cpp push_ddb), else null
   int step;                  // baseline variant: frames processed so far (position in the dilated-dense history rings)
+  FzTa ta;                   // CTFA frequency branch: see nutls_internal.hpp
 };
 
 #ifndef FZ_PROF
@@ -1352,11 +1362,18 @@ struct FzArgs {
 #define FZ_LAUNCH launch_fused_step_g2
 #define FZ_ATTR fused_step_g2_set_attributes
 #define FZ_NO_PROF_TWIN 1
+#elif FZ_STREAMS == 4 && FZ_PROF
+// (optional translation unit fused_step_g4_prof.hip, built with NUTLS_BUILD_G4_PROF=1: the packed kernel with op-boundary stamps)
+#define FZ_KERNEL nutls_fused_step_g4_prof_kernel
+#define FZ_LAUNCH launch_fused_step_g4_prof
+#define FZ_ATTR fused_step_g4_prof_set_attributes
 #elif FZ_STREAMS == 4
 #define FZ_KERNEL nutls_fused_step_g4_kernel
 #define FZ_LAUNCH launch_fused_step_g4
 #define FZ_ATTR fused_step_g4_set_attributes
 #define FZ_NO_PROF_TWIN 1
+#define FZ_OPT_PROF_LAUNCH launch_fused_step_g4_prof
+#define FZ_OPT_PROF_ATTR fused_step_g4_prof_set_attributes
 #elif FZ_PROF && FZ_BASE
 #define FZ_KERNEL nutls_fused_base_step_prof_kernel
 #define FZ_LAUNCH launch_fused_base_step_prof
@@ -1396,11 +1413,17 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.ysr = (gcb_t)(unsigned long long)(slice + kYsOff + (a.par ? 0 : kYsBlock));
   cx.io_in = (gcf_t)(unsigned long long)(a.io_in + static_cast<size_t>(stream) * 256);
   cx.io_out = (gf_t)(unsigned long long)(a.io_out + static_cast<size_t>(stream) * 256);
-  cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;
+  cx.prof = (PROF && blockIdx.x == 0) ? a.prof : nullptr;          // (packed builds: workgroup 0 = streams 0 .. kStreams - 1)
   cx.ddb = a.ddb ? a.ddb + a.par * 13 : nullptr;
   cx.stream = stream;
   cx.step = a.step;
   cx.sstride_b = static_cast<unsigned>(a.sstride * 4);
+  cx.ta_sum = (gcb_t)(unsigned long long)a.ta.sum;
+  cx.ta_ring = (gcb_t)(unsigned long long)a.ta.ring;
+  cx.ta_sum_sstride = a.ta.sum_sstride;
+  cx.ta_sum_gstride = a.ta.sum_gstride;
+  cx.ta_ring_sstride = a.ta.ring_sstride;
+  cx.ta_ring_gstride = a.ta.ring_gstride;
 #if FZ_BASE
   {
     // one pass over the 13 parameter records of the dilated-dense ops: they stay in the scalar cache for the rest of
@@ -1433,8 +1456,8 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
 
 #if FZ_PROF
 hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s) {
-  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, prof, ddb, step};
+                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta) {
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, prof, ddb, step, ta};
   hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
   return hipGetLastError();
 }
@@ -1442,25 +1465,40 @@ hipError_t FZ_ATTR() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(fz::FZ_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
 }
 #elif defined(FZ_NO_PROF_TWIN)
-// packed builds: `grid` workgroups of kStreams streams each; no profiling twin (`prof` is ignored)
+// packed builds: `grid` workgroups of kStreams streams each.  A profiling twin exists only as an optional translation unit (weak
+// reference: null when it was not built -- `prof` then yields hipErrorNotSupported)
+#ifdef FZ_OPT_PROF_LAUNCH
+hipError_t FZ_OPT_PROF_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                              unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta) __attribute__((weak));
+hipError_t FZ_OPT_PROF_ATTR() __attribute__((weak));
+#endif
 hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s) {
-  (void)prof;
-  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr, ddb, step};
+                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta) {
+  if (prof) {
+#ifdef FZ_OPT_PROF_LAUNCH
+    if (FZ_OPT_PROF_LAUNCH) return FZ_OPT_PROF_LAUNCH(arena, sstride, blob, io_in, io_out, B, par, prof, ddb, step, grid, s, ta);
+#endif
+    return hipErrorNotSupported;
+  }
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr, ddb, step, ta};
   hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 hipError_t FZ_ATTR() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(fz::FZ_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fz::FZ_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+#ifdef FZ_OPT_PROF_ATTR
+  if (e == hipSuccess && FZ_OPT_PROF_ATTR) e = FZ_OPT_PROF_ATTR();
+#endif
+  return e;
 }
 #else
 hipError_t FZ_LAUNCH_PROF(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                          unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
+                          unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
 hipError_t FZ_ATTR_PROF();
 hipError_t FZ_LAUNCH(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s) {
-  if (prof) return FZ_LAUNCH_PROF(arena, sstride, blob, io_in, io_out, B, par, prof, ddb, step, grid, s);
-  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr, ddb, step};
+                     unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta) {
+  if (prof) return FZ_LAUNCH_PROF(arena, sstride, blob, io_in, io_out, B, par, prof, ddb, step, grid, s, ta);
+  fz::FzArgs a{arena, sstride, blob, io_in, io_out, B, par, nullptr, ddb, step, ta};
   hipLaunchKernelGGL(fz::FZ_KERNEL, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, a);
   return hipGetLastError();
 }

@@ -936,6 +936,22 @@ hipError_t launch_ysum_refresh(const float* arena, long long sstride, int x_bloc
   return hipGetLastError();
 }
 
+// Causal32 mode of the streaming CTFA (the offline model's `ctfa`, models/proposed.py:143-147: the frequency branch sees the mean of the
+// time attention over the last 32 frames): the sum over the 31 frames BEFORE the one about to be stepped, from the history ring
+// [B][12 stages][32 frames][64] -- every row but `slot`, the one this frame's time attention will replace.  grid = B * 12, 64 threads.
+__global__ __launch_bounds__(64) void ta_sum_kernel(const float* ring, float* sum, int slot) {
+  const float* r = ring + static_cast<size_t>(blockIdx.x) * (32 * 64) + threadIdx.x;
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) a += k == slot ? 0.f : r[k * 64];
+  sum[static_cast<size_t>(blockIdx.x) * 64 + threadIdx.x] = a;
+}
+
+hipError_t launch_ta_sum(const float* ring, float* sum, int slot, int B, hipStream_t s) {
+  hipLaunchKernelGGL(ta_sum_kernel, dim3(B * 12), dim3(64), 0, s, ring, sum, slot);
+  return hipGetLastError();
+}
+
 __global__ void set_step_kernel(int* step, int value) { *step = value; }
 
 hipError_t launch_set_step(int* step, int value, hipStream_t s) {

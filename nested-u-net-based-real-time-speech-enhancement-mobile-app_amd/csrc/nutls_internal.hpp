@@ -273,10 +273,16 @@ void apply_s16_plan(ConvPlan* c, const ConvParams& p);
 // fused_step.hip (LSTM variant) / fused_base.hip (baseline variant) / fused_host.cpp: the frame step as one specialised
 // instruction stream per op.  `prof` non-null selects the profiling build; `ddb` is the baseline's block table (else null);
 // `step` = frames processed so far (ring position of the baseline's dilated-dense histories), by value: ONE launch per step.
+// CTFA frequency branch of the fused kernels.  Frame mode (default; ctfa_rt with T = 1, proposed.py:162-196): `sum` is one
+// row of 64 zeros and `ring` one dump row, all strides 0 -- the branch sees TA / 32.  Causal32 mode (the offline model's `ctfa`,
+// proposed.py:125-160): `sum` [B][12][64] = the time attention summed over the 31 frames before this one (ta_sum_kernel, launched in
+// front of the step), `ring` points at this frame's row of the history [B][12][32][64] (row = frame mod 32); strides in floats.
+struct FzTa { const float* sum; float* ring; int sum_sstride, sum_gstride, ring_sstride, ring_gstride; };
+hipError_t launch_ta_sum(const float* ring, float* sum, int slot, int B, hipStream_t s);
 hipError_t launch_fused_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                             unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
+                             unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
 hipError_t launch_fused_base_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                                  unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
+                                  unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
 hipError_t fused_step_set_attributes();
 hipError_t fused_base_step_set_attributes();
 enum FusedPack : int { FZ_PACK_OK = 0, FZ_PACK_NOT_INT8 = 1, FZ_PACK_MALFORMED = 2 };
@@ -290,11 +296,13 @@ int fused_plan_parity_stride(int variant, int streams);
 int fused_plan_ys_off(int variant, int streams);
 int fused_plan_ys_block(int variant, int streams);
 int fused_plan_num_ops(int variant, int streams);
+const char* fused_plan_op_name(int variant, int streams, int i);
+double fused_plan_op_flops(int variant, int streams, int i);
 hipError_t launch_fused_step_g2(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                                unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
+                                unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
 hipError_t fused_step_g2_set_attributes();
 hipError_t launch_fused_step_g4(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
-                                unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s);
+                                unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
 hipError_t fused_step_g4_set_attributes();
 int fused_blob_floats(int variant);
 int fused_num_ops(int variant);

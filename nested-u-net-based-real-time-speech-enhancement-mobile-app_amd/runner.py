@@ -44,6 +44,7 @@ ABI_SYMBOLS = (
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
     "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all", "nutls_offline_set_ctfa_mode",
     "nutls_offline_set_pipeline", "nutls_streams_per_workgroup", "nutls_fused_plan_blob_floats", "nutls_fused_pack_blob_plan",
+    "nutls_set_ctfa_mode", "nutls_fused_plan_num_ops", "nutls_fused_plan_op_info",
 )
 
 
@@ -94,6 +95,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_process_block.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_process_block_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
     lib.nutls_offline_set_ctfa_mode.argtypes = [c.c_void_p, c.c_int]
+    lib.nutls_set_ctfa_mode.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_offline_set_pipeline.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_fused_num_ops.argtypes = [c.c_int]
     lib.nutls_fused_op_info.argtypes = [c.c_int, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
@@ -101,6 +103,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_fused_blob_floats.argtypes = [c.c_int]
     lib.nutls_fused_pack_blob.argtypes = [c.c_void_p, c.c_size_t, c.c_int, fp, c.c_size_t]
     lib.nutls_fused_plan_blob_floats.argtypes = [c.c_int, c.c_int]
+    lib.nutls_fused_plan_num_ops.argtypes = [c.c_int, c.c_int]
+    lib.nutls_fused_plan_op_info.argtypes = [c.c_int, c.c_int, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
     lib.nutls_fused_pack_blob_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, fp, c.c_size_t]
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
@@ -191,6 +195,17 @@ class NutlsEngine:
             self.close()
         except Exception:
             pass
+
+    CTFA_MODES = {"frame": 0, "causal32": 1}
+
+    def set_ctfa_mode(self, ctfa_mode: str):
+        """"frame" (default): the frame-wise graph's CTFA, whose frequency branch sees TA/32; "causal32": the offline /
+        training model's 32-frame causal mean of the time attention (models/proposed.py:143-147), history kept per stream inside
+        the library -- fused mode only."""
+        if ctfa_mode not in self.CTFA_MODES:
+            raise ValueError("ctfa_mode must be one of %s" % sorted(self.CTFA_MODES))
+        _check(self._lib, self._lib.nutls_set_ctfa_mode(self._h, self.CTFA_MODES[ctfa_mode]))
+        self.ctfa_mode = ctfa_mode
 
     def set_mode(self, mode: str):
         if mode not in self.MODES:
@@ -349,10 +364,10 @@ class NutlsEngine:
     def fused_plan(self) -> List[Dict[str, object]]:
         """The fused kernel's static schedule: op name and algorithmic flops per stream."""
         res = []
-        v = self.VARIANTS[self.variant]
-        for i in range(self._lib.nutls_fused_num_ops(v)):
+        v, spw = self.VARIANTS[self.variant], self.streams_per_workgroup
+        for i in range(self._lib.nutls_fused_plan_num_ops(v, spw)):
             name, fl = ctypes.c_char_p(), ctypes.c_double()
-            _check(self._lib, self._lib.nutls_fused_op_info(v, i, ctypes.byref(name), ctypes.byref(fl)))
+            _check(self._lib, self._lib.nutls_fused_plan_op_info(v, spw, i, ctypes.byref(name), ctypes.byref(fl)))
             res.append({"layer": name.value.decode(), "flops": fl.value})
         return res
 
@@ -364,7 +379,7 @@ class NutlsEngine:
 
     def profile_fused(self) -> np.ndarray:
         """One fused-mode step with workgroup 0 time-stamping every op boundary; microseconds per op."""
-        us = np.zeros(self._lib.nutls_fused_num_ops(self.VARIANTS[self.variant]), np.float64)
+        us = np.zeros(self._lib.nutls_fused_plan_num_ops(self.VARIANTS[self.variant], self.streams_per_workgroup), np.float64)
         _check(self._lib, self._lib.nutls_profile_fused(
             self._h, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), us.size))
         return us

@@ -180,7 +180,7 @@ def test_malformed_containers_are_error_codes_not_crashes():
 @pytest.mark.parametrize("G", [2, 4])
 def test_packed_plans_cover_every_layer_for_every_stream(G):
     """Packed plans (G streams per workgroup): the op instances are the layers of the one-stream plan -- each exactly once per stream,
-    side by side (gs = G) or one instance per stream (gs = 1, g0 = 0 .. G-1) --, a stream walks its layers in the order of the
+    gs = G, G / 2, .. or 1 streams side by side per instance --, a stream walks its layers in the order of the
     one-stream plan, everything an op touches fits LDS, rows are forwarded only to the op right after, and every same-frame HBM
     hand-off has a drain point between the producer and the op that issues the loads."""
     one = json.load(open(os.path.join(GOLDEN, "fused_plan_lstm.json")))
@@ -192,7 +192,7 @@ def test_packed_plans_cover_every_layer_for_every_stream(G):
         mine = [o for o in ops if o["g0"] <= s < o["g0"] + o["gs"]]
         assert [o["name"] for o in mine] == names, "stream %d does not walk the network in order" % s
         assert [o["layer"] for o in mine] == list(range(len(names)))
-    assert all(o["gs"] in (1, G) and (o["gs"] == 1 or o["g0"] == 0) for o in ops)
+    assert all(o["gs"] in (1, 2, 4) and o["gs"] <= G and o["g0"] % o["gs"] == 0 for o in ops)          # groups: G, G / 2, .. 1 streams, aligned
     assert sum(o["gs"] == G for o in ops) > len(names) // 2          # most layers run side by side
     SCR_B = 160 * 1024 - 8192
     for o in ops:

@@ -310,10 +310,20 @@ def build(variant="lstm", G=1):
     if G == 1:
         return build_for(variant, 1, {})
     assert variant == "lstm", "packed plans exist for the LSTM variant"
-    # classification: which layers run side by side -- decided on the layer list of the one-stream plan, by LDS fit
+    # classification: which layers run how many streams side by side -- decided on the layer list of the one-stream plan, by LDS fit
     _A, _W, layers = build_for(variant, 1, {})
-    cls = classify(layers, G)
-    return build_for(variant, G, cls)
+    cap = {}
+    for _attempt in range(64):
+        cls = classify(layers, G, cap)
+        try:
+            return build_for(variant, G, cls)
+        except NextImageDoesNotFit as e:
+            # the op could not complete the image set of the op after it (its exchange buffer / the CTFA's scratch is in the way): the
+            # one with the larger group runs a smaller one
+            victim = e.target if cls[e.target] >= cls[e.builder] else e.builder
+            assert cls[victim] > 1, str(e)
+            cap[victim] = cls[victim] // 2
+    raise AssertionError("no packed plan found")
 
 
 def sbs_fit(o, G, nxt_bytes=0):
@@ -336,49 +346,58 @@ def sbs_fit(o, G, nxt_bytes=0):
     return None
 
 
-def classify(layers, G):
-    """layer name -> streams per instance (G: side by side, 1: one stream at a time)."""
+def group_sizes(G):
+    out, g = [], G
+    while g >= 1:
+        out.append(g)
+        g //= 2
+    return out
+
+
+def classify(layers, G, cap=None):
+    """layer name -> how many of the workgroup's G streams one instance of the layer runs side by side: G, G / 2, ... or 1 -- the
+    largest group whose images (and exchange buffer) fit LDS, made equal along the links that have no HBM copy of the rows.
+    `cap`: upper bounds per layer (build() lowers them where an op could not complete the image set of the op after it)."""
+    cap = cap or {}
     cls = {}
     convs = [o for o in layers if o["type"] == T_CONV]
     for o in convs:
-        cls[o["name"]] = G if sbs_fit(o, G) else 1
-    # an op completes the image of the conv after it between its own barriers: that image set must stay clear of its exchange buffer
+        cls[o["name"]] = next(g for g in group_sizes(G) if g <= cap.get(o["name"], G) and (g == 1 or sbs_fit(o, g)))
     changed = True
     while changed:
         changed = False
-        for a, b in zip(convs, convs[1:]):
-            if cls[a["name"]] == G and cls[b["name"]] == G:
-                ta, ga, lima = sbs_fit(a, G)
-                tb, gb, limb = sbs_fit(b, G)
-                if layers[a["layer"] + 1]["type"] == T_CTFA:
-                    lima = min(lima, SCR_B - (G - 1) * PK_CTFA_SCR_STRIDE)
-                if G * gb["bytes"] > lima:
-                    # demote the one with the larger footprint
-                    cls[(a if ga["bytes"] + (SCR_B - lima) >= gb["bytes"] else b)["name"]] = 1
-                    changed = True
-        # links without an HBM copy of the rows: both ends run the same way.  (decoder) sub-pixel conv D -> CTFA -> down / up-sampling;
-        # up-sampling -> in-conv of the decoder stage; input layer -> first in-conv
+        # links without an HBM copy of the rows: both ends run the same streams.  (decoder) sub-pixel conv D -> CTFA -> down / up-sampling;
+        # up-sampling -> in-conv of the decoder stage; conv D -> LSTM -> sub-pixel conv 1
         for i, o in enumerate(layers):
             if o["type"] == T_CTFA:
                 grp = [layers[i - 1]] + ([layers[i + 1]] if i + 1 < len(layers) else [])
             elif o["type"] == T_CONV and o["kind"] == K_UP:
                 grp = [o, layers[i + 1]]
+            elif o["type"] in (T_LSTM, T_DDB):
+                grp = [layers[i - 1], layers[i + 1]]
             else:
                 continue
-            if any(cls[x["name"]] == 1 for x in grp) and any(cls[x["name"]] == G for x in grp):
-                for x in grp:
-                    cls[x["name"]] = 1
-                changed = True
+            m = min(cls[x["name"]] for x in grp)
+            for x in grp:
+                if cls[x["name"]] != m:
+                    cls[x["name"]] = m
+                    changed = True
     for i, o in enumerate(layers):
         if o["type"] == T_CTFA:
             cls[o["name"]] = cls[layers[i - 1]["name"]]
         elif o["type"] == T_LSTM:
             cls[o["name"]] = cls[layers[i + 1]["name"]]
-            assert cls[layers[i - 1]["name"]] == cls[o["name"]] == G, ("an LSTM between layers that run differently", o["name"])
+            assert cls[layers[i - 1]["name"]] == cls[o["name"]] == G, ("an LSTM between layers that do not run all streams side by side", o["name"])
         elif o["type"] == T_INPUT:
             cls[o["name"]] = 1
             assert cls[layers[i + 1]["name"]] == 1
     return cls
+
+
+class NextImageDoesNotFit(Exception):
+    def __init__(self, builder, target):
+        Exception.__init__(self, "%s cannot complete the image set of %s" % (builder, target))
+        self.builder, self.target = builder, target
 
 
 def build_for(variant, G, cls):
@@ -497,7 +516,7 @@ def build_for(variant, G, cls):
                 d0 = (S_CUR, st_off(pair[3], 1) + 64, 128) if pair else None
                 d1 = None
             lst.append(conv_op("%s_spconv%d" % (p, j), "%s_spconv%d" % (p, j), K_DL, side, j, D, P, d0=d0, d1=d1, row_mul=2))
-        c = new_op(type=T_CTFA, name=p + "_ctfa", wkey=p, F=f0, e0_off=st_off(ct, 1), e0_ld=c1, drain=1)
+        c = new_op(type=T_CTFA, name=p + "_ctfa", wkey=p, F=f0, e0_off=st_off(ct, 1), e0_ld=c1, drain=1, bidx=(6 + s if side else s))      # bidx: which of the 12 CTFAs (history ring of the causal32 mode)
         c["cw_off"] = W.add(2 * (64 * 16 + 16 + 64 * 16 + 64) + 65, "ctfa", p)
         lst.append(c)
         return lst
@@ -600,21 +619,29 @@ def build_for(variant, G, cls):
         inst = layers
     else:
         inst = []
-        i = 0
-        while i < len(layers):
-            if layers[i]["gs"] == G:
-                inst.append(layers[i])
-                i += 1
-                continue
-            j = i
-            while j < len(layers) and layers[j]["gs"] == 1:
-                j += 1
-            for g0 in range(G):
-                for k in range(i, j):
-                    o = copy.deepcopy(layers[k])
-                    o["g0"] = g0
+
+        def walk(lo, hi, group):
+            """layers[lo:hi] for the streams of `group`: a layer that runs that many side by side becomes one instance; a maximal run of
+            layers with smaller groups is walked once per half of the group (and so on down to single streams)."""
+            i = lo
+            while i < hi:
+                L = layers[i]
+                if L["gs"] >= len(group):
+                    assert L["gs"] == len(group), (L["name"], L["gs"], group)
+                    o = copy.deepcopy(L)
+                    o["g0"] = group[0]
                     inst.append(o)
-            i = j
+                    i += 1
+                    continue
+                j = i
+                while j < hi and layers[j]["gs"] < len(group):
+                    j += 1
+                half = len(group) // 2
+                walk(i, j, group[:half])
+                walk(i, j, group[half:])
+                i = j
+
+        walk(0, len(layers), list(range(G)))
     ops = inst
     for i, o in enumerate(ops):
         o["idx"] = i
@@ -725,7 +752,8 @@ def build_for(variant, G, cls):
             lim_n = lim
             if o["idx"] + 1 < n_ops and ops[o["idx"] + 1]["type"] == T_CTFA:
                 lim_n = min(lim_n, ops[o["idx"] + 1]["scr_b"])          # (the CTFA between them works in place on J's image set)
-            assert J["gs"] * J["img"]["bytes"] <= lim_n, (o["name"], "next image over the exchange buffer / scratch", J["name"])
+            if J["gs"] * J["img"]["bytes"] > lim_n:
+                raise NextImageDoesNotFit(o["name"], J["name"])
         assert len(o["parts"]) <= MAX_PARTS and len(g["zero"]) <= MAX_ZERO and o["nseg"] <= MAX_SEG, o["name"]
         assert sum(z[1] for z in g["zero"]) <= 512, o["name"]
         tasks = o["PG"] * o["CG"] * o["KSt"] * o["KSg"]
