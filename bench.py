@@ -52,7 +52,7 @@ def kernel_source_sha16(mode, variant="lstm"):
     fused = ["fused_step.hip", "fused_plan.hpp", "fused_plan_lstm.inc"]      # (the one-stream plan: the kernel of the headline configuration)
     if variant == "baseline":
         fused = ["fused_step.hip", "fused_base.hip", "fused_plan.hpp", "fused_plan_base.inc", "ddb_device.hpp", "ddb_fused.hpp"]
-    files = {"fused": fused, "persistent": ["megakernel.hip", "ddb_device.hpp"]}.get(mode, [])
+    files = {"fused": fused}.get(mode, [])
     h = hashlib.sha256()
     for f in files:
         with open(os.path.join(PKG, "csrc", f), "rb") as fh:
@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=256, help="streams per GPU")
-    ap.add_argument("--mode", default=None, choices=["fused", "persistent", "graph", "launches"],
+    ap.add_argument("--mode", default=None, choices=["fused", "graph", "launches"],
                     help="default: fused")
     ap.add_argument("--variant", default="lstm", choices=["lstm", "baseline"],
                     help="baseline = dilated-dense bottleneck with synthetic weights, seed 4321 (BASELINE configs[2])")
@@ -399,7 +399,7 @@ def kernel_report(args, eng, pool, out, B, mode):
         by_layer[p["layer"].split("#")[0]]["flops"] += p["flops"]
         by_layer[p["layer"].split("#")[0]]["bytes"] += p["bytes"]
     rep = {}
-    one_launch = mode in ("fused", "persistent")
+    one_launch = mode == "fused"
     if one_launch:
         # The whole step is ONE kernel.  Its average duration over the timed region: HIP events on the launch stream.
         # The event window covers at least --steps launches AND at least 100 ms, so that a short driver run (--steps 20 = 12 ms)
@@ -432,7 +432,7 @@ def kernel_report(args, eng, pool, out, B, mode):
         # peak -- below the HBM bound: the roofline that bounds the step is HBM, and that is the primary record.  The
         # fp32-MFMA view (the arithmetic the results are equivalent to, last round's primary) stays beside it.
         spw = getattr(eng, "streams_per_workgroup", 1) if mode == "fused" else 1
-        kname = fused_kernel_name(args.variant, spw) if mode == "fused" else "nutls_stream_step_kernel"
+        kname = fused_kernel_name(args.variant, spw)
         bf16x3 = mode == "fused"
         alg_bytes = ALG_BYTES_PER_FRAME[args.variant] * B + eng.weight_blob_bytes()
         gbps = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -468,8 +468,8 @@ def kernel_report(args, eng, pool, out, B, mode):
             rep["roofline"].pop("hbm_measured", None)
             return rep
         # in-kernel timeline of workgroup 0 (wall clock stamps at every op boundary)
-        prof = eng.profile_fused if mode == "fused" else eng.profile_persistent
-        names = [p["layer"] for p in (eng.fused_plan() if mode == "fused" else plan)]
+        prof = eng.profile_fused
+        names = [p["layer"] for p in eng.fused_plan()]
         for _ in range(2):
             prof()
         us = np.zeros(len(names))

@@ -134,15 +134,14 @@ int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_ou
 int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out);
 
 /* Execution mode of nutls_step:
- *   3            fused kernel: ONE launch per frame, one 512-thread workgroup per stream; every op of the step
+ *   3            fused kernel: ONE launch per frame, one 512-thread workgroup per stream (per two / four streams from two / four
+ *                streams per CU on: nutls_streams_per_workgroup); every op of the step
  *                is its own specialised instruction stream (static schedule, no plan decoding).  Both variants
  *                have one; it keeps the conv kernels int8 on the device, so it exists for handles made from a
  *                container with int8 conv kernels (what the reference's .tflite stores) and is their default;
- *   2            persistent kernel: ONE launch per frame, one 512-thread workgroup per stream interprets
- *                the device-resident plan (layer boundary = workgroup barrier, not a kernel boundary);
  *   1            one kernel per layer, the ~160 launches captured in a hipGraph (one per state parity);
- *   0            one kernel per layer, plain launches.
- * All of them compute the same function (tests/test_gpu_parity.py::test_execution_modes_agree). */
+ *   0            one kernel per layer, plain launches (the default for containers without int8 conv kernels is 1 in the Python wrapper).
+ * (2 was the plan-interpreter kernel of rounds 1-3; retired, nutls_set_mode(2) is an error.)  All of them compute the same function (tests/test_gpu_parity.py::test_execution_modes_agree). */
 int nutls_set_mode(nutls_handle* h, int mode);
 /* enable != 0: mode 1 (capture + replay); enable == 0: mode 0. */
 int nutls_use_graph(nutls_handle* h, int enable);
@@ -191,10 +190,6 @@ int nutls_launch_info(nutls_handle* h, int index, const char** layer, const char
  * HIP events recorded on that stream; writes the milliseconds of each launch to ms[0..n).
  * Advances the state like nutls_step (input = the library's mag_in buffer).  Synchronous. */
 int nutls_profile_step(nutls_handle* h, float* ms, int n);
-
-/* Persistent-mode twin of nutls_profile_step: runs one step in mode 2 with workgroup 0 stamping
- * wall_clock64() at every layer boundary; writes microseconds per layer to us[0..n). */
-int nutls_profile_persistent(nutls_handle* h, double* us, int n);
 
 /* Fused-mode twin: op count / names / algorithmic flops per stream of a variant's static schedule, and one profiled
  * step (workgroup 0 stamps every op boundary); microseconds per op to us[0..nutls_fused_num_ops(variant of h)). */

@@ -90,9 +90,9 @@ struct StageStates {
   int h, c;
 };
 
-struct ConvLayerW { float *wpk, *wpk16, *bias, *gamma, *beta; float alpha; float *wbf, *wscale; };
+struct ConvLayerW { float *wpk, *bias, *gamma, *beta; float alpha; float *wbf, *wscale; };
 struct LstmW { float *wxT, *whT, *bias, *wdT, *bd; int din, dout; };
-struct CtfaW { float *w1T, *b1, *w2T, *b2, *w2; };   // w2: [64][16] as stored (persistent kernel), w2T: [16][64]
+struct CtfaW { float *w1T, *b1, *w2T, *b2, *w2; };   // w2: [64][16] as stored, w2T: [16][64]
 
 struct Engine {
   int B = 0, device = 0;
@@ -147,8 +147,8 @@ struct Engine {
   int ochunks = 0;                      // 0 = chosen from the block length
   std::vector<int> ogroup;              // launch index of plan_off -> group (a group ends with an LSTM)
   int next_parity = 0;   // parity the next step writes (`cur`); `prev` is read from 1 - next_parity
-  int mode = 2;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 2 persistent per-stream kernel (plan interpreter),
-                         // 3 fused kernel (statically scheduled; both variants)
+  int mode = 0;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 3 fused kernel (statically scheduled; both variants);
+                         // (2 was the plan-interpreter kernel of rounds 1-3, retired)
   float* fz_blob = nullptr;              // weight blob of the fused kernel (plan order)
   int fz_streams = 1;                    // streams per workgroup of the fused plan this handle runs (packed plans: 2 from 512 streams on, 4 from 1024)
   // CTFA frequency branch of the fused kernel (nutls_internal.hpp FzTa): fz_ta_zero = 64 zeros + a dump row (frame mode); causal32 mode of a
@@ -156,8 +156,6 @@ struct Engine {
   float *fz_ta_zero = nullptr, *fz_ta_ring = nullptr, *fz_ta_sum = nullptr;
   std::string fz_reason;                 // why there is none (what the packer said), for nutls_set_mode(3)
   unsigned long long* fz_prof = nullptr; // op boundary stamps of workgroup 0 (profiling build)
-  CompactOp* dplan[2] = {nullptr, nullptr};
-  unsigned long long* dprof = nullptr;
   int n_cu = 256;
   hipGraphExec_t gexec[2] = {nullptr, nullptr};
   std::unordered_map<std::string, std::pair<float*, size_t>> debug;   // name -> (ptr, floats per stream)
@@ -287,7 +285,6 @@ static int prep_conv(Engine* e, const WeightMap& wm, const std::string& layer, c
   ConvLayerW cw{};
   int rc = upload(e, pack_conv_weights(*w, perm, taps, sh.tt, sh.cin, sh.nt), &cw.wpk);
   if (rc) return rc;
-  if ((rc = upload(e, pack_conv_weights16(*w, perm, taps, sh.tt, sh.cin, sh.nt), &cw.wpk16))) return rc;
   std::vector<float> bp(perm.size());
   for (size_t i = 0; i < perm.size(); ++i) bp[i] = b->data[perm[i]];
   if ((rc = upload(e, bp, &cw.bias))) return rc;
@@ -615,7 +612,7 @@ static void push_conv(Engine* e, std::vector<Launch>* plan, const std::string& w
   L.name = wkey;
   L.encoder_strided = enc_strided;
   ConvParams& p = L.conv;
-  p.src0 = src0; p.src1 = src1; p.wpk = w.wpk; p.wpk16 = w.wpk16; p.bias = w.bias; p.gamma = w.gamma; p.beta = w.beta;
+  p.src0 = src0; p.src1 = src1; p.wpk = w.wpk; p.bias = w.bias; p.gamma = w.gamma; p.beta = w.beta;
   p.wbf = w.wbf; p.wscale = w.wscale; p.use_bf16 = 0;
   p.dst0 = dst0; p.dst1 = dst1; p.src_ld = src_ld; p.ld0 = ld0; p.ld1 = ld1;
   p.B = e->B; p.F_in = f_in; p.F_out = f_out; p.log2_fout = ilog2(f_out);
@@ -825,113 +822,8 @@ static void collect_writes(const Launch& L, int idx, std::vector<WriteRegion>* o
 // (hand-off) -- possible when N keeps all its phases resident and every channel of N's current-frame
 // input was written either by L itself (then L forwards those rows from its epilogue) or by a launch
 // before L (then L prefetches them from HBM while its own MFMAs run).
-static void plan_handoffs(const std::vector<Launch>& plan, std::vector<DevLaunch>* dv) {
-  std::vector<WriteRegion> writes;
-  for (size_t i = 0; i < plan.size(); ++i) collect_writes(plan[i], static_cast<int>(i), &writes);
-  const bool disabled = getenv("NUTLS_NO_HANDOFF") != nullptr;
-  for (size_t i = 0; i + 1 < plan.size(); ++i) {
-    if (plan[i + 1].kind != Launch::CONV || plan[i].kind == Launch::OUTCONV || plan[i].kind == Launch::DDB) continue;
-    DevLaunch& L = (*dv)[i];
-    DevLaunch& N = (*dv)[i + 1];
-    const ConvParams& np = N.conv;
-    const float* ncur = (N.cp.tt == 2) ? np.src1 : np.src0;
-    const bool lconv = plan[i].kind == Launch::CONV;
-    bool ok = N.cp.merged && !disabled;
-    int fwd_sel = 0, fwd_coff = 0, covered = 0;
-    if (ok) {
-      for (const WriteRegion& w : writes) {
-        if (w.ld != np.src_ld) continue;
-        const ptrdiff_t off = w.ptr - ncur;
-        if (off < 0 || off >= N.cp.cin) continue;          // not a channel slice of N's input rows
-        covered += w.nchan;
-        if (w.launch > static_cast<int>(i)) ok = false;    // produced later than L (cannot happen, guard)
-        if (w.launch == static_cast<int>(i)) {
-          const int sel = (!lconv || w.ptr == L.conv.dst0) ? 1 : 2;
-          if (fwd_sel && fwd_sel != sel) ok = false;
-          fwd_sel = sel;
-          fwd_coff = static_cast<int>(off);
-        }
-      }
-      // up-sampling writes alternate rows with two launches: each covers all channels once
-      if (covered < N.cp.cin) ok = false;
-      if (fwd_sel && lconv) {
-        const int rows_l = L.conv.F_out * L.conv.row_mul;
-        if (rows_l != np.F_in || (fwd_coff % 4)) ok = false;
-      }
-      if (!lconv && !fwd_sel) ok = false;                  // a non-conv op only hands over what it feeds itself
-    }
-    if (ok && lconv) {
-      L.cp.hand_next = 1;
-      L.cp.fwd_sel = fwd_sel;
-      L.cp.fwd_coff4 = fwd_coff / 4;
-      const bool all_rows = (L.cp.R == L.conv.row_mul);
-      L.cp.fwd_rmul = all_rows ? 1 : L.conv.row_mul;
-      L.cp.fwd_radd = all_rows ? 0 : L.conv.row_add;
-      N.cp.staged_by_prev = 1;
-    } else if (ok) {
-      L.nc_hand = 1;
-      L.nc_fwd_coff = fwd_coff;
-      N.cp.staged_by_prev = 1;
-    } else if (lconv && N.cp.tt == 2 && !N.cp.merged && !disabled) {
-      // un-merged two-tap layer: round 0 is the previous-frame tap of chunk 0, which never depends on
-      // this frame -> hand over that single phase
-      L.cp.hand_next = 1;
-      L.cp.fwd_sel = 0;
-      N.cp.staged_by_prev = 1;
-    }
-  }
-}
-
-static int upload_device_plans(Engine* e) {
-  for (int par = 0; par < 2; ++par) {
-    std::vector<DevLaunch> dv(e->plan[par].size());
-    for (size_t i = 0; i < dv.size(); ++i) {
-      const Launch& L = e->plan[par][i];
-      DevLaunch& d = dv[i];
-      std::memset(&d, 0, sizeof(d));
-      d.ck = L.ck;
-      switch (L.kind) {
-        case Launch::CONV:
-          d.op = DEV_OP_CONV; d.conv = L.conv; d.cp = make_conv_plan(L.ck, L.conv); d.cp.fwd_rmul = 1;
-          if (!getenv("NUTLS_NO_S16")) apply_s16_plan(&d.cp, L.conv);
-          break;
-        case Launch::LSTM: d.op = DEV_OP_LSTM; d.lstm = L.lstm; break;
-        case Launch::CTFA: d.op = DEV_OP_CTFA; d.ctfa = L.ctfa; break;
-        case Launch::INLAYER: d.op = DEV_OP_INLAYER; d.inl = L.inl; break;
-        case Launch::OUTCONV: d.op = DEV_OP_OUTCONV; d.outc = L.outc; break;
-        case Launch::DDB: d.op = DEV_OP_DDB; d.ddb_index = L.ddb_index; break;
-      }
-    }
-    plan_handoffs(e->plan[par], &dv);
-    for (size_t i = 0; i + 1 < dv.size(); ++i) {
-      if (dv[i].op != DEV_OP_CONV || !dv[i].cp.hand_next) continue;
-      ConvPlan& c = dv[i].cp;
-      const ConvPlan& nc = dv[i + 1].cp;
-      const ConvParams& np = dv[i + 1].conv;
-      c.hx_src0 = np.src0; c.hx_src1 = np.src1; c.hx_ld = np.src_ld;
-      c.hx_cc4_shift = nc.cc4_shift; c.hx_n4p_shift = nc.n4p_shift; c.hx_nch_shift = nc.nch_shift;
-      c.hx_nhand = nc.merged ? nc.nph : 1;
-    }
-    if (par == 0 && getenv("NUTLS_DUMP_PLAN")) {
-      for (size_t i = 0; i < dv.size(); ++i)
-        if (dv[i].op == DEV_OP_CONV) {
-          const ConvPlan& c = dv[i].cp;
-          fprintf(stderr, "%-24s F %3d->%3d s16 %d merged %d rounds %d RG %2d KS %2d gpk %2d tiles %2d | staged_by_prev %d pf0 %d hand %d fwd %d@%d r%%%d==%d pre0 %d\n",
-                  e->plan[par][i].name.c_str(), dv[i].conv.F_in, dv[i].conv.F_out, c.s16, c.merged, c.rounds, c.RG, c.KS, c.gpk, c.tiles,
-                  c.staged_by_prev, c.pf_phase0_ready, c.hand_next, c.fwd_sel, c.fwd_coff4, c.fwd_rmul, c.fwd_radd, c.pre_next_phase0);
-        } else {
-          fprintf(stderr, "%-24s (op %d) nc_hand %d fwd_coff %d\n", e->plan[par][i].name.c_str(), dv[i].op, dv[i].nc_hand, dv[i].nc_fwd_coff);
-        }
-    }
-    if (dv.size() > static_cast<size_t>(MK_MAX_OPS)) return fail(NUTLS_ERR_ARG, "plan too long for the LDS-resident form");
-    std::vector<CompactOp> cv(dv.size());
-    for (size_t i = 0; i < dv.size(); ++i) cv[i] = encode_op(dv[i], e->arena, e->warena);
-    void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, cv.size() * sizeof(CompactOp)));
-    e->allocs.push_back(p);
-    HIP_TRY(hipMemcpy(p, cv.data(), cv.size() * sizeof(CompactOp), hipMemcpyHostToDevice));
-    e->dplan[par] = static_cast<CompactOp*>(p);
-  }
+// The baseline variant's 13 dilated-dense blocks, as the device-side table every kernel family reads (host copy: Engine::ddbs).
+static int upload_ddb_table(Engine* e) {
   if (!e->ddbs.empty()) {
     void* t = nullptr;
     HIP_TRY(hipMalloc(&t, e->ddbs.size() * sizeof(DdbParams)));
@@ -939,22 +831,6 @@ static int upload_device_plans(Engine* e) {
     HIP_TRY(hipMemcpy(t, e->ddbs.data(), e->ddbs.size() * sizeof(DdbParams), hipMemcpyHostToDevice));
     e->d_ddb = static_cast<DdbParams*>(t);
   }
-  void* q = nullptr;
-  HIP_TRY(hipMalloc(&q, (e->plan[0].size() * 9 + 3 + 128) * sizeof(unsigned long long)));   // layer stamps + 8 sub-stamps per layer + 2 clock64 + 16 debug
-  HIP_TRY(hipMemset(q, 0, (e->plan[0].size() * 9 + 3 + 128) * sizeof(unsigned long long)));
-  e->allocs.push_back(q);
-  e->dprof = static_cast<unsigned long long*>(q);
-  return NUTLS_OK;
-}
-
-static int run_persistent(Engine* e, int par, hipStream_t s, bool prof) {
-  const int grid = e->B;   // one workgroup per stream; the hardware runs as many as fit (1 per CU)
-  StepArgs a{e->dplan[par], static_cast<int>(e->plan[par].size()), e->B, e->arena, static_cast<long long>(e->sstride), e->warena,
-             e->io_in, e->io_out, prof ? e->dprof : nullptr, e->d_ddb,
-             (prof && getenv("NUTLS_DBG_OP")) ? atoi(getenv("NUTLS_DBG_OP")) : -1};
-  hipError_t err = launch_stream_step(a, grid, s);
-  if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("persistent step launch: ") + hipGetErrorString(err));
-  if (e->variant == NUTLS_VARIANT_BASELINE) HIP_TRY(launch_incr_step(e->d_step, s));
   return NUTLS_OK;
 }
 
@@ -1203,7 +1079,7 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
   build_plan(e, 0);
   build_plan(e, 1);
   try {
-    rc = upload_device_plans(e);
+    rc = upload_ddb_table(e);
   } catch (const std::exception& ex) {     // planning invariants (weights.cpp) are reported, never thrown through the C ABI
     return fail(NUTLS_ERR_ARG, std::string("plan: ") + ex.what());
   }
@@ -1218,7 +1094,6 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
     if (rc) return rc;
     if (e->fz_blob) e->mode = 3;          // the default for streaming handles whose container holds int8 conv kernels
   }
-  HIP_TRY(stream_step_set_attributes());      // dynamic-LDS limit of the one-launch kernels, on THIS handle's device
   e->debug["input_layer"] = {e->t_inlayer, 256 * 64};
   e->debug["msfe6_de.y"] = {e->t_y, 256 * 64};
   e->debug["msfe6_de.up"] = {e->t_up, 256 * 128};
@@ -1516,7 +1391,8 @@ int nutls_use_graph(nutls_handle* h, int enable) {
 }
 
 int nutls_set_mode(nutls_handle* h, int mode) {
-  if (!h || mode < 0 || mode > 3) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode must be 0, 1, 2 or 3");
+  if (!h || mode < 0 || mode > 3) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode must be 0, 1 or 3");
+  if (mode == 2) return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 2 (the plan-interpreter kernel of rounds 1-3) was retired: 3 = fused kernel, 1 / 0 = one kernel per layer");
   if (mode == 3 && !h->eng.fz_blob)
     return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 3 (fused kernel) needs a streaming handle made from a container with int8 conv kernels" +
                                    (h->eng.fz_reason.empty() ? std::string() : " (" + h->eng.fz_reason + ")"));
@@ -1540,11 +1416,6 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   const int par = e->next_parity;
   if (e->mode == 3) {
     int rc = run_fused(e, par, s, false, mag_in, mag_out);
-    if (rc) return rc;
-  } else if (e->mode == 2) {
-    e->ys_dirty = true;      // (every mode but the fused kernel leaves its carried partial sums behind)
-    int rc = sync_step_counter(e, s);
-    if (!rc) rc = run_persistent(e, par, s, false);
     if (rc) return rc;
   } else if (e->mode == 1) {
     e->ys_dirty = true;
@@ -1980,59 +1851,5 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n) {
   return NUTLS_OK;
 }
 
-int nutls_profile_persistent(nutls_handle* h, double* us, int n) {
-  if (!h || !us) return fail(NUTLS_ERR_ARG, "nutls_profile_persistent: null pointer");
-  Engine* e = &h->eng;
-  const int par = e->next_parity;
-  const int n_ops = static_cast<int>(e->plan[par].size());
-  if (n != n_ops) return fail(NUTLS_ERR_ARG, "nutls_profile_persistent: n must equal nutls_launches_per_step");
-  HIP_TRY(hipSetDevice(e->device));
-  int rc = sync_step_counter(e, e->stream);
-  e->ys_dirty = true;
-  if (!rc) rc = run_persistent(e, par, e->stream, true);
-  if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  std::vector<unsigned long long> t(n_ops + 1);
-  HIP_TRY(hipMemcpy(t.data(), e->dprof, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  int khz = 100000;
-  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device);
-  if (khz <= 0) khz = 100000;
-  for (int i = 0; i < n_ops; ++i) us[i] = static_cast<double>(t[i + 1] - t[i]) * 1000.0 / khz;
-  e->next_parity = 1 - par;
-  e->steps += 1;
-  if (const char* dump = getenv("NUTLS_SUBSTAMPS")) {   // debugging aid: phase breakdown of every conv layer
-    std::vector<unsigned long long> sub(static_cast<size_t>(n_ops) * 8);
-    HIP_TRY(hipMemcpy(sub.data(), e->dprof + n_ops + 1, sub.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (FILE* f = fopen(dump, "w")) {
-      unsigned long long ck[2];
-      (void)hipMemcpy(ck, e->dprof + static_cast<size_t>(n_ops) * 9 + 1, sizeof(ck), hipMemcpyDeviceToHost);
-      if (getenv("NUTLS_DBG_OP")) {
-        unsigned long long dg[128];
-        (void)hipMemcpy(dg, e->dprof + static_cast<size_t>(n_ops) * 9 + 3, sizeof(dg), hipMemcpyDeviceToHost);
-        fprintf(f, "# op %s cycle stamps (delta from wave 0 op start):\n", e->plan[par][atoi(getenv("NUTLS_DBG_OP"))].name.c_str());
-        for (int w = 0; w < 8; ++w) {
-          fprintf(f, "#   wave %d: start %lld dec %lld |", w, static_cast<long long>(dg[w * 16 + 15] - dg[15]), static_cast<long long>(dg[w * 16 + 14] - dg[15]));
-          for (int k = 0; k < 12; ++k) fprintf(f, " T%d %lld", k, static_cast<long long>(dg[w * 16 + k] - dg[15]));
-          fprintf(f, "\n");
-        }
-      }
-      fprintf(f, "# shader clock: %.0f MHz over the step (%llu cycles in %.1f us)\n",
-              static_cast<double>(ck[1] - ck[0]) / (static_cast<double>(t[n_ops] - t[0]) * 1000.0 / khz), ck[1] - ck[0],
-              static_cast<double>(t[n_ops] - t[0]) * 1000.0 / khz);
-      for (int i = 0; i < n_ops; ++i) {
-        if (e->plan[par][i].kind != Launch::CONV) continue;
-        fprintf(f, "%-24s", e->plan[par][i].name.c_str());
-        fprintf(f, " init %6.2f", static_cast<double>(sub[8 * i] - t[i]) * 1000.0 / khz);
-        const char* nm[5] = {"stage", "mfma", "pwrite", "epi", "bar"};
-        for (int k = 0; k < 5; ++k) fprintf(f, " %s %6.2f", nm[k], static_cast<double>(sub[8 * i + k + 1] - sub[8 * i + k]) * 1000.0 / khz);
-        fprintf(f, " | params %5.2f tohook %5.2f afterhook %5.2f", static_cast<double>(sub[8 * i + 6] - sub[8 * i + 1]) * 1000.0 / khz,
-                static_cast<double>(sub[8 * i + 7] - sub[8 * i + 6]) * 1000.0 / khz, static_cast<double>(sub[8 * i + 2] - sub[8 * i + 7]) * 1000.0 / khz);
-        fprintf(f, "\n");
-      }
-      fclose(f);
-    }
-  }
-  return NUTLS_OK;
-}
 
 }  // extern "C"

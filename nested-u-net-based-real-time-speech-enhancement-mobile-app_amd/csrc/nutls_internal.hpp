@@ -37,7 +37,6 @@ struct ConvParams {
   const float* src0;   // time tap 0 (previous frame) -- or the only input when TT == 1
   const float* src1;   // time tap 1 (current frame)
   const float* wpk;    // weights in MFMA fragment order (pack_conv_weights)
-  const float* wpk16;  // the same weights in 16x16x4 fragment order (pack_conv_weights16; persistent kernel, F_out <= 16)
   const float* wbf;    // int8 containers: the int8 weights widened to bf16 in 32x32x16 fragment order (pack_conv_weights_bf16), else null
   const float* wscale; // ... and their per-output-channel scale, packed channel order [32*NT]
   int use_bf16;        // launch the bf16-pipe kernel (block mode; needs wbf / wscale)
@@ -136,7 +135,7 @@ struct CtfaParams {
   float* y; int y_ld;            // out  [B,F,64]
   const float* ta_w1T; const float* ta_b1; const float* ta_w2T; const float* ta_b2;  // [64][16],[16],[16][64],[64]
   const float* fa_w1T; const float* fa_b1; const float* fa_w2T; const float* fa_b2;
-  const float* ta_w2; const float* fa_w2;   // [64][16] (output channel major): the persistent kernel reads a lane's 16 weights as 4 float4
+  const float* ta_w2; const float* fa_w2;   // [64][16] (output channel major), as stored
   int B, F;
   long long sstride;
 };
@@ -165,10 +164,7 @@ struct OutConvParams {   // 1x1 conv 64->1
 hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
 
 
-// ------------------------------------------------------------------ persistent kernel ---------
-// Device-resident launch plan: one entry per layer, consumed by nutls_stream_step_kernel
-// (megakernel.hip), which runs the whole frame step of one stream inside one workgroup.
-enum DevOp : int { DEV_OP_CONV = 0, DEV_OP_LSTM, DEV_OP_CTFA, DEV_OP_INLAYER, DEV_OP_OUTCONV, DEV_OP_DDB };
+// ------------------------------------------------------------------ streaming loop constants / front end ---------
 constexpr int NUTLS_DEV_BINS = 256;
 constexpr int NUTLS_FRAME_LEN = 512;    // interpreter_proposed.py:17
 constexpr int NUTLS_FRAME_STEP = 256;   // interpreter_proposed.py:18
@@ -176,81 +172,8 @@ constexpr int NUTLS_FRAME_STEP = 256;   // interpreter_proposed.py:18
 hipError_t launch_stft_hop(const float* pcm, float* tail, const float* win, const float* tw, float* mag, float* ph, int B, hipStream_t s);
 hipError_t launch_istft_hop(const float* est, const float* ph, const float* inv_win, const float* tw, float* ola, float* pcm_out,
                             int dc_edge, int B, hipStream_t s);
-// Host-precomputed execution plan of one conv-like layer inside the persistent kernel (all the
-// integer bookkeeping the kernel would otherwise redo per layer: LDS geometry, task split, hand-off).
-struct ConvPlan {
-  int cin, nt, stride, tt, kf, padl, epi_ln, g;      // copy of ConvShape
-  // LDS image of one phase (= one (time tap, 64-channel chunk)): rows x channels, padded pitch
-  int cc, cc4_shift, pitch, rows, vrows, n4p_shift, nch_shift, nph, phase_floats;
-  // task decomposition over the 16 waves
-  int merged;            // every phase resident at once (rounds == 1)
-  int rounds, RG, KS, gpk, gpc, PT, tiles, nt_shift;
-  int tw;                // 32x32 output tiles per wave: 2 (position-tile pairs sharing the weight fragments) when the
-                         // layer has more tiles than waves, else 1
-  int tasks, tasks_shift; // wave tasks per K slice = tiles / tw
-  int opitch, slot_floats, R, lpg;
-  // hand-off between consecutive layers
-  int staged_by_prev;    // the previous layer's epilogue already completed this layer's LDS image
-  int pf_phase0_ready;   // the previous layer already issued this layer's phase-0 loads into the prefetch registers
-  int s16;               // F_out <= 16: 16x16x4 MFMA tiles (16 positions x 16 channels), nt = channel tiles of 16
-  int hand_next;         // complete the next layer's LDS image in this layer's epilogue
-  // what the hand-off loads of the NEXT layer's image need (copied from its plan, so that this layer's
-  // descriptor alone drives them): source offsets (floats from the arena), row pitch, item bit fields, phases
-  const float* hx_src0; const float* hx_src1; int hx_ld, hx_cc4_shift, hx_n4p_shift, hx_nch_shift, hx_nhand;
-  int fwd_sel;           // 1 / 2: rows written to dst0 / dst1 are also forwarded into the next layer's image
-  int fwd_coff4;         // float4 offset of the forwarded block inside the next layer's input row
-  int fwd_rmul, fwd_radd; // rows this layer writes: row % fwd_rmul == fwd_radd (1, 0 = every row)
-  int pre_next_phase0;   // next is an un-merged two-tap conv: prefetch its phase 0 (previous-frame rows)
-};
-
-struct DevLaunch {
-  int op;   // DevOp
-  int ck;   // ConvKind when op == DEV_OP_CONV
-  int pad0, pad1;
-  union {
-    ConvParams conv;
-    LstmParams lstm;
-    CtfaParams ctfa;
-    InLayerParams inl;
-    OutConvParams outc;
-  };
-  ConvPlan cp;   // valid when op == DEV_OP_CONV
-  int ddb_index; // DEV_OP_DDB: index into the DdbParams table
-  // hand-off of a NON-conv op (LSTM / CTFA / input layer) to the conv layer that follows it
-  int nc_hand;       // 1: this op completes the next conv layer's LDS image
-  int nc_fwd_coff;   // channel offset (floats) of this op's output inside the next layer's input row
-};
-constexpr int MK_LDS_IN_FLOATS = 17920;   // staged input: >= 256 rows x 68, 129 row pairs x 132, 2 x 130 rows x 68
-constexpr int MK_STAGE_ITEMS = 4096;      // float4 a merged layer may stage through registers (8 per thread)
-constexpr int MK_NWAVES = 8;              // waves per workgroup of the persistent kernel (512 threads, 2 per SIMD)
-// Fills everything of ConvPlan except the hand-off fields.
-ConvPlan make_conv_plan(ConvKind k, const ConvParams& p);
-// Compact, LDS-resident form of the plan: 24 dwords per op, pointers as 32-bit float offsets from
-// the stream arena / the weight arena.  The persistent kernel copies the whole plan into LDS once
-// and every wave decodes the current and the next op from there (a handful of ds_reads) instead of
-// chasing ~12 scalar-cache misses per layer through the full-size structs.
-constexpr int MK_OP_WORDS = 24;
-struct CompactOp { uint32_t w[MK_OP_WORDS]; };
-constexpr uint32_t MK_NULL_OFF = 0xFFFFFFFFu;
-constexpr int MK_MAX_OPS = 168;
-struct StepArgs {            // kernel arguments of the persistent kernel
-  const CompactOp* plan;
-  int n_ops, B;
-  float* arena;              // stream-0 base of the per-stream arena
-  long long sstride;         // floats per stream
-  const float* wbase;        // weight arena
-  const float* io_in;        // [B,256]
-  float* io_out;             // [B,256]
-  unsigned long long* prof;  // nullable
-  const DdbParams* ddb;      // baseline variant: table of the 13 dilated-dense blocks (else null)
-  int dbg_op;                // profiling: op index whose inner cycle stamps are recorded (-1: none)
-};
-CompactOp encode_op(const DevLaunch& d, const float* arena, const float* wbase);
-hipError_t launch_stream_step(const StepArgs& a, int grid, hipStream_t s);
-hipError_t stream_step_set_attributes();
-
-// grid = number of workgroups (each loops over streams blockIdx.x, +grid, ...); prof (nullable)
-// receives wall_clock64() at every layer boundary of workgroup 0 (n_ops + 1 entries).
+// (Rounds 1-3 kept a third kernel family here: a persistent plan-interpreter kernel, megakernel.hip, execution mode 2 -- retired in
+//  round 4: the fused kernel is the one-launch path, the per-layer kernels below are the cross-check and the block mode.)
 
 // Packs OHWI conv weights [Cout][th][kw][Cin] into the order the MFMA loop streams them.
 //   perm[n'] = original output channel feeding packed channel n'
@@ -262,12 +185,6 @@ std::vector<float> pack_conv_weights(const HostTensor& w, const std::vector<int>
 // holds W[16 rt + (l & 15)][16 g + 4 (l >> 4) + j], j = 0..3.  Order [t][chunk][kf][g16][rt][lane][4].
 std::vector<float> pack_conv_weights_bf16(const HostTensor& w, const std::vector<int>& perm,
                                           const std::vector<std::pair<int, int>>& taps_per_t, int tt, int cin, int nt);
-std::vector<float> pack_conv_weights16(const HostTensor& w, const std::vector<int>& perm,
-                                       const std::vector<std::pair<int, int>>& taps_per_t,
-                                       int tt, int cin, int nt32);
-// Re-plans a layer with F_out <= 16 for 16x16x4 tiles (no-op otherwise).
-void apply_s16_plan(ConvPlan* c, const ConvParams& p);
-
 
 // ------------------------------------------------------------------ fused (statically scheduled) kernel ----
 // fused_step.hip (LSTM variant) / fused_base.hip (baseline variant) / fused_host.cpp: the frame step as one specialised

@@ -17,7 +17,7 @@ namespace nutls {
 namespace {
 constexpr int U = 21, G4 = 84;
 constexpr float kLog2e = 1.44269504088896341f;
-// (sigmoid / tanh of the scan: v_exp_f32 / v_rcp_f32 forms as in the persistent kernel -- the scan is a serial chain, IEEE expf / division are
+// (sigmoid / tanh of the scan: v_exp_f32 / v_rcp_f32 forms as in the fused kernel -- the scan is a serial chain, IEEE expf / division are
 // 10-30 instructions each)
 }  // namespace
 

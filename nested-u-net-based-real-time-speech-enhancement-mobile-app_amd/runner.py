@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "nutls_use_graph", "nutls_set_mode", "nutls_state_get", "nutls_state_set", "nutls_state_count",
     "nutls_state_info", "nutls_reset", "nutls_debug_get", "nutls_batch",
     "nutls_launches_per_step", "nutls_launch_info", "nutls_profile_step",
-    "nutls_profile_persistent", "nutls_last_error",
+    "nutls_last_error",
     "nutls_version",
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
     "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
@@ -86,7 +86,6 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_launch_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p),
                                       c.POINTER(c.c_double), c.POINTER(c.c_double)]
     lib.nutls_profile_step.argtypes = [c.c_void_p, fp, c.c_int]
-    lib.nutls_profile_persistent.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
     lib.nutls_enhance_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_enhance_hop_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
     lib.nutls_stft_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
@@ -133,15 +132,14 @@ def _fptr(a: np.ndarray):
 class NutlsEngine:
     """B streams, device-resident state.  ``step`` takes/returns ``[B,256]`` magnitudes."""
 
-    MODES = {"launches": 0, "graph": 1, "persistent": 2, "fused": 3}
+    MODES = {"launches": 0, "graph": 1, "fused": 3}
     VARIANTS = {"lstm": 0, "baseline": 1}
 
     def __init__(self, weights=None, batch: int = 1, device: int = 0, mode: Optional[str] = None, variant: str = "lstm",
                  streams_per_workgroup: Optional[int] = None):
         """``mode``: "fused" (the default when the container holds int8 conv kernels, as the reference's .tflite does:
-        one launch per frame, one workgroup per stream, every op its own specialised instruction stream), "persistent"
-        (the default for float containers: one launch per frame, one workgroup per stream interprets the
-        device-resident plan), "graph" (one kernel per layer, hipGraph replay) or "launches" (one kernel per layer).
+        one launch per frame, one workgroup per one / two / four streams, every op its own specialised instruction stream),
+        "graph" (one kernel per layer, hipGraph replay; the default for float containers) or "launches" (one kernel per layer).
         ``variant``: "lstm" (NUNet-TLS-LSTM, trained weights ship in weights/) or "baseline"
         (dilated-dense bottleneck; no trained weights exist -- pass a container, e.g.
         ``weights.write_blob(weights.synthetic_weights("baseline"), int8_convs=True)``).
@@ -178,11 +176,11 @@ class NutlsEngine:
         self.io_in_ptr, self.io_out_ptr = pin.value, pout.value
         if mode is not None:
             self.set_mode(mode)
-        else:       # library default: fused when the container holds int8 conv kernels, else persistent
+        else:       # fused when the container holds int8 conv kernels, else the per-layer kernels replayed as a hipGraph
             try:
                 self.set_mode("fused")
             except ValueError:
-                self.set_mode("persistent")
+                self.set_mode("graph")
 
     # -- lifetime --------------------------------------------------------------------------
     def close(self):
@@ -352,14 +350,6 @@ class NutlsEngine:
                                                           ctypes.byref(fl), ctypes.byref(by)))
             res.append({"layer": layer.value.decode(), "family": fam.value.decode(), "flops": fl.value, "bytes": by.value})
         return res
-
-    def profile_persistent(self) -> np.ndarray:
-        """One persistent-mode step with workgroup 0 time-stamping every layer boundary
-        (wall clock); returns microseconds per layer."""
-        us = np.zeros(self.launches_per_step, np.float64)
-        _check(self._lib, self._lib.nutls_profile_persistent(
-            self._h, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), us.size))
-        return us
 
     def fused_plan(self) -> List[Dict[str, object]]:
         """The fused kernel's static schedule: op name and algorithmic flops per stream."""

@@ -70,9 +70,9 @@ def test_causal32_history_follows_reset_and_mode_switches(clip):
     eng.set_ctfa_mode("frame")
     eng.set_ctfa_mode("causal32")
     with pytest.raises(ValueError):
-        eng.set_mode("persistent")          # the other kernels have no causal32 CTFA
+        eng.set_mode("graph")          # the per-layer kernels have no causal32 CTFA for streaming handles
     eng.set_ctfa_mode("frame")
-    eng.set_mode("persistent")
+    eng.set_mode("graph")
     with pytest.raises(ValueError):
         eng.set_ctfa_mode("causal32")
     eng.close()

@@ -104,25 +104,26 @@ def test_batch_256_synthetic_vs_oracle():
 
 
 def test_execution_modes_agree(clip):
-    """fused kernel == plan-interpreter kernel == per-layer hipGraph replay == per-layer plain launches (the
-    per-layer modes are bit-identical to each other; the one-launch kernels split K across waves -- and the fused
-    one applies the int8 weight scale after the sum instead of before it -- so they may differ from them in the
-    last bits only).  Default mode of the LSTM variant = fused."""
-    a, b, c, d = (NutlsEngine(batch=2, mode=m) for m in ("graph", "launches", "persistent", "fused"))
+    """fused kernel == per-layer hipGraph replay == per-layer plain launches (the per-layer modes are bit-identical to
+    each other; the fused kernel splits K across waves and applies the int8 weight scale after the sum instead of
+    before it, so it may differ from them in the last bits only).  Default mode of the LSTM variant = fused; the
+    plan-interpreter kernel of rounds 1-3 (mode 2, "persistent") is retired and says so."""
+    a, b, d = (NutlsEngine(batch=2, mode=m) for m in ("graph", "launches", "fused"))
     dflt = NutlsEngine(batch=2)
     assert dflt.mode == "fused"
+    with pytest.raises(ValueError):
+        dflt.set_mode("persistent")
+    assert dflt._lib.nutls_set_mode(dflt._h, 2) != 0 and b"retired" in dflt._lib.nutls_last_error()
     for i in range(5):
         x = clip["mags_in"][2 * i:2 * i + 2]
-        oa, ob, oc, od = a.step(x), b.step(x), c.step(x), d.step(x)
+        oa, ob, od = a.step(x), b.step(x), d.step(x)
         assert np.array_equal(oa, ob)
-        assert rms(oa, oc) < 1e-6
         assert rms(oa, od) < 1e-6
         assert np.array_equal(od, dflt.step(x))
     for base, shp in T.state_specs():
         name = base if len(shp) == 1 else base.format("prev")
-        np.testing.assert_allclose(a.state_get(name), c.state_get(name), rtol=1e-4, atol=1e-4, err_msg=name)
         np.testing.assert_allclose(a.state_get(name), d.state_get(name), rtol=1e-4, atol=1e-4, err_msg=name)
-    for e in (a, b, c, d, dflt):
+    for e in (a, b, d, dflt):
         e.close()
 
 
@@ -134,7 +135,7 @@ def test_fused_carried_sums_follow_mode_switches_and_state_edits(clip):
     continue exactly like a fused-only stream."""
     ref = NutlsEngine(batch=2, mode="fused")
     sw = NutlsEngine(batch=2, mode="fused")
-    modes = ["fused"] * 4 + ["persistent"] * 3 + ["fused"] * 3 + ["launches"] * 2 + ["fused"] * 4
+    modes = ["fused"] * 4 + ["graph"] * 3 + ["fused"] * 3 + ["launches"] * 2 + ["fused"] * 4
     for i, m in enumerate(modes):
         x = clip["mags_in"][2 * i:2 * i + 2]
         sw.set_mode(m)
@@ -153,11 +154,11 @@ def test_fused_carried_sums_follow_mode_switches_and_state_edits(clip):
 
 def test_fused_mode_needs_the_int8_container(clip):
     """The fused kernel keeps the conv kernels int8 on the device (what the reference's .tflite stores); a container
-    with float conv weights still works, on the plan-interpreter kernel, and says so when asked for mode 3."""
+    with float conv weights still works, on the per-layer kernels (hipGraph replay), and says so when asked for mode 3."""
     from nunet_amd.weights import load_weights, write_blob
     blob = write_blob(load_weights())                   # the same parameters, de-quantised to float32
     eng = NutlsEngine(blob, batch=1)
-    assert eng.mode == "persistent"
+    assert eng.mode == "graph"
     with pytest.raises(ValueError):
         eng.set_mode("fused")
     ref = NutlsEngine(batch=1)
@@ -264,7 +265,7 @@ def baseline_weights():
     return parse_blob(blob), blob
 
 
-@pytest.mark.parametrize("mode", ["fused", "persistent", "launches"])
+@pytest.mark.parametrize("mode", ["fused", "graph", "launches"])
 def test_baseline_variant_matches_oracle(baseline_weights, mode):
     w, blob = baseline_weights
     B, steps = 3, 40                                       # 40 > 32: the deepest history ring wraps
@@ -295,7 +296,7 @@ def test_baseline_mode_switches_keep_the_ring_position(baseline_weights):
     mags = synthetic_mags(B, steps, seed=78)
     eng = NutlsEngine(blob, batch=B, variant="baseline", mode="fused")
     ref = NutlsRef(w, batch=B, variant="baseline")
-    order = ["fused"] * 5 + ["persistent"] * 3 + ["fused"] * 7 + ["launches"] * 2 + ["fused"] * 20 + ["graph"] * 3 + ["fused"] * 5
+    order = ["fused"] * 5 + ["graph"] * 3 + ["fused"] * 7 + ["launches"] * 2 + ["fused"] * 20 + ["graph"] * 3 + ["fused"] * 5
     assert len(order) == steps
     for s, mode in enumerate(order):
         eng.set_mode(mode)

@@ -10,6 +10,6 @@ P=$R/nested-u-net-based-real-time-speech-enhancement-mobile-app_amd
 mkdir -p $P/build/exp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $FLAGS -c $P/csrc/fused_step.hip -o $P/build/exp/fused_step_$NAME.o
 OBJS=""
-for s in fused_step_prof fused_base fused_base_prof kernels megakernel stft offline weights fused_host engine; do OBJS="$OBJS $P/build/$s.o"; done
+for s in fused_step_g2 fused_step_g4 fused_step_prof fused_base fused_base_prof kernels stft offline weights fused_host engine; do OBJS="$OBJS $P/build/$s.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/build/exp/libnutls_$NAME.so $P/build/exp/fused_step_$NAME.o $OBJS
 echo built $P/build/exp/libnutls_$NAME.so

@@ -702,6 +702,15 @@ def build_for(variant, G, cls):
             q["g0"], q["ng"], q["gstride_b"] = missing[0], len(missing), gj["gstride_b"]
             q["fwdsub"] = 1
             parts.append(q)
+        # Packed plans: where the builder is not the op the one-stream plan stages this image behind (an instance boundary: another
+        # stream's short down-sampling / CTFA op, an in-conv that also hands rows over through HBM), the loads go out one op EARLIER
+        # (la 2, up to 8 carried float4 per thread) -- measured with la 1: msfe6_down_sampling 3.4 -> 8.9 us per instance, msfe6_de_ctfa
+        # 3.2 -> 8.0, msfe5_down_sampling 2.1 -> 7.5 (profiles/r04_g4_v1_timeline.json): the builder waits for HBM between its barriers
+        boundary = G > 1 and (bool(missing) or not feeds)
+        if boundary:
+            for q in parts:
+                if q["la"] == 1 and (q["ng"] * q["rows"] * q["c4s"] + 511) // 512 <= 8:
+                    q["la"] = 2          # (the drain rule below takes it back to 1 where the rows are not visible that early)
         J["parts"] = parts
     # the last sub-pixel conv instance(s) of the network feed the last CTFA
     for o in ops:

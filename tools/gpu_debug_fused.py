@@ -9,7 +9,7 @@ from nunet_amd import NutlsEngine, topology as T
 B = int(os.environ.get("B", "2"))
 frames = int(os.environ.get("FRAMES", "3"))
 clip = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "clip_4s.npz"))
-a = NutlsEngine(batch=B, mode="persistent")
+a = NutlsEngine(batch=B, mode="graph")
 b = NutlsEngine(batch=B, mode="fused")
 names = []
 for st in T.STAGES:

@@ -16,7 +16,7 @@ from oracle.nutls_ref import NutlsRef  # noqa: E402
 def main():
     nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     clip = np.load(os.path.join(ROOT, "tests/golden/clip_4s.npz"))
-    mode = sys.argv[2] if len(sys.argv) > 2 else "persistent"
+    mode = sys.argv[2] if len(sys.argv) > 2 else "graph"
     eng = NutlsEngine(batch=1, mode=mode)
     ref = NutlsRef(batch=1)
     print("launches per step:", eng.launches_per_step)

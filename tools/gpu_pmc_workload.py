@@ -7,6 +7,7 @@ weights = None
 if variant == "baseline":
     from nunet_amd.weights import synthetic_weights, write_blob
     weights = write_blob(synthetic_weights("baseline", seed=4321), int8_convs=True)
-eng = nunet_amd.NutlsEngine(weights, batch=256, mode=os.environ.get("NUTLS_MODE", "fused"), variant=variant)
-x = (0.25*np.abs(np.random.default_rng(0).standard_normal((256,256)))).astype(np.float32)
+B = int(os.environ.get("NUTLS_BATCH", "256"))          # (1024 / 2048: the packed plans)
+eng = nunet_amd.NutlsEngine(weights, batch=B, mode=os.environ.get("NUTLS_MODE", "fused"), variant=variant)
+x = (0.25*np.abs(np.random.default_rng(0).standard_normal((B,256)))).astype(np.float32)
 for _ in range(20): eng.step(x)

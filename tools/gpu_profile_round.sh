@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-KPAT=nutls_fused_step; [ "$VARIANT" = baseline ] && KPAT=nutls_fused_base_step; [ "$MODE" = persistent ] && KPAT=nutls_stream
+KPAT=nutls_fused_step; [ "$VARIANT" = baseline ] && KPAT=nutls_fused_base_step
 # 1. bench line (with the CPU baseline leg) and the timeline
 ( cd $R && timeout 900 python bench.py --mode $MODE --variant $VARIANT --profile-json $OUT/timeline.json > $OUT/bench.json 2> $OUT/bench.err )
 # 2. kernel trace of the same command
@@ -23,6 +23,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
 done
 } > $OUT/pmc.txt 2>&1
 python $R/tools/pmc_traffic.py $OUT/pmc.txt $MODE 256 $VARIANT > $OUT/pmc_traffic.json
-[ "$VARIANT" = lstm ] && ( cd $R && { timeout 300 python bench.py --no-cpu-baseline --variant baseline; timeout 300 python bench.py --no-cpu-baseline --batch 1024 --host-io --steps 100; timeout 300 python bench.py --no-cpu-baseline --batch 2048 --steps 50; timeout 300 python bench.py --no-cpu-baseline --frontend; timeout 300 python bench.py --no-cpu-baseline --mode persistent; timeout 300 python bench.py --no-cpu-baseline --offline 1024 --steps 20; } > $OUT/bench_other_configs.json 2>/dev/null )
+[ "$VARIANT" = lstm ] && ( cd $R && { timeout 300 python bench.py --no-cpu-baseline --variant baseline; timeout 300 python bench.py --no-cpu-baseline --batch 1024 --host-io --steps 100; timeout 300 python bench.py --no-cpu-baseline --batch 2048 --steps 50; timeout 300 python bench.py --no-cpu-baseline --frontend; timeout 300 python bench.py --no-cpu-baseline --offline 1024 --steps 20; } > $OUT/bench_other_configs.json 2>/dev/null )
 [ -f $OUT/bench_other_configs.json ] && cut -c1-330 $OUT/bench_other_configs.json
 tail -1 $OUT/bench.json | cut -c1-900; head -5 $OUT/kernel_stats.txt; cat $OUT/pmc.txt; cat $OUT/pmc_traffic.json
