@@ -917,11 +917,12 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* 
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
   if (int rc = ysum_refresh(e, par, s)) return rc;
   auto launch = base ? launch_fused_base_step : (e->fz_streams == 4 ? launch_fused_step_g4 : (e->fz_streams == 2 ? launch_fused_step_g2 : launch_fused_step));
-  FzTa ta{e->fz_ta_zero, e->fz_ta_zero + 64, 0, 0, 0, 0};
+  static const int skew = [] { const char* v = getenv("NUTLS_FUSED_SKEW"); return v ? atoi(v) : 0; }();
+  FzTa ta{e->fz_ta_zero, e->fz_ta_zero + 64, 0, 0, 0, 0, skew};
   if (e->ctfa_causal && e->fz_ta_ring) {
     const int slot = static_cast<int>(e->steps & 31);          // this frame's row of the history: the sums leave it out, the step overwrites it
     HIP_TRY(launch_ta_sum(e->fz_ta_ring, e->fz_ta_sum, slot, e->B, s));
-    ta = FzTa{e->fz_ta_sum, e->fz_ta_ring + slot * 64, 12 * 64, 64, 12 * 32 * 64, 32 * 64};
+    ta = FzTa{e->fz_ta_sum, e->fz_ta_ring + slot * 64, 12 * 64, 64, 12 * 32 * 64, 32 * 64, skew};
   }
   hipError_t err = launch(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
                           mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,

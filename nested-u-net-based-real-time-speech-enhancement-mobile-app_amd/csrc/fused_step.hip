@@ -112,7 +112,19 @@ struct Ctx {
   unsigned long long* prof;
   const DdbParams* ddb;        // baseline variant: the 13 dilated-dense blocks of this step's parity
   int stream, step;            // step: frame counter (position in the dilated-dense history rings)
+  int wave;                    // this wavefront's index in the workgroup (an SGPR for the whole kernel: see thread_id)
 };
+// Thread index of the 512-thread workgroup, rebuilt per op from the wave index (scalar) and the lane count: threadIdx.x itself is ONE
+// vector register that stays live from the kernel entry to the last op -- in the packed builds, which need all 256 registers, the
+// allocator spilled it and re-loaded it from scratch at the top of EVERY op, behind an `s_waitcnt vmcnt(0)` that also waited for every
+// prefetch in flight (fused_step_g4: one scratch_load per op, 185 us of 1 057 in the op prologues).
+// (The lane count is taken by a VOLATILE asm statement: the mbcnt builtins are pure, so the optimiser computed the thread index once at
+//  the kernel entry and kept -- spilled -- that instead.)
+__device__ __forceinline__ int thread_id(const Ctx& cx) {
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  return (cx.wave << 6) + lane;
+}
 // byte offset of stream slot g's arena slice relative to the workgroup's first stream (added to the 32-bit offset of a load / store)
 __device__ __forceinline__ unsigned gofs(const Ctx& cx, int g) {
   if constexpr (NSTREAMS == 1) return 0u;
@@ -312,7 +324,7 @@ constexpr int carry_w(int i) {
   if (i >= kNumOps) return 0;
   const OpD& d = kOps[i];
   if (d.type == T_CONV) return ring_sf(d);
-  if (d.type == T_LSTM) return lstm_s0(d) + 10 + 3 * (d.gs - 1);      // (packed plans: h (2 slots) and c (1) of every further stream)
+  if (d.type == T_LSTM) return lstm_s0(d) + 10 + 2 * (d.gs - 1);      // (packed plans: the h values (2 slots) of every further stream)
   if (d.type == T_CTFA) return d.gs * ctfa_ni(d) + 2;
 #if FZ_BASE
   if (d.type == T_DDB) {
@@ -544,20 +556,20 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
       });
       const int h0 = xs ? 0 : 6 * hs;
       sfor<6 * d.gs>([&](auto jj) {
-        constexpr int j = decltype(jj)::value % 6, gi = decltype(jj)::value / 6, SH = gi == 0 ? S0 : S0 + 10 + 3 * (gi - 1);
+        constexpr int j = decltype(jj)::value % 6, gi = decltype(jj)::value / 6, SH = gi == 0 ? S0 : S0 + 10 + 2 * (gi - 1);
         w[SH + j / 4][j % 4] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + h0 + j) * 4) + gofs(cx, d.g0 + gi));      // (h[21..23]: slot padding, zero)
       });
-      const int drow = tid < d.dout ? tid : d.dout - 1;
+      // (packed plans: gates and Dense outputs are dealt to threads as (stream, unit) / (stream, output): thread tid owns unit tid % 21 of
+      //  stream tid / 21 and output tid % dout -- of stream (tid + 512 pass) / dout)
+      const int drow = d.gs > 1 ? (tid & (d.dout - 1)) : (tid < d.dout ? tid : d.dout - 1);
       sfor<6>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
         w[S0 + 2 + j] = ldb(cx.wb, static_cast<unsigned>((WD + drow * 24 + 4 * j) * 4));
       });
-      const int u21 = tid < 21 ? tid : 20;
+      const int u21 = d.gs > 1 ? (tid < 21 * d.gs ? tid % 21 : 20) : (tid < 21 ? tid : 20);
+      const int g21 = d.gs > 1 ? (tid < 21 * d.gs ? tid / 21 : d.gs - 1) : 0;          // the stream slot whose cell state this thread updates
       w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((BIAS + 4 * u21) * 4));
-      sfor<d.gs>([&](auto gg) {
-        constexpr int gi = decltype(gg)::value, SC = gi == 0 ? S0 + 9 : S0 + 10 + 3 * (gi - 1) + 2;
-        w[SC][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4) + gofs(cx, d.g0 + gi));
-      });
+      w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4) + gofs(cx, d.g0 + g21));
 #if FZ_BASE
     } else if constexpr (d.type == T_DDB) {
       ddbz_prefetch<THREADS, d.x_cols / 2, d.din / d.x_cols>(ddbz_load_rec(cx.ddb + d.bidx), cx.stream, cx.step, tid, w);
@@ -1075,8 +1087,9 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
   // z = [x ; h] . [Wx ; Wh] + b with the gate columns interleaved (column 4 u + g: gate g of unit u), so that one float4
   // is (i, f, g, o) of a unit.  K is cut into 16 slices of x (threads (u, slice), tid < 336) and 4 slices of h
   // (tid 336..419); every operand arrived in the carry (slot map: [0, S0) weight rows of the thread's slice,
-  // [S0, S0+2) its h values, [S0+2, S0+8) the Dense row of output tid, S0+8 the unit's bias, S0+9 its cell state; packed plans:
-  // h and c of stream slot gi >= 1 at S0 + 10 + 3 (gi - 1) + {0, 1} and + 2 -- the weights serve every stream of the op).
+  // [S0, S0+2) its h values, [S0+2, S0+8) the Dense row of its output, S0+8 the unit's bias, S0+9 the cell state it updates; packed
+  // plans: the h values of stream slot gi >= 1 at S0 + 10 + 2 (gi - 1) + {0, 1} -- the weights serve every stream of the op; gates and
+  // Dense outputs are dealt to the threads as (stream, unit) / (stream, output)).
   constexpr OpD d = kOps[I];
   constexpr int KN = d.din / 16, XS = clog2(d.x_cols), S0 = lstm_s0(d), GS = d.gs;
   constexpr int PART = d.scr_b, HN = d.scr_b + 20 * 21 * 16, SGB = d.scr_gstride_b;      // stream slot gi: + gi * SGB
@@ -1097,7 +1110,7 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
   } else if (tid < 420) {
 #pragma unroll
     for (int gi = 0; gi < GS; ++gi) {
-      const int SH = gi == 0 ? S0 : S0 + 10 + 3 * (gi - 1);
+      const int SH = gi == 0 ? S0 : S0 + 10 + 2 * (gi - 1);
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -1108,26 +1121,29 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
     }
   }
   lds_barrier();
-  if (tid < 21) {
+  if (tid < 21 * GS) {          // thread (stream slot gi, unit uu): the unit's four gates
+    const int gi = GS > 1 ? tid / 21 : 0, uu = GS > 1 ? tid % 21 : tid;
+    f32x4 z = c.w[S0 + 8];
 #pragma unroll
-    for (int gi = 0; gi < GS; ++gi) {
-      f32x4 z = c.w[S0 + 8];
-#pragma unroll
-      for (int s2 = 0; s2 < 20; ++s2) z += lds4(PART + gi * SGB + (s2 * 21 + tid) * 16);
-      const float c_old = c.w[gi == 0 ? S0 + 9 : S0 + 10 + 3 * (gi - 1) + 2][0];
-      const float gi_ = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
-      const float c_new = gf * c_old + gi_ * gg;
-      const float h_new = go * fast_tanh(c_new);
-      const unsigned so = gofs(cx, d.g0 + gi);
-      stb1(cx.sbc, static_cast<unsigned>((d.c_off + tid) * 4) + so, c_new);
-      stb1(cx.sbc, static_cast<unsigned>((d.h_off + tid) * 4) + so, h_new);
-      lds1(HN + gi * SGB + tid * 4) = h_new;
-    }
+    for (int s2 = 0; s2 < 20; ++s2) z += lds4(PART + gi * SGB + (s2 * 21 + uu) * 16);
+    const float c_old = c.w[S0 + 9][0];
+    const float gi_ = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
+    const float c_new = gf * c_old + gi_ * gg;
+    const float h_new = go * fast_tanh(c_new);
+    const unsigned so = gofs(cx, d.g0 + gi);
+    stb1(cx.sbc, static_cast<unsigned>((d.c_off + uu) * 4) + so, c_new);
+    stb1(cx.sbc, static_cast<unsigned>((d.h_off + uu) * 4) + so, h_new);
+    lds1(HN + gi * SGB + uu * 4) = h_new;
   }
   lds_barrier();
-  if (tid < d.dout) {
+  // Dense: output n of stream gi by thread (gi * dout + n) mod 512 (its row of the Dense kernel arrived in the carry: 512 is a multiple
+  // of dout, so a thread's row is the same in every pass)
+  constexpr int DPASS = (d.dout * GS + THREADS - 1) / THREADS;
 #pragma unroll
-    for (int gi = 0; gi < GS; ++gi) {
+  for (int ps = 0; ps < DPASS; ++ps) {
+    const int idx = tid + THREADS * ps;
+    if (idx < d.dout * GS) {
+      const int gi = GS > 1 ? idx >> clog2(d.dout) : 0, n = GS > 1 ? idx & (d.dout - 1) : tid;
       float a = c.w[S0 + 2 + 5][1];          // bd
 #pragma unroll
       for (int q = 0; q < 5; ++q) {
@@ -1135,7 +1151,7 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
         a += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
       }
       a = fmaf(c.w[S0 + 2 + 5][0], lds1(HN + gi * SGB + 80), a);
-      const int f = tid >> XS, cc = tid & (d.x_cols - 1);
+      const int f = n >> XS, cc = n & (d.x_cols - 1);
       img_st1<d.x_fmt>(d.y_b + gi * d.x_gstride_b + f * d.x_pitch_b + cc * esz_of(d.x_fmt), d.x_plane_b, a);
       if constexpr (d.ldst_on) stb1(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4) + gofs(cx, d.g0 + gi), a);
     }
@@ -1278,7 +1294,7 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
 template <int I, bool PROF>
 __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
   constexpr OpD d = kOps[I];
-  int tid = threadIdx.x;
+  int tid = thread_id(cx);
   asm volatile("" : "+v"(tid));          // per-op thread id: nothing derived from it is hoisted across ops
   if (PROF && cx.prof && tid == 0) cx.prof[I] = wall_clock64();
   // Drain point of an LSTM / CTFA op: every wave waits for its own earlier HBM stores BEFORE it issues this op's loads (a
@@ -1417,6 +1433,7 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.ddb = a.ddb ? a.ddb + a.par * 13 : nullptr;
   cx.stream = stream;
   cx.step = a.step;
+  cx.wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   cx.sstride_b = static_cast<unsigned>(a.sstride * 4);
   cx.ta_sum = (gcb_t)(unsigned long long)a.ta.sum;
   cx.ta_ring = (gcb_t)(unsigned long long)a.ta.ring;
@@ -1442,14 +1459,19 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
         : "=&s"(t) : "s"(cx.ddb), "n"((13 * sizeof(DdbParams) + 63) / 64) : "memory");
   }
 #endif
+  if (a.ta.skew > 0) {
+    // start skew (FzTa::skew): every workgroup of a launch walks the same op sequence, so their staging bursts hit HBM together
+    const int n = (blockIdx.x & 3) * a.ta.skew;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   Carry<0> c0;
   {
-    int tid = threadIdx.x;
+    int tid = thread_id(cx);
     prefetch_w<1>(cx, tid, c0.w2, c0.prm2);
     prefetch_y<1>(cx, tid, c0.yp2);
   }
   run_from<0, PROF>(cx, c0);
-  if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();
+  if (PROF && cx.prof && thread_id(cx) == 0) cx.prof[kNumOps] = wall_clock64();
 }
 
 }  // namespace fz

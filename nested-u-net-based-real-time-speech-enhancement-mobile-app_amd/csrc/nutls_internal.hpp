@@ -194,7 +194,12 @@ std::vector<float> pack_conv_weights_bf16(const HostTensor& w, const std::vector
 // row of 64 zeros and `ring` one dump row, all strides 0 -- the branch sees TA / 32.  Causal32 mode (the offline model's `ctfa`,
 // proposed.py:125-160): `sum` [B][12][64] = the time attention summed over the 31 frames before this one (ta_sum_kernel, launched in
 // front of the step), `ring` points at this frame's row of the history [B][12][32][64] (row = frame mod 32); strides in floats.
-struct FzTa { const float* sum; float* ring; int sum_sstride, sum_gstride, ring_sstride, ring_gstride; };
+struct FzTa {
+  const float* sum; float* ring; int sum_sstride, sum_gstride, ring_sstride, ring_gstride;
+  // (rides along: start skew of the workgroups, in units of 64 clocks -- workgroup w sleeps (w mod 4) * skew before its first op, so that
+  //  the HBM bursts of the op sequence, which all workgroups of a launch walk in lock step, spread out; 0 = off.  NUTLS_FUSED_SKEW.)
+  int skew;
+};
 hipError_t launch_ta_sum(const float* ring, float* sum, int slot, int B, hipStream_t s);
 hipError_t launch_fused_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
                              unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);

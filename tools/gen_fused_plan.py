@@ -938,8 +938,9 @@ def main():
             print("fused plan (%s) is %s" % (plan_tag(variant, G), "current" if ok else "STALE"))
             stale = stale or not ok
             continue
-        open(inc_path(variant, G), "w").write(inc)
-        open(json_path(variant, G), "w").write(js)
+        for path, text in ((inc_path(variant, G), inc), (json_path(variant, G), js)):
+            if not (os.path.exists(path) and open(path).read() == text):          # (an unchanged plan keeps its mtime: no rebuild of its kernel)
+                open(path, "w").write(text)
         r32 = [o for o in ops if o["type"] == T_CONV and o["path"] == P_R32B]
         sbs = [o for o in ops if o["gs"] > 1]
         print("%-8s ops %d (conv %d, of which %d on 32x32 tiles; %d side by side), arena %d floats (parity stride %d), blob %d floats" % (
