@@ -83,7 +83,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         todo = [s for s in todo if s in only.split(",")]
     if not todo and not only and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(_obj(s)) for s in SOURCES):
         return LIB
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(lambda s: _run([hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", _obj(s)], verbose), todo))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in SOURCES], verbose)
     return LIB

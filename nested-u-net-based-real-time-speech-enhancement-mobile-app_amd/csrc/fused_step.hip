@@ -112,19 +112,7 @@ struct Ctx {
   unsigned long long* prof;
   const DdbParams* ddb;        // baseline variant: the 13 dilated-dense blocks of this step's parity
   int stream, step;            // step: frame counter (position in the dilated-dense history rings)
-  int wave;                    // this wavefront's index in the workgroup (an SGPR for the whole kernel: see thread_id)
 };
-// Thread index of the 512-thread workgroup, rebuilt per op from the wave index (scalar) and the lane count: threadIdx.x itself is ONE
-// vector register that stays live from the kernel entry to the last op -- in the packed builds, which need all 256 registers, the
-// allocator spilled it and re-loaded it from scratch at the top of EVERY op, behind an `s_waitcnt vmcnt(0)` that also waited for every
-// prefetch in flight (fused_step_g4: one scratch_load per op, 185 us of 1 057 in the op prologues).
-// (The lane count is taken by a VOLATILE asm statement: the mbcnt builtins are pure, so the optimiser computed the thread index once at
-//  the kernel entry and kept -- spilled -- that instead.)
-__device__ __forceinline__ int thread_id(const Ctx& cx) {
-  int lane;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-  return (cx.wave << 6) + lane;
-}
 // byte offset of stream slot g's arena slice relative to the workgroup's first stream (added to the 32-bit offset of a load / store)
 __device__ __forceinline__ unsigned gofs(const Ctx& cx, int g) {
   if constexpr (NSTREAMS == 1) return 0u;
@@ -1294,8 +1282,11 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
 template <int I, bool PROF>
 __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
   constexpr OpD d = kOps[I];
-  int tid = thread_id(cx);
+  int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));          // per-op thread id: nothing derived from it is hoisted across ops
+  // (Tried in round 4: the index rebuilt per op from a scalar wave index + a volatile lane count, so that threadIdx.x is not live across
+  //  all ops -- the 4-stream build spills it and re-loads it in every op prologue.  200 scratch loads fewer there, no change in its step
+  //  time; the one-stream kernel 1 % slower (0.3777 -> 0.3813 ms, four alternating runs on one box).  Dropped.)
   if (PROF && cx.prof && tid == 0) cx.prof[I] = wall_clock64();
   // Drain point of an LSTM / CTFA op: every wave waits for its own earlier HBM stores BEFORE it issues this op's loads (a
   // wait at the end of the op would also wait for those loads -- a full HBM round trip per drain point); the op's own
@@ -1433,7 +1424,6 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.ddb = a.ddb ? a.ddb + a.par * 13 : nullptr;
   cx.stream = stream;
   cx.step = a.step;
-  cx.wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   cx.sstride_b = static_cast<unsigned>(a.sstride * 4);
   cx.ta_sum = (gcb_t)(unsigned long long)a.ta.sum;
   cx.ta_ring = (gcb_t)(unsigned long long)a.ta.ring;
@@ -1466,12 +1456,12 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   }
   Carry<0> c0;
   {
-    int tid = thread_id(cx);
+    int tid = threadIdx.x;
     prefetch_w<1>(cx, tid, c0.w2, c0.prm2);
     prefetch_y<1>(cx, tid, c0.yp2);
   }
   run_from<0, PROF>(cx, c0);
-  if (PROF && cx.prof && thread_id(cx) == 0) cx.prof[kNumOps] = wall_clock64();
+  if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();
 }
 
 }  // namespace fz
