@@ -134,6 +134,65 @@ def cpu_baseline(budget_s=12.0):
     return rec
 
 
+def bench_offline(args, rank, world, local_rank):
+    """one utterance per GPU, blocks of T frames resident in HBM; value = frames/s of that utterance."""
+    import torch
+    import nunet_amd
+    T_ = args.offline
+    U = max(1, args.offline_utterances)      # independent utterances, one handle and one torch stream each
+    offs = [nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, pipeline=args.offline_chunks) for _ in range(U)]
+    pool = torch.from_numpy(synthetic_pool(T_, 4, 1234 + rank)).cuda()
+    outs = [torch.empty(T_, 256, device="cuda") for _ in range(U)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(U - 1)]
+    out = outs[0]
+
+    def blocks(n):
+        for s in range(n):
+            for u in range(U):
+                with torch.cuda.stream(streams[u]):
+                    offs[u].process_block_device(pool[(s + u) % 4], outs[u])
+
+    torch.cuda.synchronize()
+    blocks(max(2, args.warmup // 8))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    blocks(args.steps)
+    t_enq = time.perf_counter() - t0                  # the host's share: all launches of all blocks enqueued
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    if rank == 0:
+        # roofline of the block as a whole: the mode is many kernels (one per layer and chunk + 13 scans); its arithmetic is the step's
+        # (SURVEY 8(d): 147.9 MFLOP per frame), executed as three bf16 MFMAs per fp32 product -- priced against the fp32-MFMA peak (the
+        # arithmetic the results are equivalent to) with the executed-bf16 view beside it.  The layer-fused bytes per frame (SURVEY 8(d):
+        # 4 151 808 B) put the HBM bound far below: the mode is bound by its serial scans and its launch chain (DESIGN.md section 4).
+        fps = U * T_ * args.steps / dt
+        tfl = fps * FLOPS_PER_FRAME / 1e12
+        offline_roofline = {"kernel": "block mode (conv_bf16x3_kernel per layer and chunk + lstm_scan_kernel x 13 per chunk)", "bound": "mfma",
+                            "achieved": round(tfl, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_F32_MFMA_TFLOPS, 4),
+                            "traffic": None,
+                            "executed_bf16": {"tflops": round(3 * tfl, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(3 * tfl / PEAK_BF16_MFMA_TFLOPS, 4)},
+                            "hbm_layer_fused_gbps": round(fps * 4_151_808 / 1e9, 1),
+                            "scan_floor": "13 scans x T x 0.153 us per step = %.2f ms per block of %d frames (serial per stage; chunks overlap them)" % (13 * T_ * 0.153e-3, T_)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            b1 = _time_oracle(1, min(8, os.cpu_count() or 1), 6.0)      # one utterance on the CPU = the oracle frame by frame
+            cpu = {"value": round(b1[0], 1), "unit": "frames/s", "cores": min(8, os.cpu_count() or 1), "kind": "port",
+                   "sample": "oracle/nutls_ref.py, one stream frame by frame: %d frames in %.1f s" % (b1[1], b1[2])}
+        print(json.dumps({"metric": "STFT frames/sec (512-pt, 50% hop) through the NUNet-TLS frame step", "value": round(U * T_ * args.steps / dt, 1),
+                          "roofline": offline_roofline, "cpu_baseline": cpu,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup // 8),
+                          "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic magnitudes 0.25*|N(0,1)|, trained weights",
+                          "config": {"workload": "offline / block mode: %s, %d consecutive frames per call (SURVEY 8f.2)" % ("ONE utterance" if U == 1 else "%d utterances side by side" % U, T_),
+                                     "frames_per_block": T_, "utterances": U, "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames, 3 from 768)",
+                                     "mode": "per-layer kernels, frame index as stream index, single-wavefront LSTM scan, block pipeline"},
+                          "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6),
+                          "host_enqueue_ms_per_block": round(1e3 * t_enq / args.steps, 4)}))
+    for off in offs:
+        off.close()
+
+
 def other_config_records(local_rank):
     """The other BASELINE.json configurations, each timed over its own >= 100 ms window on this GPU, so that the driver's default
     run records them too (the headline `value` stays configs[1]): configs[2] (baseline variant, B = 256), the per-GPU size of

@@ -144,3 +144,12 @@ def test_bench_py_rank_plumbing_eight_ranks_gloo():
     col = j["collective"]
     assert col["ranks_reduced"] == 8 and col["backend"] == "gloo" and len(col["per_rank_frames_per_s"]) == 8
     assert "other_configs" not in j and "cpu_baseline" not in j          # N > 1: only the sharded workload is run
+
+
+def test_bench_py_defines_every_entry_its_main_dispatches_to():
+    """`bench.py --offline` / `other_configs` / `cpu_baseline` are separate functions that only a GPU run reaches: at least their names must
+    resolve (an edit once dropped `bench_offline` and only the GPU box would have noticed)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for fn in ("bench_offline", "other_config_records", "cpu_baseline", "kernel_report", "parity_check", "self_launch"):
+        assert callable(getattr(bench, fn)), fn
