@@ -516,7 +516,7 @@ def build_for(variant, G, cls):
                 d0 = (S_CUR, st_off(pair[3], 1) + 64, 128) if pair else None
                 d1 = None
             lst.append(conv_op("%s_spconv%d" % (p, j), "%s_spconv%d" % (p, j), K_DL, side, j, D, P, d0=d0, d1=d1, row_mul=2))
-        c = new_op(type=T_CTFA, name=p + "_ctfa", wkey=p, F=f0, e0_off=st_off(ct, 1), e0_ld=c1, drain=1, bidx=(6 + s if side else s))      # bidx: which of the 12 CTFAs (history ring of the causal32 mode)
+        c = new_op(type=T_CTFA, name=p + "_ctfa", wkey=p, F=f0, e0_off=st_off(ct, 1), e0_ld=c1, drain=0, bidx=(6 + s if side else s))      # bidx: which of the 12 CTFAs (history ring of the causal32 mode)
         c["cw_off"] = W.add(2 * (64 * 16 + 16 + 64 * 16 + 64) + 65, "ctfa", p)
         lst.append(c)
         return lst
@@ -786,6 +786,18 @@ def build_for(variant, G, cls):
                 return True
         return False
 
+    def ensure_drained(prod, issue):
+        """A drain point in [prod, issue)?  CTFA ops drain (at their start) only where a hand-off needs it -- none does in the one-stream
+        plans: the LSTM of the stage has drained by then, and a CTFA's drain is a full round trip of the stores the sub-pixel conv before it
+        just issued -- so: use what is there, else switch on the last CTFA in between, else (packed plans) let a conv op drain at its end."""
+        if drained_between(prod, issue):
+            return True
+        cand = [k for k in range(prod + 1, issue) if ops[k]["type"] == T_CTFA]
+        if cand:
+            ops[cand[-1]]["drain"] = 1
+            return True
+        return False
+
     def producers(src, off, ld, strm):
         return [q["idx"] for q in ops for d in (q["d0"], q["d1"]) if d and d[0] == src and d[1] == off and d[2] == ld and strm in streams(q)]
 
@@ -801,11 +813,11 @@ def build_for(variant, G, cls):
                 prods.append(pr[0])
             prod = max(prods)
             assert prod < b_idx or p.get("fwdsub"), (o["name"], p, prod, b_idx)
-            if p["la"] == 2 and not (prod < b_idx - 1 and drained_between(prod, b_idx - 1)):
+            if p["la"] == 2 and not (prod < b_idx - 1 and ensure_drained(prod, b_idx - 1)):
                 p["la"] = 1
             issue = b_idx - (p["la"] - 1)
             assert prod < issue, (o["name"], "a staged part's rows are produced by the op that would load them", p, prod, issue)
-            if not drained_between(prod, issue):
+            if not ensure_drained(prod, issue):
                 assert G > 1, (o["name"], p, prod, issue)
                 cand = [k for k in range(prod, issue) if ops[k]["type"] == T_CONV]          # (a conv op drains at its END: its own stores included)
                 assert cand, (o["name"], "no op to drain in between", ops[prod]["name"], ops[issue]["name"])
@@ -820,7 +832,7 @@ def build_for(variant, G, cls):
             prod = [k for k in producers(S_CUR, o["e0_off"], o["e0_ld"], strm) if k < o["idx"]]
             assert len(prod) == 1, (o["name"], "producer of the residual rows")
             issue = o["idx"] - 2
-            assert drained_between(prod[0], issue), (o["name"], "no drain point between", prod[0], "and the prefetch in", issue)
+            assert ensure_drained(prod[0], issue), (o["name"], "no drain point between", prod[0], "and the prefetch in", issue)
     return A, W, ops
 
 
