@@ -136,3 +136,54 @@ def test_packed_carried_sums_follow_state_edits(clip, G):
         assert rms(a.step(x(i)), b.step(x(i))) < 1e-6, i          # (the rebuilt sums are added up in another order than the kernel's)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_state_moves_between_plans(clip, G):
+    """The ABI's state tensors mean the same on every plan: an utterance started on a one-stream handle continues on a packed handle after
+    all 130 tensors were copied over (nutls_state_get / nutls_state_set; the packed handle rebuilds its carried partial sums, whose
+    layout is the plan's own), and back."""
+    frames = clip["mags_in"]
+    B = 4
+    x = lambda i: np.stack([frames[(i + 23 * s) % 249] for s in range(B)])
+    ref = NutlsEngine(batch=B, streams_per_workgroup=1)
+    a = NutlsEngine(batch=B, streams_per_workgroup=1)
+    b = NutlsEngine(batch=B, streams_per_workgroup=G)
+    for i in range(6):
+        ref.step(x(i))
+        a.step(x(i))
+    for base, shp in T.state_specs():
+        name = base if len(shp) == 1 else base.format("prev")
+        b.state_set(name, a.state_get(name))
+    for i in range(6, 12):
+        assert rms(ref.step(x(i)), b.step(x(i))) < 2e-6, i
+    for base, shp in T.state_specs():
+        name = base if len(shp) == 1 else base.format("prev")
+        a.state_set(name, b.state_get(name))
+    for i in range(12, 16):
+        assert rms(ref.step(x(i)), a.step(x(i))) < 2e-6, i
+    for e in (ref, a, b):
+        e.close()
+
+
+def test_packed_extreme_inputs_and_full_clip(clip):
+    """Silence, a single huge bin, denormal-scale noise and the real clip side by side in ONE workgroup of the 4-stream plan: LayerNorm's
+    eps path and PReLU's negative side next to ordinary data; the clip's 249 frames in slot 3 against the goldens."""
+    B = 4
+    eng, ref = NutlsEngine(batch=B, streams_per_workgroup=4), NutlsRef(batch=B)
+    assert eng.streams_per_workgroup == 4
+    outs = []
+    for i in range(249):
+        x = np.zeros((B, 256), np.float32)
+        x[1, 17] = 1.0e4
+        x[2] = 1e-20
+        x[3] = clip["mags_in"][i]
+        out = eng.step(x)
+        assert np.isfinite(out).all()
+        outs.append(out[3])
+        if i < 3:
+            want = ref.step(x).numpy()
+            scale = max(1.0, float(np.abs(want).max()))
+            assert rms(out, want) < 1e-4 * scale
+    assert rms(np.stack(outs), clip["mags_out"]) < TIGHT_RMS
+    eng.close()
