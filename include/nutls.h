@@ -171,10 +171,11 @@ int nutls_reset(nutls_handle* h, int stream_idx);
 int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
 
 int nutls_batch(nutls_handle* h);
-/* Streams one workgroup of the fused kernel steps (mode 3): 1, or -- handles of at least two streams per CU, LSTM variant -- 2: the packed
- * plan (csrc/fused_step_g2.hip: the layers whose LDS images fit twice run both streams side by side on one position axis, sharing
- * the weight fetch and conversion).  A stream's results do not depend on its slot or partner.  NUTLS_FUSED_STREAMS=1 at creation
- * keeps the one-stream plan.  No reference counterpart (the reference steps one stream: interpreter_proposed.py:215). */
+/* Streams one workgroup of the fused kernel steps (mode 3): 1, or -- LSTM variant, more streams than CUs -- 2 or 4: a packed plan
+ * (csrc/fused_step_g2.hip / _g4.hip: the layers whose LDS images fit that often run the streams side by side on one position axis, sharing
+ * the weight fetch and conversion; chosen by nutls_create so that rounds of workgroups x step time of the plan is smallest: 256 streams 1,
+ * 512 2, 1024 and 2048 4).  A stream's results do not depend on its slot or partners.  NUTLS_FUSED_STREAMS=1 at creation keeps the
+ * one-stream plan.  No reference counterpart (the reference steps one stream: interpreter_proposed.py:215). */
 int nutls_streams_per_workgroup(nutls_handle* h);
 int nutls_launches_per_step(nutls_handle* h);
 

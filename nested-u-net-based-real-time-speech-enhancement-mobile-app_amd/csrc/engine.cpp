@@ -850,10 +850,23 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   for (int i = 0; ok && i < fused_num_scratch(v) && i < 11; ++i) ok = scratch[i] - e->arena == fused_scratch_off(v, i);
   if (ok && v == NUTLS_VARIANT_BASELINE) ok = e->d_ddb != nullptr && e->ddbs.size() == 26;
   if (!ok) return fail(NUTLS_ERR_ARG, "fused plan (tools/gen_fused_plan.py) does not match the engine's arena layout");
-  // Which plan: one stream per workgroup, or -- once there are at least two streams per CU -- the packed plan (two streams per workgroup:
-  // one weight fetch / conversion and one latency chain for both in the layers whose images fit LDS twice).  NUTLS_FUSED_STREAMS=1 / 2
-  // overrides (2 needs an even stream count).
-  int streams = (e->B >= 4 * e->n_cu && e->B % 4 == 0) ? 4 : ((e->B >= 2 * e->n_cu && e->B % 2 == 0) ? 2 : 1);
+  // Which plan: one stream per workgroup, or a packed plan (two / four streams per workgroup: one weight fetch / conversion and one latency
+  // chain for all of them in the layers whose images fit LDS that often).  NUTLS_FUSED_STREAMS=1 / 2 / 4 overrides (the stream count must be
+  // a multiple).
+  // Choice by a two-number cost model: a step takes ceil(workgroups / CUs) rounds of the plan's step time, and those are 1 : 1.58 : 2.82 for
+  // 1 / 2 / 4 streams per workgroup (0.37 / 0.585 / 1.04 ms, profiles/r04_*).  256 streams: one per workgroup (one round); 300 .. 512: two
+  // (one round instead of two); 768: four (192 workgroups, one round); 1024, 2048: four; 1536: two (three rounds of 0.585 ms < two of 1.04).
+  int streams = 1;
+  {
+    const double t_plan[5] = {0.0, 1.0, 1.58, 0.0, 2.82};
+    double best = 0.0;
+    for (int g : {1, 2, 4}) {
+      if (e->B % g != 0 || !fused_has_plan(v, g)) continue;
+      const int wgs = e->B / g, rounds = (wgs + e->n_cu - 1) / e->n_cu;
+      const double t = rounds * t_plan[g];
+      if (best == 0.0 || t < best * 0.98) { best = t; streams = g; }      // (ties and near-ties: the smaller group)
+    }
+  }
   if (const char* ev = getenv("NUTLS_FUSED_STREAMS")) streams = atoi(ev);
   if (streams < 1 || !fused_has_plan(v, streams) || e->B % streams != 0) streams = 1;
   if (streams > 1 && (fused_plan_arena_floats(v, streams) != fused_arena_floats(v) || fused_plan_parity_stride(v, streams) != fused_parity_stride(v) ||

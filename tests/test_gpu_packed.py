@@ -27,8 +27,11 @@ def clip():
 
 
 def test_plan_choice_follows_the_stream_count():
-    """>= 2 streams per CU: the packed plan by default; fewer, an odd count, or NUTLS_FUSED_STREAMS=1: one stream per workgroup."""
-    for B, want in ((256, 1), (511, 1), (512, 2), (1022, 2), (1024, 4), (2048, 4)):
+    """More streams than CUs: a packed plan by default, chosen by rounds x step time; an odd count or NUTLS_FUSED_STREAMS=1: one stream per
+    workgroup."""
+    # (the choice minimises rounds x step time of the plan: 300 streams are one round of pairs instead of two rounds of single streams,
+    #  768 one round of 192 four-stream workgroups, 1536 three rounds of pairs rather than two of fours)
+    for B, want in ((1, 1), (256, 1), (300, 2), (511, 1), (512, 2), (768, 4), (1022, 2), (1024, 4), (1536, 2), (2048, 4)):
         eng = NutlsEngine(batch=B)
         assert eng.streams_per_workgroup == want, (B, eng.streams_per_workgroup)
         eng.close()
