@@ -219,3 +219,72 @@ def test_packed_plans_cover_every_layer_for_every_stream(G):
                     assert any(ops[k]["drain"] and (k > prod or ops[k]["type"] == 1) for k in range(prod, issue)), (ops[o["nxt"]]["name"], p)
         if o["type"] == 2:          # LSTM: side by side, its scratch in the middle of LDS
             assert o["gs"] == G and o["scr_b"] + G * o["scr_gstride_b"] <= o["xcopy_b"] and o["xcopy_b"] + G * 1024 <= ops[o["idx"] - 1]["ex_b"]
+
+
+def _input_rows(o):
+    """rows x channels of one time tap of a conv op's input (per stream): what its LDS image must hold before its MFMA loop starts"""
+    kind, P = o["kind"], o["P"]
+    return {0: P, 1: 2 * P, 2: P, 3: 2 * P, 4: P}[kind], o["cin"]
+
+
+@pytest.mark.parametrize("tag", ["lstm", "base", "lstm_g2", "lstm_g4"])
+def test_every_image_is_completed_exactly_once(tag):
+    """Data flow of a plan, re-derived from its records alone: for every conv op instance, every stream it runs and every time tap, each
+    (input row, 32-channel block) of its LDS image is written exactly once before the op starts -- by the rows the op before it forwards
+    from registers (Fwd, for the streams in its mask), by the LSTM / dilated-dense op in between, or by a staged part (HBM -> LDS) -- with
+    no gaps and no overlaps, inside the stream's own sub-image; and a part that reads this frame's rows reads what an EARLIER op of the
+    same stream wrote to exactly that tensor."""
+    plan = json.load(open(os.path.join(GOLDEN, "fused_plan_%s.json" % tag)))
+    ops = plan["ops"]
+    builder = {o["nxt"]: o for o in ops if o["nxt"] >= 0}
+    n_checked = 0
+    for J in ops:
+        if J["type"] != 1:
+            continue
+        g = J["img"]
+        esz = 2 if g["fmt"] else 4
+        rows, cin = _input_rows(J)
+        cover = {}          # (stream, tap, row, channel block of 32) -> how often written
+
+        def put(stream, lds_b, row0, nrows, nch, what):
+            sub = lds_b - (stream - J["g0"]) * g["gstride_b"]
+            tap = 1 if (g["taps"] == 2 and sub >= g["tap_b"]) else 0
+            ch0 = (sub - tap * g["tap_b"]) // esz
+            assert 0 <= ch0 and ch0 + nch <= cin and ch0 % 32 == 0 and nch % 32 == 0, (J["name"], what, ch0, nch)
+            for r in range(nrows):
+                lr = row0 + r - g["row0"]          # input row (the image's first rows are the halo)
+                assert 0 <= lr < rows, (J["name"], what, lr, rows)
+                for cb in range(ch0 // 32, (ch0 + nch) // 32):
+                    cover[(stream, tap, lr, cb)] = cover.get((stream, tap, lr, cb), 0) + 1
+
+        B = builder.get(J["idx"])
+        if B is not None and B["fwd"] and B["type"] in (0, 1):
+            f = B["fwd"]
+            out_rows, out_ch = (256, 64) if B["type"] == 0 else (B["P"] * B["R"], B["gc"])
+            for i in range(B["gs"]):
+                if (f["mask"] >> i) & 1:
+                    s = B["g0"] + i
+                    assert J["g0"] <= s < J["g0"] + J["gs"]
+                    put(s, f["base_b"] + i * f["gstride_b"] + (B["g0"] - J["g0"]) * 0, f["row0"], out_rows, out_ch, "fwd of " + B["name"])
+        prev = ops[J["idx"] - 1]
+        if prev["type"] in (2, 4):          # LSTM / dilated-dense op: writes [F][x_cols] at channels 0 .. x_cols - 1 of the current tap
+            F = prev["dout"] // prev["x_cols"]
+            for i in range(prev["gs"]):
+                put(prev["g0"] + i, prev["y_b"] - g["row0"] * g["pitch_b"] + i * prev["x_gstride_b"] + (prev["g0"] - J["g0"]) * g["gstride_b"],
+                    g["row0"], F, prev["x_cols"], prev["name"])
+        for p in J["parts"]:
+            for i in range(p["ng"]):
+                s = p["g0"] + i
+                put(s, p["lds_b"] + i * p["gstride_b"], p["row0"], p["rows"], 4 * p["c4s"], "part")
+                if p["src"] != 0:          # this frame's rows: an earlier op of this stream wrote exactly that tensor
+                    prod = ops[p["producer"]]
+                    assert prod["idx"] < J["idx"] and any(d and d[0] == p["src"] and d[1] == p["off"] and d[2] == p["ld"] for d in (prod["d0"], prod["d1"]))
+        want = {(s, t, r, cb) for s in range(J["g0"], J["g0"] + J["gs"]) for t in range(g["taps"]) for r in range(rows) for cb in range(cin // 32)}
+        if J["cin"] < 32:
+            continue
+        missing = want - set(cover)
+        extra = {k: v for k, v in cover.items() if v != 1 or k not in want}
+        assert not missing, (tag, J["name"], J["g0"], sorted(missing)[:4], len(missing))
+        assert not extra, (tag, J["name"], J["g0"], list(extra.items())[:4])
+        n_checked += 1
+    assert n_checked >= 128
