@@ -56,6 +56,11 @@ enum {
 int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, int device,
                  nutls_handle** out);
 
+/* nutls_create with the fused kernel's plan chosen by the caller: streams_per_workgroup = 0 (the library's choice, = nutls_create), 1, 2 or
+ * 4 (see nutls_streams_per_workgroup; a count the batch is not a multiple of, or a variant without such a plan, falls back to 1). */
+int nutls_create_plan(const void* weights, size_t n_bytes, int variant, int batch, int device, int streams_per_workgroup,
+                      nutls_handle** out);
+
 /* Replaces: del interpreter. */
 int nutls_destroy(nutls_handle* h);
 

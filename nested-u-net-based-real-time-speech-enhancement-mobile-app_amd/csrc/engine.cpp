@@ -150,6 +150,7 @@ struct Engine {
   int mode = 0;          // 0 plain per-layer launches, 1 per-layer hipGraph replay, 3 fused kernel (statically scheduled; both variants);
                          // (2 was the plan-interpreter kernel of rounds 1-3, retired)
   float* fz_blob = nullptr;              // weight blob of the fused kernel (plan order)
+  int fz_streams_req = 0;                // nutls_create_plan: the caller's choice of plan (0: the library's)
   int fz_streams = 1;                    // streams per workgroup of the fused plan this handle runs (packed plans: 2 from 512 streams on, 4 from 1024)
   // CTFA frequency branch of the fused kernel (nutls_internal.hpp FzTa): fz_ta_zero = 64 zeros + a dump row (frame mode); causal32 mode of a
   // streaming handle (nutls_set_ctfa_mode): history ring [B][12][32][64] and the per-step sums [B][12][64]
@@ -868,6 +869,7 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
     }
   }
   if (const char* ev = getenv("NUTLS_FUSED_STREAMS")) streams = atoi(ev);
+  if (e->fz_streams_req > 0) streams = e->fz_streams_req;          // (nutls_create_plan: the caller's choice wins)
   if (streams < 1 || !fused_has_plan(v, streams) || e->B % streams != 0) streams = 1;
   if (streams > 1 && (fused_plan_arena_floats(v, streams) != fused_arena_floats(v) || fused_plan_parity_stride(v, streams) != fused_parity_stride(v) ||
                       fused_plan_ys_off(v, streams) != fused_ys_off(v) || fused_plan_ys_block(v, streams) != fused_ys_block(v)))
@@ -1033,12 +1035,13 @@ const char* nutls_version(void) { return "nutls-hip 0.4 (gfx950; fused step: fp3
 
 static int build_offline_plan(Engine* e);
 
-static int create_body(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out);
+static int create_body(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out, int streams_req);
 
 // (nothing may be thrown through the C ABI: a malformed container or an allocation failure is an error code)
-static int create_common(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out) {
+static int create_common(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out,
+                         int streams_req = 0) {
   try {
-    return create_body(weights, n_bytes, variant, batch, device, offline_frames, out);
+    return create_body(weights, n_bytes, variant, batch, device, offline_frames, out, streams_req);
   } catch (const std::bad_alloc&) {
     return fail(NUTLS_ERR_WEIGHTS, "nutls_create: out of host memory (malformed weight container?)");
   } catch (const std::exception& ex) {
@@ -1046,7 +1049,7 @@ static int create_common(const void* weights, size_t n_bytes, int variant, int b
   }
 }
 
-static int create_body(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out) {
+static int create_body(const void* weights, size_t n_bytes, int variant, int batch, int device, int offline_frames, nutls_handle** out, int streams_req) {
   if (!weights || !out || batch < 1) return fail(NUTLS_ERR_ARG, "nutls_create: null pointer or batch < 1");
   if (variant != NUTLS_VARIANT_LSTM && variant != NUTLS_VARIANT_BASELINE) return fail(NUTLS_ERR_ARG, "nutls_create: unknown variant");
   int ndev = 0;
@@ -1098,6 +1101,7 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
     return fail(NUTLS_ERR_ARG, std::string("plan: ") + ex.what());
   }
   if (rc) return rc;
+  e->fz_streams_req = streams_req;
   e->n_cu = prop.multiProcessorCount;
   if (offline_frames == 0) {
     try {
@@ -1125,6 +1129,11 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
 
 int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, int device, nutls_handle** out) {
   return create_common(weights, n_bytes, variant, batch, device, 0, out);
+}
+
+int nutls_create_plan(const void* weights, size_t n_bytes, int variant, int batch, int device, int streams_per_workgroup, nutls_handle** out) {
+  if (streams_per_workgroup < 0) return fail(NUTLS_ERR_ARG, "nutls_create_plan: streams_per_workgroup must be 0 (library's choice), 1, 2 or 4");
+  return create_common(weights, n_bytes, variant, batch, device, 0, out, streams_per_workgroup);
 }
 
 int nutls_create_offline(const void* weights, size_t n_bytes, int max_frames, int device, nutls_handle** out) {

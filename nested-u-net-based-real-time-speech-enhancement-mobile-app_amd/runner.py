@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
     "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all", "nutls_offline_set_ctfa_mode",
     "nutls_offline_set_pipeline", "nutls_streams_per_workgroup", "nutls_fused_plan_blob_floats", "nutls_fused_pack_blob_plan",
-    "nutls_set_ctfa_mode", "nutls_fused_plan_num_ops", "nutls_fused_plan_op_info",
+    "nutls_set_ctfa_mode", "nutls_fused_plan_num_ops", "nutls_fused_plan_op_info", "nutls_create_plan",
 )
 
 
@@ -67,6 +67,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
                            % (p, ver, ABI_VERSION_PREFIX))
     fp = c.POINTER(c.c_float)
     lib.nutls_create.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
+    lib.nutls_create_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
     lib.nutls_destroy.argtypes = [c.c_void_p]
     lib.nutls_step.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     lib.nutls_step_host.argtypes = [c.c_void_p, fp, fp]
@@ -144,8 +145,7 @@ class NutlsEngine:
         (dilated-dense bottleneck; no trained weights exist -- pass a container, e.g.
         ``weights.write_blob(weights.synthetic_weights("baseline"), int8_convs=True)``).
         ``streams_per_workgroup``: which plan the fused kernel runs -- None: the library's choice (the packed plan, two streams per
-        workgroup, from two streams per CU on), 1 / 2: that plan (2 needs an even ``batch``); it is read by ``nutls_create`` from
-        the environment variable NUTLS_FUSED_STREAMS, which this sets for the duration of the call."""
+        workgroup when there are more streams than CUs), 1 / 2 / 4: that plan (``nutls_create_plan``; the batch must be a multiple)."""
         self._lib = load_library()
         if variant not in self.VARIANTS:
             raise ValueError("variant must be one of %s" % sorted(self.VARIANTS))
@@ -155,18 +155,8 @@ class NutlsEngine:
         blob = read_blob(weights if weights is not None else DEFAULT_WEIGHTS)
         self._h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(blob, len(blob))
-        saved = os.environ.get("NUTLS_FUSED_STREAMS")
-        if streams_per_workgroup is not None:
-            os.environ["NUTLS_FUSED_STREAMS"] = str(int(streams_per_workgroup))
-        try:
-            _check(self._lib, self._lib.nutls_create(buf, len(blob), self.VARIANTS[variant], int(batch), int(device),
-                                                     ctypes.byref(self._h)))
-        finally:
-            if streams_per_workgroup is not None:
-                if saved is None:
-                    os.environ.pop("NUTLS_FUSED_STREAMS", None)
-                else:
-                    os.environ["NUTLS_FUSED_STREAMS"] = saved
+        _check(self._lib, self._lib.nutls_create_plan(buf, len(blob), self.VARIANTS[variant], int(batch), int(device),
+                                                      int(streams_per_workgroup or 0), ctypes.byref(self._h)))
         # fp32 bytes of the container's tensors: what the modes that de-quantise on load (0-2) keep on the device
         self._fp32_weight_bytes = 4 * sum(int(np.asarray(a).size) for a in parse_blob(blob).values())
         self.batch = int(batch)
