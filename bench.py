@@ -300,6 +300,9 @@ def main():
                     help="offline / block mode: ONE utterance, a step = one block of T consecutive frames (frames/s of that utterance)")
     ap.add_argument("--offline-chunks", type=int, default=0, help="offline mode: chunks of the block pipeline (0 = library default)")
     ap.add_argument("--offline-utterances", type=int, default=1, help="offline mode: independent utterances processed side by side, one handle and stream each (value = their total frames/s)")
+    ap.add_argument("--ctfa-mode", default="frame", choices=["frame", "causal32"],
+                    help="causal32: the offline model's 32-frame causal CTFA in the streaming kernel (per-stream attention history kept by the library: "
+                         "BASELINE configs[4]'s 'persistent CTFA state'); default: what the reference's streaming graph computes (TA / 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` records of the default line (configs[2], [3]-size, [4])")
     ap.add_argument("--profile-json", default="", help="write the per-op timeline here")
@@ -350,6 +353,8 @@ def main():
             # random-init weights (none are trained), stored as the reference's export stores them: conv kernels int8
             weights = write_blob(synthetic_weights("baseline", seed=4321), int8_convs=True)
         eng = nunet_amd.NutlsEngine(weights, batch=B, device=local_rank, mode=mode, variant=args.variant)
+        if args.ctfa_mode != "frame":
+            eng.set_ctfa_mode(args.ctfa_mode)
     pool_host = synthetic_pool(B, 8, 1234 + lo)
     pool = torch.from_numpy(pool_host).to(device)            # inputs resident in HBM
     out = torch.empty(B, 256, device=device)
@@ -413,7 +418,7 @@ def main():
                        ("NUNet-TLS dilated-dense baseline frame step, synthetic weights seed 4321, batch=%d streams per GPU (BASELINE configs[2])" % args.batch),
                        "variant": args.variant, "host_io": bool(args.host_io), "stft_istft_on_gpu": bool(args.frontend),
                        "streams_per_gpu": args.batch, "total_streams": total_frames // args.steps, "parallelism": "stream-sharded x%d" % world,
-                       "mode": mode, "streams_per_workgroup": getattr(eng, "streams_per_workgroup", 1)},
+                       "mode": mode, "streams_per_workgroup": getattr(eng, "streams_per_workgroup", 1), "ctfa_mode": args.ctfa_mode},
             "rtf_per_stream": round(1e3 * max_elapsed / args.steps / 16.0, 5),
             # whole-job rate x SURVEY 8(d)'s 147.93 MFLOP per frame (the graph as lowered: the CTFA frequency branch as a conv over
             # all F bins); `roofline.achieved` uses the plan's own count (144.0 M: those 1x1s at their true size) -- both stated
@@ -431,12 +436,12 @@ def main():
         if args.host_io:
             line["step_latency_ms"] = line["ms_per_step"]
             line["real_time_budget_ms"] = 16.0
-        if not selftest and not args.no_cpu_baseline and args.variant == "lstm":
+        if not selftest and not args.no_cpu_baseline and args.variant == "lstm" and args.ctfa_mode == "frame":
             import nunet_amd
             line["cpu_baseline"] = cpu_baseline()
             line["parity_rms_vs_oracle"] = parity_check(nunet_amd.NutlsEngine, pool_host)
         default_run = (not selftest and world == 1 and mode == "fused" and args.variant == "lstm" and args.batch == 256
-                       and not (args.host_io or args.frontend))
+                       and not (args.host_io or args.frontend) and args.ctfa_mode == "frame")
         if default_run and not args.no_other_configs:
             eng.close()
             line["other_configs"] = other_config_records(local_rank)
