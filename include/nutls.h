@@ -57,7 +57,8 @@ int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, in
                  nutls_handle** out);
 
 /* nutls_create with the fused kernel's plan chosen by the caller: streams_per_workgroup = 0 (the library's choice, = nutls_create), 1, 2 or
- * 4 (see nutls_streams_per_workgroup; a count the batch is not a multiple of, or a variant without such a plan, falls back to 1). */
+ * 4 (see nutls_streams_per_workgroup).  An explicit count the batch is not a multiple of, or one the variant has no plan for (3, 8, ...;
+ * the baseline variant has the one-stream plan only) is NUTLS_ERR_ARG -- an explicit request never silently becomes another plan. */
 int nutls_create_plan(const void* weights, size_t n_bytes, int variant, int batch, int device, int streams_per_workgroup,
                       nutls_handle** out);
 
@@ -139,13 +140,13 @@ int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_ou
 int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out);
 
 /* Execution mode of nutls_step:
- *   3            fused kernel: ONE launch per frame, one 512-thread workgroup per stream (per two / four streams from two / four
- *                streams per CU on: nutls_streams_per_workgroup); every op of the step
+ *   3            fused kernel: ONE launch per frame, one 512-thread workgroup per stream (per two / four streams where the library's
+ *                cost model finds a packed plan faster -- more streams than CUs: nutls_streams_per_workgroup); every op of the step
  *                is its own specialised instruction stream (static schedule, no plan decoding).  Both variants
  *                have one; it keeps the conv kernels int8 on the device, so it exists for handles made from a
  *                container with int8 conv kernels (what the reference's .tflite stores) and is their default;
  *   1            one kernel per layer, the ~160 launches captured in a hipGraph (one per state parity);
- *   0            one kernel per layer, plain launches (the default for containers without int8 conv kernels is 1 in the Python wrapper).
+ *   0            one kernel per layer, plain launches (handles made from containers without int8 conv kernels start in mode 1).
  * (2 was the plan-interpreter kernel of rounds 1-3; retired, nutls_set_mode(2) is an error.)  All of them compute the same function (tests/test_gpu_parity.py::test_execution_modes_agree). */
 int nutls_set_mode(nutls_handle* h, int mode);
 /* enable != 0: mode 1 (capture + replay); enable == 0: mode 0. */
@@ -178,9 +179,9 @@ int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n
 int nutls_batch(nutls_handle* h);
 /* Streams one workgroup of the fused kernel steps (mode 3): 1, or -- LSTM variant, more streams than CUs -- 2 or 4: a packed plan
  * (csrc/fused_step_g2.hip / _g4.hip: the layers whose LDS images fit that often run the streams side by side on one position axis, sharing
- * the weight fetch and conversion; chosen by nutls_create so that rounds of workgroups x step time of the plan is smallest: 256 streams 1,
- * 512 2, 1024 and 2048 4).  A stream's results do not depend on its slot or partners.  NUTLS_FUSED_STREAMS=1 at creation keeps the
- * one-stream plan.  No reference counterpart (the reference steps one stream: interpreter_proposed.py:215). */
+ * the weight fetch and conversion; chosen by nutls_create so that rounds of workgroups x step time of the plan is smallest -- with 256 CUs:
+ * 256 streams 1, 300 .. 512 2, 768, 1024 and 2048 4, 1536 2).  A stream's results do not depend on its slot or partners.
+ * NUTLS_FUSED_STREAMS=1 at creation keeps the one-stream plan; nutls_create_plan chooses explicitly.  No reference counterpart (the reference steps one stream: interpreter_proposed.py:215). */
 int nutls_streams_per_workgroup(nutls_handle* h);
 int nutls_launches_per_step(nutls_handle* h);
 

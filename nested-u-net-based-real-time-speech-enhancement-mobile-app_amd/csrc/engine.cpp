@@ -137,6 +137,7 @@ struct Engine {
   bool off_bf16 = false;          // block mode: convs on the bf16 matrix pipe where the container holds int8 kernels (NUTLS_OFFLINE_FP32=1: the fp32-MFMA kernels)
   float* zx = nullptr;   // [offline + kScanReadAhead][84] LSTM input products of a block
   int ctfa_causal = 0;   // offline handles: 1 = true 32-frame causal average in the CTFA frequency branch (proposed.py:143-147)
+  bool ta_ring_cleared_by_set = false;   // streaming causal32: nutls_state_set cleared the history ring since the last step
   float* ta_hist = nullptr;   // [12 stages][31 + offline][64] time-attention history (causal mode)
   // block pipeline of an offline handle: the block is cut into chunks of consecutive frames, chunk c runs on its own
   // HIP stream one bottleneck behind chunk c-1 (every layer is causal in time: frame t needs frames <= t only)
@@ -151,7 +152,7 @@ struct Engine {
                          // (2 was the plan-interpreter kernel of rounds 1-3, retired)
   float* fz_blob = nullptr;              // weight blob of the fused kernel (plan order)
   int fz_streams_req = 0;                // nutls_create_plan: the caller's choice of plan (0: the library's)
-  int fz_streams = 1;                    // streams per workgroup of the fused plan this handle runs (packed plans: 2 from 512 streams on, 4 from 1024)
+  int fz_streams = 1;                    // streams per workgroup of the fused plan this handle runs (packed plans 2 / 4: chosen by the cost model in fused_setup or by nutls_create_plan)
   // CTFA frequency branch of the fused kernel (nutls_internal.hpp FzTa): fz_ta_zero = 64 zeros + a dump row (frame mode); causal32 mode of a
   // streaming handle (nutls_set_ctfa_mode): history ring [B][12][32][64] and the per-step sums [B][12][64]
   float *fz_ta_zero = nullptr, *fz_ta_ring = nullptr, *fz_ta_sum = nullptr;
@@ -868,9 +869,15 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
       if (best == 0.0 || t < best * 0.98) { best = t; streams = g; }      // (ties and near-ties: the smaller group)
     }
   }
-  if (const char* ev = getenv("NUTLS_FUSED_STREAMS")) streams = atoi(ev);
-  if (e->fz_streams_req > 0) streams = e->fz_streams_req;          // (nutls_create_plan: the caller's choice wins)
+  if (const char* ev = getenv("NUTLS_FUSED_STREAMS")) streams = atoi(ev);      // (developer override; falls back like the library's own choice)
   if (streams < 1 || !fused_has_plan(v, streams) || e->B % streams != 0) streams = 1;
+  if (e->fz_streams_req > 0) {          // nutls_create_plan: the caller's choice wins -- or the call fails, it never silently becomes another plan
+    if (!fused_has_plan(v, e->fz_streams_req))
+      return fail(NUTLS_ERR_ARG, "nutls_create_plan: no fused plan with that many streams per workgroup for this variant (plans: 1, 2, 4 for the LSTM variant, 1 for the baseline)");
+    if (e->B % e->fz_streams_req != 0)
+      return fail(NUTLS_ERR_ARG, "nutls_create_plan: the batch must be a multiple of streams_per_workgroup");
+    streams = e->fz_streams_req;
+  }
   if (streams > 1 && (fused_plan_arena_floats(v, streams) != fused_arena_floats(v) || fused_plan_parity_stride(v, streams) != fused_parity_stride(v) ||
                       fused_plan_ys_off(v, streams) != fused_ys_off(v) || fused_plan_ys_block(v, streams) != fused_ys_block(v)))
     return fail(NUTLS_ERR_ARG, "packed fused plan does not share the arena layout of the one-stream plan");
@@ -879,8 +886,8 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   std::string err;
   if (fused_pack_blob(v, wm, &blob, &err, streams) != FZ_PACK_OK) {
     // Not packable for the fused kernel -- float conv kernels (no int8 payload), only some of them int8, a scale count that
-    // does not match ... -- is not an error of the handle: modes 0-2 only need the de-quantised floats, the default becomes
-    // the plan-interpreter kernel (mode 2), and nutls_set_mode(3) reports the reason kept here.
+    // does not match ... -- is not an error of the handle: the per-layer modes only need the de-quantised floats, the handle
+    // runs on them (hipGraph replay, mode 1, chosen at the end of nutls_create), and nutls_set_mode(3) reports the reason kept here.
     e->fz_reason = err;
     return NUTLS_OK;
   }
@@ -892,7 +899,8 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   int rcz = dev_alloc(e, 128, &e->fz_ta_zero, true);
   if (rcz) return rcz;
   void* q = nullptr;
-  const size_t n_stamps = static_cast<size_t>(fused_plan_num_ops(v, streams)) * 9 + 1;     // op starts + 8 phase stamps per op
+  // op starts + 8 phase stamps per op (wave 0) + the per-wave trace of the FZ_WTRACE build: 8 waves x ops x 12 shader-clock stamps
+  const size_t n_stamps = static_cast<size_t>(fused_plan_num_ops(v, streams)) * (9 + 8 * 12) + 1;
   HIP_TRY(hipMalloc(&q, n_stamps * sizeof(unsigned long long)));
   e->allocs.push_back(q);
   HIP_TRY(hipMemset(q, 0, n_stamps * sizeof(unsigned long long)));
@@ -1110,7 +1118,13 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
       return fail(NUTLS_ERR_WEIGHTS, std::string("fused plan weights: ") + ex.what());
     }
     if (rc) return rc;
-    if (e->fz_blob) e->mode = 3;          // the default for streaming handles whose container holds int8 conv kernels
+    if (e->fz_blob) {
+      e->mode = 3;          // the default for streaming handles whose container holds int8 conv kernels
+    } else {
+      // float containers: the per-layer kernels, replayed as a hipGraph -- the same default for C and Python callers
+      if ((rc = capture_graphs(e))) return rc;
+      e->mode = 1;
+    }
   }
   e->debug["input_layer"] = {e->t_inlayer, 256 * 64};
   e->debug["msfe6_de.y"] = {e->t_y, 256 * 64};
@@ -1401,9 +1415,18 @@ int nutls_io_buffers(nutls_handle* h, float** mag_in, float** mag_out) {
   return NUTLS_OK;
 }
 
+// The causal32 CTFA of a streaming handle lives in the fused kernel only: the per-layer kernels compute the frame-mode attention and
+// never write the history ring, so every path that would run them on such a handle refuses instead of mixing the two silently.
+static int refuse_per_layer_in_causal32(const Engine* e, const char* who) {
+  if (e->ctfa_causal && !e->offline)
+    return fail(NUTLS_ERR_ARG, std::string(who) + ": the causal32 CTFA of a streaming handle runs on the fused kernel (mode 3) only -- nutls_set_ctfa_mode(NUTLS_CTFA_FRAME) first");
+  return NUTLS_OK;
+}
+
 int nutls_use_graph(nutls_handle* h, int enable) {
   if (!h) return fail(NUTLS_ERR_ARG, "null handle");
   Engine* e = &h->eng;
+  if (int rc = refuse_per_layer_in_causal32(e, "nutls_use_graph")) return rc;
   HIP_TRY(hipSetDevice(e->device));
   if (enable) {
     int rc = capture_graphs(e);
@@ -1420,8 +1443,8 @@ int nutls_set_mode(nutls_handle* h, int mode) {
     return fail(NUTLS_ERR_ARG, "nutls_set_mode: mode 3 (fused kernel) needs a streaming handle made from a container with int8 conv kernels" +
                                    (h->eng.fz_reason.empty() ? std::string() : " (" + h->eng.fz_reason + ")"));
   if (h->eng.offline && mode != 0) return fail(NUTLS_ERR_ARG, "nutls_set_mode: offline handles run per-layer launches (mode 0)");
-  if (mode != 3 && h->eng.ctfa_causal && !h->eng.offline)
-    return fail(NUTLS_ERR_ARG, "nutls_set_mode: the causal32 CTFA of a streaming handle runs on the fused kernel (mode 3) only");
+  if (mode != 3)
+    if (int rc = refuse_per_layer_in_causal32(&h->eng, "nutls_set_mode")) return rc;
   if (mode == 1) return nutls_use_graph(h, 1);
   h->eng.mode = mode;
   return NUTLS_OK;
@@ -1454,6 +1477,7 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   if (!direct && mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
   e->next_parity = 1 - par;
   e->steps += 1;
+  e->ta_ring_cleared_by_set = false;
   return NUTLS_OK;
 }
 
@@ -1581,6 +1605,12 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
   HIP_TRY(hipDeviceSynchronize());
   if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), const_cast<float*>(host_buf), false, 0);
   e->ys_dirty = true;      // a conv-input state changed under the fused kernel's carried partial sums: rebuilt before its next step
+  // causal32 CTFA: the 31-frame time-attention history is state that is not among the ABI's tensors; a caller that loads states starts new
+  // utterances (the migration path), which must not inherit the previous occupants' history (nutls.h, nutls_set_ctfa_mode)
+  if (e->fz_ta_ring && e->ctfa_causal && !e->ta_ring_cleared_by_set) {
+    HIP_TRY(hipMemset(e->fz_ta_ring, 0, static_cast<size_t>(e->B) * 12 * 32 * 64 * sizeof(float)));
+    e->ta_ring_cleared_by_set = true;      // (once per burst of nutls_state_set calls: the next step re-arms it)
+  }
   if (st->ring_d > 1) {
     std::vector<float> tmp(host_buf, host_buf + n_floats);
     rotate_ring(e, *st, tmp.data(), false);
@@ -1761,6 +1791,7 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   const int par = e->next_parity;
   const std::vector<Launch>& plan = e->plan[par];
   if (n != static_cast<int>(plan.size())) return fail(NUTLS_ERR_ARG, "nutls_profile_step: n must equal nutls_launches_per_step");
+  if (int rc = refuse_per_layer_in_causal32(e, "nutls_profile_step")) return rc;
   HIP_TRY(hipSetDevice(e->device));
   std::vector<hipEvent_t> ev(plan.size() + 1);
   for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
@@ -1777,6 +1808,7 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   for (auto& x : ev) (void)hipEventDestroy(x);
   e->next_parity = 1 - par;
   e->steps += 1;
+  e->ta_ring_cleared_by_set = false;
   return NUTLS_OK;
 }
 
@@ -1851,6 +1883,15 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n) {
   for (int i = 0; i < n; ++i) us[i] = static_cast<double>(t[i + 1] - t[i]) * 1000.0 / khz;
   e->next_parity = 1 - par;
   e->steps += 1;
+  e->ta_ring_cleared_by_set = false;
+  if (const char* wt = getenv("NUTLS_FUSED_WTRACE")) {       // debugging aid: the raw per-wave trace [8 waves][ops][12] of an FZ_WTRACE build (zeros otherwise)
+    std::vector<unsigned long long> tr(static_cast<size_t>(n) * 8 * 12);
+    HIP_TRY(hipMemcpy(tr.data(), e->fz_prof + static_cast<size_t>(n) * 9 + 1, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(wt, "wb")) {
+      fwrite(tr.data(), sizeof(unsigned long long), tr.size(), f);
+      fclose(f);
+    }
+  }
   if (const char* dump = getenv("NUTLS_FUSED_PHASES")) {     // debugging aid: phase stamps of every conv op (wave 0 of workgroup 0)
     std::vector<unsigned long long> sub(static_cast<size_t>(n) * 8);
     HIP_TRY(hipMemcpy(sub.data(), e->fz_prof + n + 1, sub.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1860,7 +1901,12 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n) {
         // stamp slots in chronological order: 0 loads issued, 5 carried weights arrived, 6 MFMA loop done (4x4 path),
         // 1 partials / parameters written, 2 past barrier 1, 3 epilogue done, 4 next image built
         const int order[7] = {0, 5, 6, 1, 2, 3, 4};
-        const char* nm[7] = {"issue", "wwait", "mloop", "mfma", "bar1", "epi", "build"};
+        const char* nm_conv[7] = {"issue", "wwait", "mloop", "mfma", "bar1", "epi", "build"};
+        // CTFA ops: loads issued | column sums | barrier | time-attention perceptron | frequency-attention perceptron + gate | barrier; the rest (bar2) = gate applied
+        const char* nm_ctfa[7] = {"issue", "colsum", "-", "bar1", "mlp_ta", "mlp_fa", "barg"};
+        const char* opn = fused_plan_op_name(e->variant, e->fz_streams, i);
+        const size_t ol = std::strlen(opn);
+        const char* const* nm = (ol >= 4 && std::strcmp(opn + ol - 4, "ctfa") == 0) ? nm_ctfa : nm_conv;
         unsigned long long prev = t[i];
         for (int k = 0; k < 7; ++k) {
           const unsigned long long v = sub[8 * i + order[k]];

@@ -54,7 +54,8 @@
 // tells what the part costs.  1 halo zeroing, 2 staging (HBM -> image), 4 HBM stores of the row-wise epilogue, 16 LayerNorm / PReLU
 // of the row-wise epilogue, 32 LSTM body, 64 CTFA body, 128 workgroup barriers, 256 MFMA loops of the 16x16x32 path, 512 partial-sum
 // reads of the row-wise epilogue, 2048 weight prefetch of the conv ops (MFMAs kept, on garbage), 4096 MFMA loops of the 32x32x16 path,
-// 8192 previous-frame tap staging of the strided convs (the upper bound of carrying that tap as a partial sum instead)
+// 8192 previous-frame tap staging of the strided convs (the upper bound of carrying that tap as a partial sum instead); round 5, inside the
+// 16x16-tile MFMA loops: 0x10000 no int8 -> bf16 conversion of the weights, 0x20000 no LDS reads of the B fragments, 0x40000 no MFMAs
 #ifndef FZ_ABL
 #define FZ_ABL 0
 #endif
@@ -121,6 +122,14 @@ __device__ __forceinline__ unsigned gofs(const Ctx& cx, int g) {
 
 // profiling build: phase stamps inside an op (wave 0 of workgroup 0), slot k of op I at prof[kNumOps + 1 + 8 I + k]
 #define FZ_STAMP(I, k) do { if (FZ_PROF && cx.prof && tid == 0) cx.prof[kNumOps + 1 + 8 * (I) + (k)] = wall_clock64(); } while (0)
+// FZ_WTRACE (profiling twin only, tools/gpu_wave_trace.py): EVERY wave of workgroup 0 stamps the shader clock (s_memtime, one tick per
+// cycle) at the phase boundaries of every op: slot k of op I of wave w at prof[9 kNumOps + 1 + (w kNumOps + I) 12 + k].  The stamps cost
+// a scalar memory round trip each -- the trace shows who waits for whom, not the un-instrumented step time.
+#ifndef FZ_WTRACE
+#define FZ_WTRACE 0
+#endif
+#define FZ_WSTAMP(I, k) do { if (FZ_PROF && FZ_WTRACE && cx.prof && (tid & 63) == 0) \
+    cx.prof[9 * kNumOps + 1 + ((tid >> 6) * kNumOps + (I)) * 12 + (k)] = __builtin_readcyclecounter(); } while (0)
 
 // ---- memory helpers (byte offsets) ---------------------------------------------------------------
 __device__ __forceinline__ f32x4 ldb(gcb_t base, unsigned boff) { return *(gc4_t)(base + static_cast<unsigned long long>(boff)); }
@@ -806,14 +815,22 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
         constexpr int f = lo + decltype(ff)::value;
         constexpr int s = f / GW, g = f % GW;
         constexpr int sf = f / 2;
-        const bf16x8 a = wfrag(c.w[sf % CW], f % 2);
+        bf16x8 a;
+        if constexpr ((FZ_ABL & 0x10000) != 0) a = as_bf(c.w[sf % CW]);      // (timing experiment: the raw bytes as the A operand, no conversion)
+        else a = wfrag(c.w[sf % CW], f % 2);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
-            const bf16x8 b = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 64 + pl * d.img.plane_b));
-            if constexpr ((UP && s == 2) || (BOTH && s < 3)) acco[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acco[pt][pl], 0, 0, 0);
-            else acc[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[pt][pl], 0, 0, 0);
+            bf16x8 b;
+            if constexpr ((FZ_ABL & 0x20000) != 0) { f32x4 bz = {0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(bz)); b = as_bf(bz); }      // (timing experiment: no B reads)
+            else b = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 64 + pl * d.img.plane_b));
+            if constexpr ((FZ_ABL & 0x40000) != 0) {      // (timing experiment: operands formed, no MFMA)
+              asm volatile("" :: "v"(a), "v"(b));
+            } else {
+              if constexpr ((UP && s == 2) || (BOTH && s < 3)) acco[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acco[pt][pl], 0, 0, 0);
+              else acc[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[pt][pl], 0, 0, 0);
+            }
           }
         }
         if constexpr ((f % 2 == 1 || f + 1 == NF) && sf + CW < NSF) {
@@ -1242,7 +1259,9 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
     }
     if (lane < 16) lds4(PART + gi * SGB + (wave * 64 + 4 * c4) * 4) = s4;
   }
+  FZ_STAMP(I, 5);
   lds_barrier();
+  FZ_STAMP(I, 1);
   if (wave < GS) {
     const int sb = wave * SGB;          // this wave's stream slot
     float m = 0.f;
@@ -1250,13 +1269,16 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
     for (int r = 0; r < 8; ++r) m += lds1(PART + sb + (r * 64 + lane) * 4);
     m = m * (1.0f / d.F);
     const float ta = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t, MSCR + sb, lane));
+    FZ_STAMP(I, 2);
     // (frame mode: ta_prev = 0 and the ring is one dump row -- proposed.py:179-183 with T = 1; causal32: the offline model's 32-frame
     //  average, proposed.py:143-147, the history in a ring of 32 rows per stage outside the arena, engine.cpp nutls_set_ctfa_mode)
     const float fa = fast_sigmoid(gate_mlp((ta_prev + ta) * (1.0f / 32.0f), w1f, b1f, w2f, b2f, MSCR + sb, lane));
     stb1(cx.ta_ring, static_cast<unsigned>(((cx.stream + d.g0 + wave) * cx.ta_ring_sstride + d.bidx * cx.ta_ring_gstride + lane) * 4), ta);
     lds1(GATE + sb + lane * 4) = fa * ta;
   }
+  FZ_STAMP(I, 3);
   lds_barrier();
+  FZ_STAMP(I, 4);
 #pragma unroll
   for (int gi = 0; gi < GS; ++gi) {
     const f32x4 g4 = lds4(GATE + gi * SGB + 16 * c4);

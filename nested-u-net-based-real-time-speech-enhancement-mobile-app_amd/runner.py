@@ -144,8 +144,9 @@ class NutlsEngine:
         ``variant``: "lstm" (NUNet-TLS-LSTM, trained weights ship in weights/) or "baseline"
         (dilated-dense bottleneck; no trained weights exist -- pass a container, e.g.
         ``weights.write_blob(weights.synthetic_weights("baseline"), int8_convs=True)``).
-        ``streams_per_workgroup``: which plan the fused kernel runs -- None: the library's choice (the packed plan, two streams per
-        workgroup when there are more streams than CUs), 1 / 2 / 4: that plan (``nutls_create_plan``; the batch must be a multiple)."""
+        ``streams_per_workgroup``: which plan the fused kernel runs -- None: the library's choice (a packed plan, two or four streams
+        per workgroup, where its cost model finds one faster: more streams than CUs), 1 / 2 / 4: that plan (``nutls_create_plan``; a batch
+        that is not a multiple, or a variant without such a plan, raises)."""
         self._lib = load_library()
         if variant not in self.VARIANTS:
             raise ValueError("variant must be one of %s" % sorted(self.VARIANTS))
@@ -157,8 +158,8 @@ class NutlsEngine:
         buf = ctypes.create_string_buffer(blob, len(blob))
         _check(self._lib, self._lib.nutls_create_plan(buf, len(blob), self.VARIANTS[variant], int(batch), int(device),
                                                       int(streams_per_workgroup or 0), ctypes.byref(self._h)))
-        # fp32 bytes of the container's tensors: what the modes that de-quantise on load (0-2) keep on the device
-        self._fp32_weight_bytes = 4 * sum(int(np.asarray(a).size) for a in parse_blob(blob).values())
+        self._blob = blob          # (kept for weight_blob_bytes() of the per-layer modes: parsed there, on demand)
+        self._fp32_weight_bytes = None
         self.batch = int(batch)
         self.device = int(device)
         pin, pout = ctypes.c_void_p(), ctypes.c_void_p()
@@ -203,7 +204,7 @@ class NutlsEngine:
 
     @property
     def streams_per_workgroup(self) -> int:
-        """Streams one workgroup of the fused kernel steps: 1, or 2 (packed plan, handles of >= 2 streams per CU)."""
+        """Streams one workgroup of the fused kernel steps: 1, or 2 / 4 (packed plans, chosen for handles with more streams than CUs)."""
         return int(self._lib.nutls_streams_per_workgroup(self._h))
 
     @property
@@ -355,6 +356,8 @@ class NutlsEngine:
         """Bytes of weights one launch reads: the fused kernel's packed blob (conv kernels int8), else the fp32 tensors."""
         if self.mode == "fused":
             return 4 * int(self._lib.nutls_fused_plan_blob_floats(self.VARIANTS[self.variant], self.streams_per_workgroup))
+        if self._fp32_weight_bytes is None:      # fp32 bytes of the container's tensors: what the modes that de-quantise on load keep on the device
+            self._fp32_weight_bytes = 4 * sum(int(np.asarray(a).size) for a in parse_blob(self._blob).values())
         return self._fp32_weight_bytes      # (lstm: 11 460 668 B = SURVEY.md section 8(d)'s fp32 weights of the graph)
 
     def profile_fused(self) -> np.ndarray:
