@@ -98,6 +98,11 @@ struct OpD {
   int xcopy_b;                             // fp32 copy of the rows an LSTM / dilated-dense op reads, stream i at xcopy_b + i * 1024 (one-stream plans: XCOPY_B)
   int x_gstride_b;                         // LSTM: LDS bytes between the sub-images (of the conv that follows) it writes its streams' rows into
   int layer;                               // index of the layer (= op index of the one-stream plan) this op is an instance of
+  // ---- role ops (one-stream plans; fused_step.hip run_role_op) -----------------------------------------
+  // 1: a small 16x16-tile conv op (one position tile, <= 4 channel tiles) whose four wave tasks run on waves 4..7 -- B reads, MFMAs,
+  // partial tiles; their weights arrive as bf16 fragments, widened by those waves at the end of the op before -- while waves 0..3
+  // issue the staging loads, run the row-wise epilogue and complete the next image.
+  int role;
 };
 constexpr int DDB_LDS_B = 64 * 1024;       // LDS scratch of a dilated-dense block op (17 920 floats), above the image it completes
 

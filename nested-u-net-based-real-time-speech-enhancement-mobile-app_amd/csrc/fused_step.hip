@@ -282,7 +282,39 @@ constexpr int ex_slices(const OpD& d) { return ksl(d) * (x16_both(d) ? 2 : 1); }
 constexpr int ex_group(const OpD& d) { return d.ys ? ex_slices(d) / 2 : ex_slices(d); }           // ... that add up to one result
 constexpr int nparams(const OpD& d) { return 2 * ntot(d) + 2 * d.gc + 1; }      // bias | weight scale | gamma | beta | alpha
 constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 1) / 2; }             // "super-fragments": 2 int8 fragments = one dwordx4 per lane
-constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), d.path == P_R32B ? RING_SF_R32 : RING_SF); }
+// Role ops (OpD::role, run_role_op): the four wave tasks of a small conv op run on waves 4..7 (the "matrix" waves), each with ALL the
+// fragments of its task in registers (no ring); waves 0..3 (the "serving" waves) issue the loads and run the row-wise epilogue.
+// (FZ_NOROLES / FZ_FORCE_SPLIT: timing experiments -- the role ops as plain conv ops with their four wave tasks on waves 0..3; the two
+//  programs without a role op in them)
+#ifndef FZ_NOROLES
+#define FZ_NOROLES 0
+#endif
+#ifndef FZ_FORCE_SPLIT
+#define FZ_FORCE_SPLIT 0
+#endif
+constexpr bool role_of(const OpD& d) { return !FZ_NOROLES && d.role != 0; }
+constexpr int ring_sf(const OpD& d) { return role_of(d) ? conv_nsf(d) : cmin(conv_nsf(d), d.path == P_R32B ? RING_SF_R32 : RING_SF); }
+constexpr bool is_role(int i) { return i >= 0 && i < kNumOps && kOps[i].type == T_CONV && role_of(kOps[i]); }
+// the weights of role op i arrive widened to bf16 (Carry::wb) when the op before it is a role op too: its matrix waves idle during the epilogue
+// (... or an LSTM / CTFA op, whose waves 4..7 idle while a few threads evaluate the gates)
+#ifndef FZ_WIDEN_GATES
+#define FZ_WIDEN_GATES 1
+#endif
+constexpr bool role_pre(int i) { return is_role(i) && (is_role(i - 1) || (FZ_WIDEN_GATES && i >= 1 && (kOps[i - 1].type == T_LSTM || kOps[i - 1].type == T_CTFA))); }
+constexpr int role_nf(int i) { return role_pre(i) ? conv_nf(kOps[i]) : 0; }
+// FZ_SPLIT 1: two programs, one per wave role (every op instantiated twice); 0: one program, a wave branch inside every role op
+#ifndef FZ_SPLIT
+#define FZ_SPLIT 0
+#endif
+#ifndef FZ_SETPRIO
+#define FZ_SETPRIO 1
+#endif
+#ifndef FZ_CTFA_PRESUM
+#define FZ_CTFA_PRESUM 1
+#endif
+#ifndef FZ_MLOADS
+#define FZ_MLOADS 1
+#endif
 // staging classes of a part: 1 loaded and stored by the op that builds the image, 2 loaded one op earlier (carried); second-round parts
 // of a two-round image (stored in the middle of the op that OWNS the image): 3 loaded at the start of that op, 4 loaded one op earlier
 constexpr int part_cls(const Part& p) { return p.round2 ? (p.la == 2 ? 4 : 3) : p.la; }
@@ -291,6 +323,7 @@ constexpr int part_cls(const Part& p) { return p.round2 ? (p.la == 2 ? 4 : 3) : 
 // queue behind the staging loads on the (in-order) memory counter, and the staging waves' waits cost the MFMA waves nothing.
 // Class-2 parts (loaded one op before they are stored) stay with all threads: both ops must agree on who holds what.
 constexpr int stg_threads(int i) {
+  if (is_role(i)) return 256;      // (the serving waves 0..3: run_role_op)
   return (i >= 0 && i < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32B && kOps[i].PG * kOps[i].CG == 4 && !kOps[i].ys) ? 256 : THREADS;
 }
 constexpr int part_items(const Part& p) { return p.ng * p.rows * p.c4s; }      // (packed plans: the block once per stream)
@@ -348,6 +381,7 @@ constexpr int ext_sf(int i) {
 template <int I>
 struct Carry {
   f32x4 w[cmax(1, carry_w(I))];
+  f32x4 wb[cmax(1, role_nf(I))];          // role op whose predecessor is a role op: ALL its fragments as bf16 (matrix waves), widened by the op before
   f32x4 p[cmax(1, nxt_regs(I, 2))];
   f32x4 p4[cmax(1, own_regs(I, 4))];      // the previous-frame tap of op I's own two-round image, requested by op I-1 (all threads hold it)
   f32x4 yp[cmax(1, yp_regs(I))];          // last frame's partial sums of op I (two-tap convs), requested two ops ahead like the weights
@@ -489,13 +523,23 @@ __device__ __forceinline__ void pin_regs(f32x4 (&r)[N]) {
   for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
 }
 
+// "Defined, contents unknown" without an instruction.  In a one-program kernel a role op assigns some carried registers in one of its two
+// wave branches only; on the other path they would be undefined -- and LLVM folds anything computed from phi(value, undef) into the block
+// that defines the value: the byte extraction of carried int8 weights moved up to their loads (a full memory round trip on the spot) and
+// travelled on as 16 separate byte registers.  An opaque definition on the other path keeps the phi a plain register phi.
+template <int N>
+__device__ __forceinline__ void opaque_regs(f32x4 (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "=v"(r[i]));
+}
+
 // ---- wave task of a conv op -----------------------------------------------------------------------------------
 struct Task { int active, wbase_f, a, b, ks; };   // a: position group, b: channel group / tile, ks: K slice (X16B)
 template <int I>
 __device__ __forceinline__ Task conv_task(int wave) {
   constexpr OpD d = kOps[I];
   Task t;
-  t.active = ntask(d) >= 8 ? 1 : wave < ntask(d);      // (a compile-time fact where all 8 waves have a task: no branch around their loads)
+  t.active = role_of(d) ? wave >= 4 : (ntask(d) >= 8 ? 1 : wave < ntask(d));      // (a compile-time fact where all 8 waves have a task: no branch around their loads; role ops: the task of wave 4 + k is task k)
   if constexpr (d.path == P_R32B) {
     t.a = wave & (d.PG - 1);                    // position group
     t.b = (wave >> clog2(d.PG)) & (d.CG - 1);   // channel group
@@ -512,12 +556,26 @@ __device__ __forceinline__ Task conv_task(int wave) {
 }
 
 // ---- prefetch of what op I needs first (issued by op I-1) ---------------------------------------------------------
-template <int I, int NW>
+// WHO (the caller is one wave role's branch of a role op, run_role_op): 0 all threads, 1 the serving waves (the weights of a role op are
+// not theirs: not loaded, "defined" without an instruction), 2 the matrix waves (the same for a role op's epilogue parameters)
+template <int I, int WHO = 0, int NW>
 __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW], f32x4& prm) {
   if constexpr (I < kNumOps) {
     constexpr OpD d = kOps[I];
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if constexpr (d.type == T_CONV) {
+    if constexpr (d.type == T_CONV && is_role(I) && WHO == 1) {
+      opaque_regs(w);
+      constexpr int NP4 = (nparams(d) + 3) / 4;
+      prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>((tid < NP4 ? tid : NP4 - 1) * 16));
+    } else if constexpr (d.type == T_CONV && is_role(I) && WHO == 2) {
+      const Task t = conv_task<I>(wave);
+      const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
+      sfor<carry_w(I)>([&](auto ff) {
+        constexpr int sf = decltype(ff)::value;
+        w[sf] = ldb(wbase + static_cast<unsigned long long>(sf * 1024), static_cast<unsigned>(lane * 16));
+      });
+      asm volatile("" : "=v"(prm));
+    } else if constexpr (d.type == T_CONV) {
       // Every load of a prefetch is issued by EVERY thread (indices clamped, no branch around a load): the compiler counts
       // outstanding loads per control-flow path, and after a branch that holds loads it must assume the path without them --
       // a later wait for an OLDER load then also drains the ones just issued (seen in the disassembly as `vmcnt(1)` in front
@@ -612,9 +670,11 @@ __device__ __forceinline__ unsigned x16_ys_off(const Ctx& cx, int item) {
 }
 
 // last frame's partial sums of op I ([pos][packed channel] fp32), in the layout its epilogue wants them
-template <int I, int NY>
+template <int I, int WHO = 0, int NY>
 __device__ __forceinline__ void prefetch_y(const Ctx& cx, int tid, f32x4 (&yp)[NY]) {
-  if constexpr (yp_regs(I) > 0) {
+  if constexpr (yp_regs(I) > 0 && is_role(I) && WHO == 2) {
+    opaque_regs(yp);
+  } else if constexpr (yp_regs(I) > 0) {
     constexpr OpD d = kOps[I];
     if constexpr (d.path == P_R32B) {
       const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -702,18 +762,30 @@ __device__ __forceinline__ bool fwd_has(int gi) {
   else if constexpr (fwd_all(d)) return true;
   else return ((d.fwd.mask >> gi) & 1) != 0;
 }
+// CTFA column sums in the epilogue of the stage's last sub-pixel conv (converter_proposed.py:257-263: the CTFA averages that conv's output
+// over frequency): the row-wise epilogue has every output row in registers, so each thread adds its rows up, the four lanes of a wave that
+// hold the same channel quad meet through two lane swaps, and every wave leaves one partial row in the CTFA's scratch (above the
+// epilogue's own parameter block).  The CTFA op then starts at its gate perceptrons: no pass over the image to form the sums, one
+// barrier less.  One-stream plans, 16x16-tile producers (the two 32x32-tile ones would need 160 lane-exchange steps per wave).
+constexpr int CSUM_OFF_B = 1792;       // inside the CTFA's scratch: 8 waves x 64 floats
+constexpr bool feeds_ctfa_sums(int i) {
+  return FZ_CTFA_PRESUM && NSTREAMS == 1 && i >= 0 && i + 1 < kNumOps && kOps[i + 1].type == T_CTFA && kOps[i].type == T_CONV && kOps[i].path == P_X16B &&
+         kOps[i].gc == 64 && !role_of(kOps[i]) && nparams(kOps[i]) * 4 <= CSUM_OFF_B;
+}
 // does op I feed an LSTM / dilated-dense op (which reads its rows as fp32 from XCOPY_B)?
 constexpr bool feeds_x(int i) { return i + 1 < kNumOps && (kOps[i + 1].type == T_LSTM || kOps[i + 1].type == T_DDB); }
 
 // ---- row-wise epilogue of the X16B path ---------------------------------------------------------------------------
 // LPG lanes per output row (float4 each): K-slice sum + bias, LayerNorm over the row's channels, PReLU, stores.
-template <int I, int NY>
+// NTHR: the threads that run it -- all, or the 256 of the serving waves of a role op (run_role_op)
+template <int I, int NTHR = THREADS, int NY>
 __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (&yp)[NY]) {
   constexpr OpD d = kOps[I];
   // (two-tap convs: slices [0, KS) of the exchange buffer hold the NEXT frame's partial sums, [KS, 2 KS) this frame's)
   constexpr int GC = d.gc, LPG = GC / 4, R = d.R, NTOT = ntot(d), KS = ex_group(d), K0 = d.ys ? KS : 0, OPB = (NTOT + 4) * 4;
   constexpr int VP = d.gs * d.P;      // (packed plans: the positions of the op's streams side by side)
-  constexpr int total = VP * NTOT / 4, passes = (total + THREADS - 1) / THREADS;
+  constexpr int total = VP * NTOT / 4, passes = (total + NTHR - 1) / NTHR;
+  static_assert(NTHR == THREADS || passes == 1, "the carried sums are dealt to 512 threads: a pass of 256 sees the same items only if it is the only one");
   const int li = tid & (LPG - 1);
   const int u0 = tid >> clog2(LPG);
   const int r = u0 & (R - 1);
@@ -726,10 +798,12 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
     bt = lds4(SCR_B + (2 * NTOT + GC + 4 * li) * 4);
     alpha = lds1(SCR_B + (2 * NTOT + 2 * GC) * 4);
   }
+  constexpr bool CSUM = feeds_ctfa_sums(I);
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};      // (CSUM: this thread's rows of the output, added up -- every row of its passes has the thread's channel quad)
   sfor<passes>([&](auto pp) {
     constexpr int ps = decltype(pp)::value;
-    const int u = u0 + ps * (THREADS / LPG);
-    if ((ps + 1) * THREADS <= total || FZ_LIKELY(u * LPG < total)) {
+    const int u = u0 + ps * (NTHR / LPG);
+    if ((ps + 1) * NTHR <= total || FZ_LIKELY(u * LPG < total)) {
       const int vpos = u >> clog2(R);
       const int gi = d.gs > 1 ? vpos >> clog2(d.P) : 0, pos = d.gs > 1 ? vpos & (d.P - 1) : vpos;      // stream slot, position inside the stream
       const int eb = d.ex_b + vpos * OPB + (r * GC + 4 * li) * 4;
@@ -750,19 +824,26 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
       }
       const int row = pos * d.row_mul + d.row_add + r;
       const unsigned go = gofs(cx, d.g0 + gi);
+      if constexpr (CSUM) cs += v;
       if constexpr (d.d0_on && !(FZ_ABL & 4)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v);
       if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v);
       if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, 4 * li, v); }
       if constexpr (feeds_x(I)) lds4(d.xcopy_b + gi * 1024 + (row * GC + 4 * li) * 4) = v;
     }
   });
+  if constexpr (CSUM) {
+    static_assert(LPG == 16 && NTHR == THREADS, "column sums: 16 lanes per row of 64 channels, all eight waves leave a partial row");
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[e] = xor32_sum(xor16_sum(cs[e]));
+    if ((tid & 63) < 16) lds4(kOps[I + 1].scr_b + CSUM_OFF_B + ((tid >> 6) * 64 + 4 * li) * 4) = cs;
+  }
   if constexpr (d.ys != 0) {
     // next frame's partial sums W[tap 0] x_t: K slices summed, stored raw ([pos][packed channel] = item order); the items are dealt
     // from the top of the workgroup, beside the epilogue rows of the low waves
     sfor<passes>([&](auto pp) {
       constexpr int ps = decltype(pp)::value;
-      const int item = (THREADS - 1 - tid) + ps * THREADS;
-      if ((ps + 1) * THREADS <= total || FZ_LIKELY(item < total)) {
+      const int item = (NTHR - 1 - tid) + ps * NTHR;
+      if ((ps + 1) * NTHR <= total || FZ_LIKELY(item < total)) {
         const int u = item >> clog2(LPG), l2 = item & (LPG - 1);
         const int eb = d.ex_b + (u >> clog2(R)) * OPB + ((u & (R - 1)) * GC + 4 * l2) * 4;
         f32x4 y = {0.f, 0.f, 0.f, 0.f};
@@ -1086,9 +1167,39 @@ __device__ __forceinline__ void input_op(const Ctx& cx, int tid) {
   }
 }
 
+// An LSTM / CTFA op in front of a role op: waves 4..7 -- the role op's matrix waves -- widen its int8 weights (requested two ops ago, in
+// c.w2) to bf16 while a few threads of the low waves evaluate the gates.  ROLE: 1 the matrix waves' program of a two-program kernel, 2 the
+// one program of a kernel that branches per role op, 0 the serving waves' program (nothing to do).
+// PART of NPARTS: an LSTM op has two shadows (gates, Dense), each shorter than the whole widening.
+template <int I, int ROLE, int PART = 0, int NPARTS = 1>
+__device__ __forceinline__ void widen_next(int tid, Carry<I>& c, Carry<I + 1>& n) {
+  if constexpr (ROLE != 0 && role_pre(I + 1)) {
+    constexpr int NFN = role_nf(I + 1), F0 = NFN * PART / NPARTS, F1 = NFN * (PART + 1) / NPARTS;
+    auto body = [&]() {
+      if constexpr (PART == 0) pin_regs(c.w2);
+#pragma unroll
+      for (int f = F0; f < F1; ++f) {
+        const bf16x8 wv = wfrag(c.w2[f / 2], f % 2);
+        n.wb[f] = __builtin_bit_cast(f32x4, wv);
+        asm volatile("" : "+v"(n.wb[f]));      // (widened HERE: nothing of it sinks into the next op)
+      }
+    };
+    if constexpr (ROLE == 1) {
+      body();
+    } else {
+      if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) {
+        body();
+      } else {
+#pragma unroll
+        for (int f = F0; f < F1; ++f) asm volatile("" : "=v"(n.wb[f]));
+      }
+    }
+  }
+}
+
 // ---- LSTM cell + Dense (proposed.py:70-119; converter_proposed.py:234-237), in place on the next conv's image ------------
-template <int I>
-__device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
+template <int I, int ROLE>
+__device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Carry<I + 1>& n) {
   // z = [x ; h] . [Wx ; Wh] + b with the gate columns interleaved (column 4 u + g: gate g of unit u), so that one float4
   // is (i, f, g, o) of a unit.  K is cut into 16 slices of x (threads (u, slice), tid < 336) and 4 slices of h
   // (tid 336..419); every operand arrived in the carry (slot map: [0, S0) weight rows of the thread's slice,
@@ -1126,6 +1237,7 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
     }
   }
   lds_barrier();
+  widen_next<I, ROLE, 0, 2>(tid, c, n);    // (waves 4..7, while 21 threads evaluate the gates: the bf16 weights of the role op that follows, first half)
   if (tid < 21 * GS) {          // thread (stream slot gi, unit uu): the unit's four gates
     const int gi = GS > 1 ? tid / 21 : 0, uu = GS > 1 ? tid % 21 : tid;
     f32x4 z = c.w[S0 + 8];
@@ -1141,6 +1253,7 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c) {
     lds1(HN + gi * SGB + uu * 4) = h_new;
   }
   lds_barrier();
+  widen_next<I, ROLE, 1, 2>(tid, c, n);    // (second half, beside the Dense rows of the low waves)
   // Dense: output n of stream gi by thread (gi * dout + n) mod 512 (its row of the Dense kernel arrived in the carry: 512 is a multiple
   // of dout, so a thread's row is the same in every pass)
   constexpr int DPASS = (d.dout * GS + THREADS - 1) / THREADS;
@@ -1215,8 +1328,8 @@ __device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1)[4], float 
 
 // ---- CTFA gate + residual (ctfa_rt, proposed.py:162-196), in place on the next image; the network's last
 //      one also applies the output 1x1 conv (proposed.py:65) and writes the enhanced magnitudes ---------------------------
-template <int I>
-__device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
+template <int I, int ROLE>
+__device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Carry<I + 1>& n) {
   constexpr OpD d = kOps[I];
   constexpr int NI = ctfa_ni(d), GS = d.gs, SGB = d.scr_gstride_b;
   // scratch of stream slot gi at d.scr_b + gi * SGB: column sums of the 8 waves | gates | the perceptrons' exchange
@@ -1245,28 +1358,35 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
   }
   const f32x4 ow = c.w[NI * GS];
   const float ob = c.w[NI * GS + 1][0];
+  constexpr bool PRE = feeds_ctfa_sums(I - 1);      // the column sums came with the rows: eight partial rows left by the conv op before
+  constexpr int PARTR = PRE ? d.scr_b + CSUM_OFF_B : PART;
+  if constexpr (!PRE) {
 #pragma unroll
-  for (int gi = 0; gi < GS; ++gi) {
-    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+    for (int gi = 0; gi < GS; ++gi) {
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int f = rg + 32 * i;
-      if (f < d.F) s4 += fwd_ld4g<I>(gi, f, 4 * c4);
+      for (int i = 0; i < NI; ++i) {
+        const int f = rg + 32 * i;
+        if (f < d.F) s4 += fwd_ld4g<I>(gi, f, 4 * c4);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s4[e] = xor32_sum(xor16_sum(s4[e]));
+      }
+      if (lane < 16) lds4(PART + gi * SGB + (wave * 64 + 4 * c4) * 4) = s4;
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s4[e] = xor32_sum(xor16_sum(s4[e]));
-    }
-    if (lane < 16) lds4(PART + gi * SGB + (wave * 64 + 4 * c4) * 4) = s4;
+    FZ_STAMP(I, 5);
+    lds_barrier();
+  } else {
+    FZ_STAMP(I, 5);
   }
-  FZ_STAMP(I, 5);
-  lds_barrier();
   FZ_STAMP(I, 1);
+  widen_next<I, ROLE>(tid, c, n);            // (waves 4..7, while wave 0 evaluates the gate perceptrons)
   if (wave < GS) {
     const int sb = wave * SGB;          // this wave's stream slot
     float m = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) m += lds1(PART + sb + (r * 64 + lane) * 4);
+    for (int r = 0; r < 8; ++r) m += lds1(PARTR + sb + (r * 64 + lane) * 4);
     m = m * (1.0f / d.F);
     const float ta = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t, MSCR + sb, lane));
     FZ_STAMP(I, 2);
@@ -1300,9 +1420,201 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c) {
   }
 }
 
+// ---- role op: a small conv op (one position tile of 16x16x32 bf16 MFMAs, <= 4 channel tiles) on two instruction streams --------------
+// A small op is a latency chain -- B reads, a few dozen MFMAs, partial tiles through LDS, barrier, row-wise LayerNorm epilogue, barrier --
+// and in the general conv op every wave carries every link of it plus the bookkeeping around it: the loads of the next images and
+// weights in front of the MFMAs, the int8 -> bf16 widening inside the loop (profiles/r05_v0_wave_trace.txt: 300-700 cycles of load
+// issue and 600-1100 of "MFMA loop" per op for 150-600 cycles of MFMA issue).  Here the two halves of the chain get their own waves:
+//   waves 4..7 ("matrix" waves, one per SIMD, ROLE 1): B reads + MFMAs of wave task (wave - 4) with ALL its weight fragments already in
+//     registers as bf16, partial tile to the exchange buffer, barrier 1; then, while the epilogue runs: request the weights of op I+2, widen
+//     the weights of op I+1 (requested one op ago), store their share of the far-ahead staged parts, zero the halos; barrier 2;
+//   waves 0..3 ("serving" waves, ROLE 0): issue the staging loads and parameter / partial-sum prefetches while the MFMAs run, barrier 1;
+//     row-wise epilogue (x_epilogue on 256 threads: bias, scale, LayerNorm, PReLU, state stores, rows of the next image), staged parts;
+//     barrier 2.
+// The barriers and every LDS hand-off are those of conv_x16b; what travels in the Carry keeps its all-threads meaning, so the ops around a
+// run of role ops are unchanged.
+// The two roles are two PROGRAMS: a kernel whose plan has role ops branches ONCE, at its entry, into run_from<0, PROF, ROLE> for its wave
+// role, and every op is instantiated per program.  (First built as a branch per role op: at every join the compiler merges the two paths'
+// outstanding-load bookkeeping -- a register one path has a load in flight for is "in flight" for the other path too, so the matrix waves
+// drained their memory counter at the head of every op; registers only one path defines became phi(value, undef), into which LLVM folds
+// the byte extraction of the carried int8 weights, up to their loads; loads whose results only the other role uses are dead loads, whose
+// destination registers are re-used behind a wait.  0.39 ms/step against 0.36 before.  With one branch there is nothing to merge, and what a
+// program does not use of a prefetch is dead code in that program.)
+// matrix waves' half of role op I.  UNI: one-program kernel (this is one branch of `if (wave >= 4)`): nothing these waves do not own is
+// loaded, what only the other branch defines gets an opaque definition, and no load is left in flight at the join -- the compiler merges
+// the outstanding-load bookkeeping of the two branches there, so the serving waves' loads count as "in flight" for these waves too: with
+// their own counter at zero every wait it derives from that is free.
+template <int I, bool UNI, bool LAST = false>
+__device__ __forceinline__ void role_matrix(const Ctx& cx, int tid, Carry<I>& c, Carry<I + 1>& n) {
+  constexpr OpD d = kOps[I];
+  constexpr int NF = conv_nf(d), GW = gw(d), NTOT = ntot(d), OPB = (NTOT + 4) * 4, J = nxt_of(I);
+  constexpr int WHO = UNI ? 2 : 0;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Task t = conv_task<I>(wave);
+  const int ks_t = t.ks >> clog2(d.KSg), ks_g = t.ks & (d.KSg - 1);
+  const int j = lane & 15, h = lane >> 4;
+  const int pos = j < d.P ? j : d.P - 1;
+  const int lane_b = pos * d.img.pitch_b + 16 * h + ks_t * d.img.tap_b + ks_g * (GW * 64);
+  bf16x8 a[NF];
+  if constexpr (role_pre(I)) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) a[f] = as_bf(c.wb[f]);
+  } else {
+    pin_regs(c.w);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) a[f] = wfrag(c.w[f / 2], f % 2);
+  }
+  FZ_WSTAMP(I, 2);
+  // Wave task = K slice (time tap, channel-group range of every segment) x channel group of NT tiles (the planner splits K first: the
+  // four waves then read disjoint B fragments).  Fragment f = (K step f / NT, tile f % NT); a B fragment serves the NT tiles of its K
+  // step.  All B reads of a batch of K steps are issued before its first MFMA (one wave per SIMD: nothing else hides the LDS latency),
+  // the next batch's reads behind the MFMAs of this one.
+  constexpr int NT = d.NT, NR = NF / NT;                  // K steps of the wave
+  constexpr int KB = 6, NB = (NR + KB - 1) / KB;          // K steps per batch: <= 18 reads = 72 registers
+  static_assert(NF == NR * NT && NB <= 2, "role op: K steps x channel tiles");
+  f32x4 acc[NT][3];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) acc[nt][pl] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 b[NB][KB][3];
+  auto rd = [&](auto bb) {
+    constexpr int B0 = decltype(bb)::value;
+    if constexpr (B0 < NB && !(FZ_ABL & 256)) {
+      sfor<cmin(KB, NR - B0 * KB)>([&](auto rr) {
+        constexpr int r = B0 * KB + decltype(rr)::value, sg = r / GW, g = r % GW;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[B0][r % KB][pl] = as_bf(lds4(lane_b + d.seg_b[sg] + g * 64 + pl * d.img.plane_b));
+      });
+    }
+  };
+  rd(std::integral_constant<int, 0>{});
+  // (FZ_MLOADS 0: what the next ops need from these waves' threads is requested here, in front of the MFMAs -- a wave issues in order, so
+  //  the MFMAs start that much later: the MFMA phase of a role op 0.5 -> 1.1 us)
+  if constexpr (FZ_MLOADS == 0) {
+    stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+    prefetch_w<I + 2, WHO>(cx, tid, n.w2, n.prm2);
+    prefetch_y<I + 2, WHO>(cx, tid, n.yp2);
+  }
+  sfor<(FZ_ABL & 256) ? 0 : NB>([&](auto bb) {
+    constexpr int B0 = decltype(bb)::value;
+    rd(std::integral_constant<int, B0 + 1>{});
+    sched_pin();
+    sfor<cmin(KB, NR - B0 * KB)>([&](auto rr) {
+      constexpr int r = B0 * KB + decltype(rr)::value;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) acc[nt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r * NT + nt], b[B0][r % KB][pl], acc[nt][pl], 0, 0, 0);
+    });
+  });
+  FZ_WSTAMP(I, 3);
+  if (j < d.P) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) lds4(d.ex_b + (t.ks * d.P + j) * OPB + (16 * (t.b * NT + nt) + 4 * h) * 4) = acc[nt][0] + (acc[nt][1] + acc[nt][2]);
+  }
+  FZ_WSTAMP(I, 4);
+  lds_barrier();                      // the partial tiles are in the exchange buffer; every matrix wave is done with this op's image
+  FZ_WSTAMP(I, 5);
+  // -- in the shadow of the epilogue: what the next ops need from these waves' threads is requested first.  The last op of a run waits for
+  // these loads at its end (below): the LSTM / CTFA op behind a run drains the memory counter at its start, and there the matrix waves'
+  // late loads made them late for its first barrier (13 LSTM ops 17 -> 23 us); here the wait sits beside the serving waves' epilogue
+  if constexpr (FZ_MLOADS == 1) {
+    stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+    prefetch_w<I + 2, WHO>(cx, tid, n.w2, n.prm2);
+    prefetch_y<I + 2, WHO>(cx, tid, n.yp2);
+    sched_pin();
+  }
+  n.prm = c.prm2;
+#pragma unroll
+  for (int k = 0; k < cmax(1, yp_regs(I + 1)); ++k) n.yp[k] = c.yp2[k];
+  if constexpr (role_pre(I + 1)) {
+    widen_next<I, 1>(tid, c, n);
+  } else {
+#pragma unroll
+    for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
+  }
+  FZ_WSTAMP(I, 6);
+  stage_store<J, 2, THREADS>(tid, c.p);
+  zero_halos<J>(tid);
+  FZ_WSTAMP(I, 7);
+  if constexpr (UNI || LAST) drain_vm();      // (issued a whole MFMA phase + epilogue ago: nothing to wait for, but the bookkeeping is clean at the join)
+}
+
+// serving waves' half of role op I
+template <int I, bool UNI>
+__device__ __forceinline__ void role_serve(const Ctx& cx, int tid, Carry<I>& c, Carry<I + 1>& n) {
+  constexpr OpD d = kOps[I];
+  constexpr int J = nxt_of(I);
+  constexpr int WHO = UNI ? 1 : 0;
+  f32x4 p1[cmax(1, nxt_regs(I, 1))];
+  stage_load<J, 1, 256>(cx, tid, p1);
+  stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+  prefetch_w<I + 2, WHO>(cx, tid, n.w2, n.prm2);
+  prefetch_y<I + 2, WHO>(cx, tid, n.yp2);
+  sched_pin();
+  n.prm = c.prm2;
+#pragma unroll
+  for (int k = 0; k < cmax(1, yp_regs(I + 1)); ++k) n.yp[k] = c.yp2[k];
+  if constexpr (role_pre(I + 1)) {
+    if constexpr (UNI) opaque_regs(n.wb);
+  } else {
+#pragma unroll
+    for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
+  }
+  FZ_STAMP(I, 0);
+  FZ_STAMP(I, 5);
+  FZ_WSTAMP(I, 1);
+  if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
+  FZ_STAMP(I, 1);
+  FZ_WSTAMP(I, 4);
+  lds_barrier();
+  FZ_STAMP(I, 2);
+  FZ_WSTAMP(I, 5);
+  if constexpr (FZ_SETPRIO) __builtin_amdgcn_s_setprio(3);      // (the epilogue is the op's critical path: ahead of the matrix wave of its SIMD, which widens weights)
+  x_epilogue<I, 256>(cx, tid, c.yp);
+  if constexpr (FZ_SETPRIO) __builtin_amdgcn_s_setprio(0);
+  FZ_STAMP(I, 3);
+  FZ_WSTAMP(I, 6);
+  stage_store<J, 1, 256>(tid, p1);
+  stage_store<J, 2, THREADS>(tid, c.p);
+  zero_halos<J>(tid);
+  FZ_STAMP(I, 4);
+  FZ_WSTAMP(I, 7);
+  if constexpr (d.drain != 0) drain_vm();      // (baseline variant: the dilated-dense op after it reads this op's rows from HBM; the stores are the serving waves')
+}
+
+// ROLE: 0 / 1 the serving / matrix waves' program (of a run of role ops, or -- FZ_SPLIT -- of the whole kernel), 2 one program that branches
+// here.  LAST: the last op of a run of role ops (the two programs join behind it).
+template <int I, bool PROF, int ROLE, bool LAST = false>
+__device__ __forceinline__ void run_role_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
+  constexpr OpD d = kOps[I];
+  constexpr int NSF = conv_nsf(d), NTOT = ntot(d);
+  static_assert(d.path == P_X16B && d.PT == 1 && d.PG == 1 && ntask(d) == 4 && d.rounds == 1 && !is_up(d) && !x16_both(d), "role op: four wave tasks of one 16-position tile");
+  static_assert(d.CG * d.NT * 16 == d.N, "role op: channel groups x tiles per task");
+  static_assert(d.gs == 1 && d.img.fmt == 1 && NSTREAMS == 1, "role ops exist in the one-stream plans");
+  static_assert(carry_w(I) == NSF && own_regs(I, 3) == 0 && own_regs(I, 4) == 0 && own_regs(I + 1, 4) == 0 && ext_sf(I) == 0, "role op: no ring, one round");
+  static_assert(d.P * NTOT / 4 <= 256 && (nparams(d) + 3) / 4 <= 256, "role op: one epilogue pass on the serving waves");
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  if (PROF && cx.prof && tid == 0) cx.prof[I] = wall_clock64();
+  FZ_WSTAMP(I, 0);
+  if constexpr (ROLE == 1) {
+    role_matrix<I, false, LAST>(cx, tid, c, n);
+  } else if constexpr (ROLE == 0) {
+    role_serve<I, false>(cx, tid, c, n);
+  } else {
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) role_matrix<I, true>(cx, tid, c, n);
+    else role_serve<I, true>(cx, tid, c, n);
+  }
+  FZ_WSTAMP(I, 9);
+  lds_barrier();
+  FZ_WSTAMP(I, 10);
+}
+
 // ---- one op -----------------------------------------------------------------------------------------------------------
-template <int I, bool PROF>
-__device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
+template <int I, bool PROF, int ROLE>
+__device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
   constexpr OpD d = kOps[I];
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));          // per-op thread id: nothing derived from it is hoisted across ops
@@ -1349,13 +1661,13 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
     if constexpr (d.path == P_X16B) conv_x16b<I>(cx, tid, c, p1, p3);
     else conv_r32b<I>(cx, tid, c, p1, p3, wx);
   } else if constexpr (d.type == T_LSTM) {
-    if constexpr (!(FZ_ABL & 32)) lstm_op<I>(cx, tid, c);
+    if constexpr (!(FZ_ABL & 32)) lstm_op<I, ROLE>(cx, tid, c, n);
 #if FZ_BASE
   } else if constexpr (d.type == T_DDB) {
     ddb_op<I>(cx, tid, c);
 #endif
   } else {
-    if constexpr (!(FZ_ABL & 64)) ctfa_op<I>(cx, tid, c);
+    if constexpr (!(FZ_ABL & 64)) ctfa_op<I, ROLE>(cx, tid, c, n);
     if constexpr (nxt_of(I) >= 0) {
       // packed plans: an instance of the network's last CTFA that is followed by another stream's ops completes the image of the conv
       // after it (its loads went out in the prologue above) -- once every thread is done with the plain rows the image overlaps
@@ -1367,14 +1679,58 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
   lds_barrier();
 }
 
-template <int I, bool PROF>
-__device__ __forceinline__ void run_from(const Ctx& cx, Carry<I>& c) {
-  if constexpr (I < kNumOps) {
+// ROLE: the program this instantiation belongs to -- 0 serving waves (0..3), 1 matrix waves (4..7) of a kernel whose plan has role ops
+// (run_role_op), 2 the only program of a kernel without
+template <int I, bool PROF, int ROLE>
+__device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
+  if constexpr (is_role(I)) run_role_op<I, PROF, ROLE>(cx, c, n);
+  else run_plain_op<I, PROF, ROLE>(cx, c, n);
+}
+
+// A RUN of consecutive role ops is executed as two programs, one per wave role: ONE branch in front of the run, one join behind it.
+// (A branch per role op loses to the compiler's bookkeeping of outstanding loads, which is merged -- conservatively -- at every join:
+// memory-counter drains at the head of every op.  Two programs for the whole kernel keep that bookkeeping exact but instantiate every
+// plain op twice, and two instruction streams per CU cost the plain ops 5-10 %: profiles/r05_role_dev_log.txt.)  At the join the matrix
+// waves have no load in flight (role_matrix LAST), so whatever the merged bookkeeping makes them wait for is free.
+// (An LSTM / CTFA op in front of a role op belongs to the run: in the matrix waves' program it widens that op's weights in the shadow
+// of its gates -- widen_next -- with no branch of its own.)
+constexpr bool is_gate_op(int i) { return i >= 0 && i < kNumOps && (kOps[i].type == T_LSTM || kOps[i].type == T_CTFA); }
+constexpr bool in_run(int i) { return is_role(i) || (FZ_WIDEN_GATES && is_gate_op(i) && is_role(i + 1)); }
+constexpr int role_run_end(int i) { while (in_run(i)) ++i; return i; }
+template <int I, int E, bool PROF, int ROLE>
+__device__ __forceinline__ void run_roles(const Ctx& cx, Carry<I>& c, Carry<E>& out) {
+  // the matrix waves leave no load in flight behind the run (the join) and in front of an LSTM / CTFA op (which drains the counter at its start)
+  constexpr bool LAST = I + 1 == E || is_gate_op(I + 1);
+  auto one = [&](auto& nn) {
+    if constexpr (is_role(I)) run_role_op<I, PROF, ROLE, LAST>(cx, c, nn);
+    else run_plain_op<I, PROF, ROLE>(cx, c, nn);
+  };
+  if constexpr (I + 1 == E) {
+    one(out);
+  } else {
     Carry<I + 1> n;
-    run_op<I, PROF>(cx, c, n);
-    run_from<I + 1, PROF>(cx, n);
+    one(n);
+    run_roles<I + 1, E, PROF, ROLE>(cx, n, out);
   }
 }
+
+template <int I, bool PROF, int ROLE>
+__device__ __forceinline__ void run_from(const Ctx& cx, Carry<I>& c) {
+  if constexpr (I < kNumOps) {
+    if constexpr (ROLE == 2 && in_run(I)) {
+      constexpr int E = role_run_end(I);
+      Carry<E> out;
+      if (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) >= 4) run_roles<I, E, PROF, 1>(cx, c, out);
+      else run_roles<I, E, PROF, 0>(cx, c, out);
+      run_from<E, PROF, ROLE>(cx, out);
+    } else {
+      Carry<I + 1> n;
+      run_op<I, PROF, ROLE>(cx, c, n);
+      run_from<I + 1, PROF, ROLE>(cx, n);
+    }
+  }
+}
+constexpr bool has_roles() { for (int i = 0; i < kNumOps; ++i) if (is_role(i)) return true; return FZ_FORCE_SPLIT != 0; }
 
 struct FzArgs {
   float* arena; long long sstride; const float* blob; const float* io_in; float* io_out; int B, par; unsigned long long* prof;
@@ -1482,7 +1838,13 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
     prefetch_w<1>(cx, tid, c0.w2, c0.prm2);
     prefetch_y<1>(cx, tid, c0.yp2);
   }
-  run_from<0, PROF>(cx, c0);
+  if constexpr (has_roles() && (FZ_SPLIT || FZ_FORCE_SPLIT)) {
+    // two programs, one per wave role (run_role_op): the only branch on the role in the whole kernel
+    if (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) >= 4) run_from<0, PROF, 1>(cx, c0);
+    else run_from<0, PROF, 0>(cx, c0);
+  } else {
+    run_from<0, PROF, 2>(cx, c0);
+  }
   if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();
 }
 

@@ -28,7 +28,7 @@ def clip():
 
 def test_plan_choice_follows_the_stream_count():
     """More streams than CUs: a packed plan by default, chosen by rounds x step time; an odd count or NUTLS_FUSED_STREAMS=1: one stream per
-    workgroup."""
+    workgroup; an explicit request for a plan the batch cannot run is an error."""
     # (the choice minimises rounds x step time of the plan: 300 streams are one round of pairs instead of two rounds of single streams,
     #  768 one round of 192 four-stream workgroups, 1536 three rounds of pairs rather than two of fours)
     for B, want in ((1, 1), (256, 1), (300, 2), (511, 1), (512, 2), (768, 4), (1022, 2), (1024, 4), (1536, 2), (2048, 4)):
@@ -41,9 +41,10 @@ def test_plan_choice_follows_the_stream_count():
     eng = NutlsEngine(batch=6, streams_per_workgroup=2)
     assert eng.streams_per_workgroup == 2
     eng.close()
-    eng = NutlsEngine(batch=5, streams_per_workgroup=2)          # odd: falls back
-    assert eng.streams_per_workgroup == 1
-    eng.close()
+    with pytest.raises(ValueError):                              # an explicit request that cannot be met fails loudly (it never becomes another plan)
+        NutlsEngine(batch=5, streams_per_workgroup=2)
+    with pytest.raises(ValueError):
+        NutlsEngine(batch=6, streams_per_workgroup=3)
     eng = NutlsEngine(batch=8, streams_per_workgroup=4)
     assert eng.streams_per_workgroup == 4
     eng.close()

@@ -39,6 +39,7 @@ def json_path(variant, G=1):
 
 # the plans that are built into the library: (variant, streams per workgroup)
 PLANS = [("lstm", 1), ("baseline", 1), ("lstm", 2), ("lstm", 4)]
+ROLES = os.environ.get("NUTLS_PLAN_ROLES", "0") != "0"      # role ops in the one-stream plans (developer knob: 0 = the round-4 tilings)
 
 # (prefix, depth, f0, conv state tag, sub-pixel state tag, resample layer)   converter_proposed.py:221-727
 ENC = [("msfe6_en", 6, 256, "msfe6_ee", "msfe6_ed", "msfe6_down_sampling"),
@@ -188,12 +189,13 @@ def carries_sums(kind, N, P):
     return 1 if kind == K_EL else 0
 
 
-def tiling(kind, N, P, cin, taps, rounds=1, gs=1):
+def tiling(kind, N, P, cin, taps, rounds=1, gs=1, waves=8):
     """-> dict(path, PT, NT, PG, CG, KSt, KSg).  R32B: 32x32x16 bf16 tiles, PT x NT tiles per wave, PG x CG wave tasks, whole
     LayerNorm groups per wave.  X16B: 16x16x32 bf16 tiles, wave task = (position group pg, channel tile ct, K slice
     (time tap ks_t, channel-group range ks_g)), PT tiles per wave; the K slices meet in the LDS exchange buffer.
     Packed plans: `gs` streams side by side -- the tiling is that of gs * P positions (32x32 tiles: whole tiles per stream).
-    None: no tiling for that many positions (the layer then runs one stream at a time)."""
+    None: no tiling for that many positions (the layer then runs one stream at a time).
+    waves = 4: the tiling of a "role" op (OpD.role): its wave tasks run on waves 4..7 only, waves 0..3 serve (staging, epilogue)."""
     per_stream = P
     P = gs * P
     table = {**R32_TABLE, **R32_TABLE_PACKED} if gs > 1 else R32_TABLE
@@ -206,7 +208,20 @@ def tiling(kind, N, P, cin, taps, rounds=1, gs=1):
     assert P <= 64, (kind, N, P)
     CT = N // 16
     ptiles = (P + 15) // 16
-    rem = max(1, 8 // CT)
+    if waves == 4:
+        # role op: four wave tasks, K split FIRST (time tap, then channel-group halves / quarters of every segment), every task all the
+        # channel tiles that are left (NT of them): the four matrix waves then read disjoint B fragments -- with one channel tile per
+        # wave each of them read the whole image, and the MFMA phase of a 36-MFMA op was LDS-bound (4 x 36 ds_read_b128 = 1150 cycles
+        # of LDS time for 612 of MFMA issue)
+        assert ptiles == 1 and kind != K_UP and rounds == 1
+        KSt = min(taps, 4)
+        KSg = 1
+        while KSt * KSg * 2 <= 4 and (cin // 32) % (KSg * 2) == 0:
+            KSg *= 2
+        CG = max(1, 4 // (KSt * KSg))
+        assert CT % CG == 0 and KSt * KSg * CG == 4, (kind, N, P, cin)
+        return dict(path=P_X16B, PT=1, NT=CT // CG, PG=1, CG=CG, KSt=KSt, KSg=KSg)
+    rem = max(1, waves // CT)
     KSt = 1 if (rounds == 2 or kind == K_UP) else min(taps, rem)
     rem //= KSt
     KSg = 1
@@ -416,7 +431,7 @@ def build_for(variant, G, cls):
                  d0=None, d1=None, row_mul=1, row_add=0, fwd=None, img=None, nxt=-1, parts=[],
                  din=0, dout=0, x_b=0, x_pitch_b=0, x_cols=0, y_b=0, h_off=0, c_off=0, ldst=None, lw_off=0,
                  F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0, x_fmt=0, x_plane_b=0, ys=0, ys_off=0, xs_off=0, xs_ld=0,
-                 gs=1, g0=0, scr_b=SCR_B, scr_gstride_b=0, xcopy_b=XCOPY_B, x_gstride_b=0, layer=-1)
+                 gs=1, g0=0, scr_b=SCR_B, scr_gstride_b=0, xcopy_b=XCOPY_B, x_gstride_b=0, layer=-1, role=0)
         d.update(kw)
         d["gs"] = gs_of(d["name"])
         ops.append(d)
@@ -431,7 +446,14 @@ def build_for(variant, G, cls):
                    rounds=rounds, d0=d0, d1=d1, row_mul=row_mul, row_add=row_add, ys=ys)
         gs = o["gs"]
         VP = gs * P         # positions of the op's streams side by side
-        o.update(tiling(kind, N, P, cin, taps, rounds, gs=gs))
+        # Role ops (one-stream plans): a small layer -- one position tile, at most four channel tiles -- keeps its MFMA work on waves 4..7
+        # (four wave tasks, every weight fragment widened to bf16 by those waves in the shadow of the op BEFORE) while waves 0..3 issue the
+        # staging loads, run the row-wise epilogue and complete the next image: the two halves of a small op's latency chain get their
+        # own instruction streams (fused_step.hip run_role_op; profiles/r05_v0_wave_trace.txt is what it answers)
+        role = 1 if (ROLES and G == 1 and gs == 1 and P <= 16 and N // 16 <= 4 and kind != K_UP and rounds == 1) else 0
+        o.update(tiling(kind, N, P, cin, taps, rounds, gs=gs, waves=4 if role else 8))
+        o["role"] = role if o["path"] == P_X16B else 0
+        assert o["role"] == role, name
         ntot = N * (2 if kind == K_UP else 1)
         x16 = o["path"] == P_X16B
         if x16:
@@ -459,7 +481,7 @@ def build_for(variant, G, cls):
         # "super-fragments" (2 fragments = 16 bytes = one dwordx4 per lane)
         segw = 3 if kind == K_UP else len(g["seg_b"]) // o["KSt"]
         if x16:
-            nf = segw * (cin // 32 // o["KSg"])
+            nf = segw * (cin // 32 // o["KSg"]) * o["NT"]
             wtasks = o["CG"] * o["KSt"] * o["KSg"]
         elif ys:
             # 32x32 tiles of a two-tap conv: waves 0..3 own the next frame's sums (time tap 0), waves 4..7 this frame's (tap 1)
@@ -889,7 +911,7 @@ def emit(A, W, ops, G=1):
         seg_b = ",".join(str(x) for x in pad(o["seg_b"], MAX_SEG))
         ldst = o["ldst"]
         row = ("{%d, /*conv*/ %d,%d,%d,%d,%d,%d,%d, %d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, %d,{%s}, %d, %d,%d, %s, %s, %d,%d, %s, %s, %d, "
-               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d},   // %d %s") % (
+               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d, /*role*/ %d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
             o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
@@ -897,7 +919,7 @@ def emit(A, W, ops, G=1):
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
             1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["x_fmt"], o["x_plane_b"], o["lw_off"],
             o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["ys"], o["ys_off"], o["xs_off"], o["xs_ld"],
-            o["gs"], o["g0"], o["scr_b"], o["scr_gstride_b"], o["xcopy_b"], o["x_gstride_b"], o["layer"], o["idx"], op_label(o))
+            o["gs"], o["g0"], o["scr_b"], o["scr_gstride_b"], o["xcopy_b"], o["x_gstride_b"], o["layer"], o["role"], o["idx"], op_label(o))
         L.append("  " + row)
     L.append("};")
     # what the host needs to pack the blob / check the arena
