@@ -302,6 +302,7 @@ constexpr bool is_role(int i) { return i >= 0 && i < kNumOps && kOps[i].type == 
 #endif
 constexpr bool role_pre(int i) { return is_role(i) && (is_role(i - 1) || (FZ_WIDEN_GATES && i >= 1 && (kOps[i - 1].type == T_LSTM || kOps[i - 1].type == T_CTFA))); }
 constexpr int role_nf(int i) { return role_pre(i) ? conv_nf(kOps[i]) : 0; }
+constexpr bool is_gate_op(int i) { return i >= 0 && i < kNumOps && (kOps[i].type == T_LSTM || kOps[i].type == T_CTFA); }
 // FZ_SPLIT 1: two programs, one per wave role (every op instantiated twice); 0: one program, a wave branch inside every role op
 #ifndef FZ_SPLIT
 #define FZ_SPLIT 0
@@ -313,7 +314,7 @@ constexpr int role_nf(int i) { return role_pre(i) ? conv_nf(kOps[i]) : 0; }
 #define FZ_CTFA_PRESUM 1
 #endif
 #ifndef FZ_MLOADS
-#define FZ_MLOADS 1
+#define FZ_MLOADS 2
 #endif
 // staging classes of a part: 1 loaded and stored by the op that builds the image, 2 loaded one op earlier (carried); second-round parts
 // of a two-round image (stored in the middle of the op that OWNS the image): 3 loaded at the start of that op, 4 loaded one op earlier
@@ -880,21 +881,28 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
   }
   constexpr bool BOTH = x16_both(d);            // two-tap conv, the wave owns both taps: segments 0..2 (tap 0) go to the second set
   constexpr bool TWO = UP || BOTH;
-  f32x4 acc[PT][3], acco[TWO ? PT : 1][3];
+  // NT channel tiles per wave task (the planner splits K before it splits the channels: the waves that would differ only in their
+  // channel tile read the same B fragments).  Fragment f = (K step f / NT, tile f % NT): a B fragment is read once per K step.
+  constexpr int NT = d.NT;
+  static_assert(d.CG * NT * 16 == d.N && NF % NT == 0, "channel groups x tiles per task");
+  f32x4 acc[PT][NT][3], acco[TWO ? PT : 1][TWO ? NT : 1][3];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) { acc[pt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (TWO) acco[pt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) { acc[pt][nt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (TWO) acco[pt][nt][pl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
   const unsigned lane16 = static_cast<unsigned>(lane * 16);
   if (t.active) pin_regs(c.w);
   FZ_STAMP(I, 5);
+  bf16x8 bfr[PT][3];
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
     if (t.active) {
       sfor<(FZ_ABL & 256) ? 0 : hi - lo>([&](auto ff) {
         constexpr int f = lo + decltype(ff)::value;
-        constexpr int s = f / GW, g = f % GW;
+        constexpr int nt = f % NT, r = f / NT, s = r / GW, g = r % GW;
         constexpr int sf = f / 2;
         bf16x8 a;
         if constexpr ((FZ_ABL & 0x10000) != 0) a = as_bf(c.w[sf % CW]);      // (timing experiment: the raw bytes as the A operand, no conversion)
@@ -903,14 +911,15 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
         for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
-            bf16x8 b;
-            if constexpr ((FZ_ABL & 0x20000) != 0) { f32x4 bz = {0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(bz)); b = as_bf(bz); }      // (timing experiment: no B reads)
-            else b = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 64 + pl * d.img.plane_b));
+            if constexpr (nt == 0) {
+              if constexpr ((FZ_ABL & 0x20000) != 0) { f32x4 bz = {0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(bz)); bfr[pt][pl] = as_bf(bz); }      // (timing experiment: no B reads)
+              else bfr[pt][pl] = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 64 + pl * d.img.plane_b));
+            }
             if constexpr ((FZ_ABL & 0x40000) != 0) {      // (timing experiment: operands formed, no MFMA)
-              asm volatile("" :: "v"(a), "v"(b));
+              asm volatile("" :: "v"(a), "v"(bfr[pt][pl]));
             } else {
-              if constexpr ((UP && s == 2) || (BOTH && s < 3)) acco[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acco[pt][pl], 0, 0, 0);
-              else acc[pt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[pt][pl], 0, 0, 0);
+              if constexpr ((UP && s == 2) || (BOTH && s < 3)) acco[pt][nt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[pt][pl], acco[pt][nt][pl], 0, 0, 0);
+              else acc[pt][nt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[pt][pl], acc[pt][nt][pl], 0, 0, 0);
             }
           }
         }
@@ -936,10 +945,13 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
     for (int pt = 0; pt < PT; ++pt) {
       const int pos = 16 * (t.a * PT + pt) + j;
       if (pos < VP) {
-        const int eb = d.ex_b + ((BOTH ? 1 : t.ks) * VP + pos) * OPB + (16 * t.b + 4 * h) * 4;
-        lds4(eb) = acc[pt][0] + (acc[pt][1] + acc[pt][2]);
-        if constexpr (UP) lds4(eb + d.N * 4) = acco[pt][0] + (acco[pt][1] + acco[pt][2]);
-        if constexpr (BOTH) lds4(eb - VP * OPB) = acco[pt][0] + (acco[pt][1] + acco[pt][2]);      // slice 0: the next frame's sums
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int eb = d.ex_b + ((BOTH ? 1 : t.ks) * VP + pos) * OPB + (16 * (t.b * NT + nt) + 4 * h) * 4;
+          lds4(eb) = acc[pt][nt][0] + (acc[pt][nt][1] + acc[pt][nt][2]);
+          if constexpr (UP) lds4(eb + d.N * 4) = acco[pt][nt][0] + (acco[pt][nt][1] + acco[pt][nt][2]);
+          if constexpr (BOTH) lds4(eb - VP * OPB) = acco[pt][nt][0] + (acco[pt][nt][1] + acco[pt][nt][2]);      // slice 0: the next frame's sums
+        }
       }
     }
   }
@@ -1489,10 +1501,14 @@ __device__ __forceinline__ void role_matrix(const Ctx& cx, int tid, Carry<I>& c,
     }
   };
   rd(std::integral_constant<int, 0>{});
-  // (FZ_MLOADS 0: what the next ops need from these waves' threads is requested here, in front of the MFMAs -- a wave issues in order, so
-  //  the MFMAs start that much later: the MFMA phase of a role op 0.5 -> 1.1 us)
-  if constexpr (FZ_MLOADS == 0) {
-    stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+  // What the next ops need from these waves' threads.  A wave issues in order, so every load in front of the MFMAs delays them (all of them
+  // here, FZ_MLOADS 0: the MFMA phase of a role op 0.5 -> 1.1 us); but the loads that come from HBM -- the far-ahead staged parts of the next
+  // image but one: previous-frame rows -- and the large parameter block of an LSTM / CTFA op two ops ahead need the lead time: requested in
+  // the shadow of the epilogue they were not there when the run ended (the matrix waves wait for their loads at the join) or when the
+  // LSTM op started (13 LSTM ops 17 -> 23 us).  The weights of the next role ops (L2 hits, one op of slack) go out in the shadow.
+  constexpr bool EARLY_W = FZ_MLOADS == 0 || (FZ_MLOADS == 2 && is_gate_op(I + 2));
+  if constexpr (FZ_MLOADS != 1) stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+  if constexpr (EARLY_W) {
     prefetch_w<I + 2, WHO>(cx, tid, n.w2, n.prm2);
     prefetch_y<I + 2, WHO>(cx, tid, n.yp2);
   }
@@ -1519,8 +1535,8 @@ __device__ __forceinline__ void role_matrix(const Ctx& cx, int tid, Carry<I>& c,
   // -- in the shadow of the epilogue: what the next ops need from these waves' threads is requested first.  The last op of a run waits for
   // these loads at its end (below): the LSTM / CTFA op behind a run drains the memory counter at its start, and there the matrix waves'
   // late loads made them late for its first barrier (13 LSTM ops 17 -> 23 us); here the wait sits beside the serving waves' epilogue
-  if constexpr (FZ_MLOADS == 1) {
-    stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+  if constexpr (FZ_MLOADS == 1) stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+  if constexpr (!EARLY_W) {
     prefetch_w<I + 2, WHO>(cx, tid, n.w2, n.prm2);
     prefetch_y<I + 2, WHO>(cx, tid, n.yp2);
     sched_pin();
@@ -1694,7 +1710,6 @@ __device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>&
 // waves have no load in flight (role_matrix LAST), so whatever the merged bookkeeping makes them wait for is free.
 // (An LSTM / CTFA op in front of a role op belongs to the run: in the matrix waves' program it widens that op's weights in the shadow
 // of its gates -- widen_next -- with no branch of its own.)
-constexpr bool is_gate_op(int i) { return i >= 0 && i < kNumOps && (kOps[i].type == T_LSTM || kOps[i].type == T_CTFA); }
 constexpr bool in_run(int i) { return is_role(i) || (FZ_WIDEN_GATES && is_gate_op(i) && is_role(i + 1)); }
 constexpr int role_run_end(int i) { while (in_run(i)) ++i; return i; }
 template <int I, int E, bool PROF, int ROLE>

@@ -85,7 +85,8 @@ def test_blob_packing_round_trips_the_container(variant, streams):
                     sg, g, T = (3 * ks if r32two else 0) + sgi // G, sgi % G, ct * o["NT"] + nt
                     npk, c0 = 32 * T + (lane & 31), 16 * g + 8 * (lane >> 5)
                 else:
-                    sg, g, T = ks_t * segw + f // GW, ks_g * GW + f % GW, ct
+                    nt, r = f % o["NT"], f // o["NT"]          # (NT channel tiles per task, the tile index fastest)
+                    sg, g, T = ks_t * segw + r // GW, ks_g * GW + r % GW, ct * o["NT"] + nt
                     npk, c0 = 16 * T + (lane & 15), 32 * g + 8 * (lane >> 4)
                 t, kw = o["seg_tk"][sg] >> 2, o["seg_tk"][sg] & 3
                 for qq in range(8):

@@ -39,6 +39,7 @@ def json_path(variant, G=1):
 
 # the plans that are built into the library: (variant, streams per workgroup)
 PLANS = [("lstm", 1), ("baseline", 1), ("lstm", 2), ("lstm", 4)]
+KFIRST = os.environ.get("NUTLS_PLAN_KFIRST", "1") != "0"    # K-split-first tilings of the small layers (developer knob: 0 = the round-4 tilings)
 ROLES = os.environ.get("NUTLS_PLAN_ROLES", "0") != "0"      # role ops in the one-stream plans (developer knob: 0 = the round-4 tilings)
 
 # (prefix, depth, f0, conv state tag, sub-pixel state tag, resample layer)   converter_proposed.py:221-727
@@ -189,7 +190,7 @@ def carries_sums(kind, N, P):
     return 1 if kind == K_EL else 0
 
 
-def tiling(kind, N, P, cin, taps, rounds=1, gs=1, waves=8):
+def tiling(kind, N, P, cin, taps, rounds=1, gs=1, waves=8, fits=None, ys=0):
     """-> dict(path, PT, NT, PG, CG, KSt, KSg).  R32B: 32x32x16 bf16 tiles, PT x NT tiles per wave, PG x CG wave tasks, whole
     LayerNorm groups per wave.  X16B: 16x16x32 bf16 tiles, wave task = (position group pg, channel tile ct, K slice
     (time tap ks_t, channel-group range ks_g)), PT tiles per wave; the K slices meet in the LDS exchange buffer.
@@ -221,6 +222,42 @@ def tiling(kind, N, P, cin, taps, rounds=1, gs=1, waves=8):
         CG = max(1, 4 // (KSt * KSg))
         assert CT % CG == 0 and KSt * KSg * CG == 4, (kind, N, P, cin)
         return dict(path=P_X16B, PT=1, NT=CT // CG, PG=1, CG=CG, KSt=KSt, KSg=KSg)
+    if KFIRST and gs == 1 and kind != K_UP and rounds == 1 and ptiles == 1 and CT <= 4:
+        # K split FIRST (one-stream plans): the waves of a position group that differ only in their channel tile read the SAME B
+        # fragments -- eight waves x the whole K range of a 128-channel sub-pixel conv are 8 x 36 ds_read_b128 per position tile, and
+        # the B reads are 5 % of the step (profiles/r05_knob_experiments.txt, `nobread`).  So: as many K slices as divide K (time tap,
+        # then channel-group halves / quarters of every segment), every wave task NT channel tiles of its slice -- a B fragment then
+        # serves NT MFMAs per plane.  Bounds: PT x NT <= 4 accumulator tiles per plane, the exchange buffer (one slice per K slice)
+        # next to the image in LDS.  Among the tilings with eight wave tasks: least LDS + memory-pipe time, then fewest slices.
+        # Only the layers of one position tile and at most four channel tiles: measured per tiling class (profiles/r05_kfirst_classes.txt),
+        # the 64-channel sub-pixel convs gain 0.1-0.4 us each and the 128-input-channel layers 0.2-0.4; with more position tiles the
+        # search splits the positions over the waves, every position group pulls the weights through the memory pipe again and the
+        # layers LOSE 0.3-1.6 us each; the 128-channel sub-pixel convs (four tiles per task) do not move.
+        nseg = taps * (3 if kind in (K_EL, K_DL, K_DOWN) else 1)
+        best = None
+        for kst in ((1, 2) if taps == 2 else (1,)):
+            for ksg in (1, 2, 4):
+                if (cin // 32) % ksg:
+                    continue
+                for cg in (1, 2, 4, 8):
+                    if CT % cg:
+                        continue
+                    for pg in (1, 2, 4):
+                        if ptiles % pg or kst * ksg * cg * pg != 8:
+                            continue
+                        pt, nt = ptiles // pg, CT // cg
+                        both = 2 if (ys and kst == 1) else 1      # a two-tap conv whose waves own both taps: two accumulator sets, two slices per K slice
+                        if pt * nt * both > 4 or (fits is not None and not fits(kst * ksg * both)):
+                            continue
+                        # cost (cycles of the two shared pipes): B reads -- 8 waves x K steps x PT x 3 planes x 8 cycles of LDS per
+                        # ds_read_b128 -- and the weights, which every position group pulls through the CU's memory pipe again
+                        reads = (nseg // kst) * (cin // 32 // ksg) * pt
+                        cost = 8 * 3 * 8 * reads + N * nseg * cin * pg // 64
+                        key = (cost, kst * ksg, -cg)
+                        if best is None or key < best[0]:
+                            best = (key, dict(path=P_X16B, PT=pt, NT=nt, PG=pg, CG=cg, KSt=kst, KSg=ksg))
+        if best is not None:
+            return best[1]
     rem = max(1, waves // CT)
     KSt = 1 if (rounds == 2 or kind == K_UP) else min(taps, rem)
     rem //= KSt
@@ -451,7 +488,13 @@ def build_for(variant, G, cls):
         # staging loads, run the row-wise epilogue and complete the next image: the two halves of a small op's latency chain get their
         # own instruction streams (fused_step.hip run_role_op; profiles/r05_v0_wave_trace.txt is what it answers)
         role = 1 if (ROLES and G == 1 and gs == 1 and P <= 16 and N // 16 <= 4 and kind != K_UP and rounds == 1) else 0
-        o.update(tiling(kind, N, P, cin, taps, rounds, gs=gs, waves=4 if role else 8))
+        ntot_ = N * (2 if kind == K_UP else 1)
+        img_b = make_img(kind, P, cin, rounds, fmt=1, cps=ys)["bytes"]
+
+        def fits(ks):      # image + exchange buffer of ks slices below the scratch
+            return img_b <= (SCR_B - ks * P * (ntot_ + 4) * 4) // 256 * 256
+        o.update(tiling(kind, N, P, cin, taps, rounds, gs=gs, waves=4 if role else 8, fits=fits, ys=ys))
+        assert not (ys and o["path"] == P_X16B and o["KSt"] == 1 and o["KSg"] > 1), name      # (both taps per wave: one K slice)
         o["role"] = role if o["path"] == P_X16B else 0
         assert o["role"] == role, name
         ntot = N * (2 if kind == K_UP else 1)

@@ -21,4 +21,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   python $R/tools/pmc_summary.py $(find /tmp/pm -name "*.db" | head -1) $KPAT
 done
 } > $OUT/pmc.txt 2>&1
+python $R/tools/pmc_traffic.py $OUT/pmc.txt fused $B lstm $S > $OUT/pmc_traffic_g$S.json
 tail -1 $OUT/bench.json | cut -c1-400; head -4 $OUT/timeline.txt; head -5 $OUT/kernel_stats.txt; cat $OUT/pmc.txt
