@@ -155,7 +155,11 @@ int nutls_use_graph(nutls_handle* h, int enable);
 /* State access by the reference's signature names.  `name` is any of the 130 state inputs
  * ("msfe6_ee_prev1" ... "msfe6_de_c", converter_proposed.py:27-186); the matching output spelling
  * ("..._cur1") is accepted as an alias.  Host buffer layout: [B, F, C] (conv states) or [B, 21],
- * float32, `n_floats` must equal B * per-stream size.  Synchronous. */
+ * float32, `n_floats` must equal B * per-stream size.  Synchronous.
+ * (The fused kernel does not write the 40 conv-input states it never reads itself -- the echoes of the strided convs' inputs,
+ * converter_proposed.py:226-231 -- on every frame: their rows exist a second time as skip-connection slices of other states, and the
+ * library rebuilds them from there before any of the accessors below, a step of another mode or nutls_reset looks at the states.
+ * What a caller sees is what the reference's runner returns, frame by frame; NUTLS_EAGER_STATES=1 makes every launch write everything.) */
 int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
 int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, size_t n_floats);
 

@@ -107,6 +107,12 @@ struct Engine {
   float* d_ys_w = nullptr;
   int n_ys_ops = 0;
   bool ys_dirty = false;
+  // Lazily written states (fused_plan.hpp OpD::d0_on = 2: the input states of the strided convs, which the fused kernel never reads): a
+  // fused step leaves them unwritten and marks them stale; whoever looks at states from outside the kernel -- nutls_state_get / _set /
+  // _get_all, nutls_reset, a step of a per-layer mode, the rebuild of the carried sums -- goes through states_materialize first.
+  LazyCopy* d_lazy = nullptr;
+  int n_lazy = 0;
+  bool eager_states = false, states_stale = false;
   std::vector<DdbParams> ddbs;   // baseline: the 13 dilated-dense blocks (host copy, per parity identical)
   DdbParams* d_ddb = nullptr;
   struct DdbStates { int in, blk[6], out; };
@@ -919,6 +925,29 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   e->n_ys_ops = static_cast<int>(yops.size());
   int rc = upload(e, yw, &e->d_ys_w);
   if (rc) return rc;
+  // the lazily written states of the one-stream plans (the packed plans hand rows over through some of them: they write everything)
+  std::vector<LazyCopy> lazy;
+  if (streams == 1) fused_lazy_table(v, &lazy);
+  e->n_lazy = static_cast<int>(lazy.size());
+  if (e->n_lazy) {
+    void* lz = nullptr;
+    HIP_TRY(hipMalloc(&lz, lazy.size() * sizeof(LazyCopy)));
+    e->allocs.push_back(lz);
+    HIP_TRY(hipMemcpy(lz, lazy.data(), lazy.size() * sizeof(LazyCopy), hipMemcpyHostToDevice));
+    e->d_lazy = static_cast<LazyCopy*>(lz);
+  }
+  if (const char* ev = getenv("NUTLS_EAGER_STATES")) e->eager_states = atoi(ev) != 0;      // (developer knob: every launch writes every state)
+  return NUTLS_OK;
+}
+
+// The state tensors the last fused step left unwritten, rebuilt from their second copy (the skip-connection slices it did write), in the
+// parity that step wrote -- the one every reader outside the kernel looks at.
+static int states_materialize(Engine* e, hipStream_t s) {
+  if (!e->states_stale || !e->n_lazy) { e->states_stale = false; return NUTLS_OK; }
+  if (!s) HIP_TRY(hipDeviceSynchronize());      // (called from a host-side accessor: the step may have run on any stream)
+  const int block = (1 - e->next_parity) ? fused_parity_stride(e->variant) : 0;
+  HIP_TRY(launch_lazy_states(e->arena, static_cast<long long>(e->sstride), block, e->d_lazy, e->n_lazy, e->B, s));
+  e->states_stale = false;
   return NUTLS_OK;
 }
 
@@ -926,6 +955,7 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
 // would have read as the previous frame -- if anything but the fused kernel wrote those since (ys_dirty).
 static int ysum_refresh(Engine* e, int par, hipStream_t s) {
   if (!e->ys_dirty || !e->n_ys_ops) return NUTLS_OK;
+  if (int rc = states_materialize(e, s)) return rc;      // (the sums are rebuilt from the conv-input states)
   const int v = e->variant;
   const int x_block = par ? 0 : fused_parity_stride(v);                       // the `prev` parity of this step
   const int ys_block = fused_ys_off(v) + (par ? 0 : fused_ys_block(v));       // the block this step reads
@@ -941,11 +971,12 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* 
   if (int rc = ysum_refresh(e, par, s)) return rc;
   auto launch = base ? launch_fused_base_step : (e->fz_streams == 4 ? launch_fused_step_g4 : (e->fz_streams == 2 ? launch_fused_step_g2 : launch_fused_step));
   static const int skew = [] { const char* v = getenv("NUTLS_FUSED_SKEW"); return v ? atoi(v) : 0; }();
-  FzTa ta{e->fz_ta_zero, e->fz_ta_zero + 64, 0, 0, 0, 0, skew};
+  const int eager = (e->eager_states || !e->n_lazy) ? 1 : 0;
+  FzTa ta{e->fz_ta_zero, e->fz_ta_zero + 64, 0, 0, 0, 0, skew, eager};
   if (e->ctfa_causal && e->fz_ta_ring) {
     const int slot = static_cast<int>(e->steps & 31);          // this frame's row of the history: the sums leave it out, the step overwrites it
     HIP_TRY(launch_ta_sum(e->fz_ta_ring, e->fz_ta_sum, slot, e->B, s));
-    ta = FzTa{e->fz_ta_sum, e->fz_ta_ring + slot * 64, 12 * 64, 64, 12 * 32 * 64, 32 * 64, skew};
+    ta = FzTa{e->fz_ta_sum, e->fz_ta_ring + slot * 64, 12 * 64, 64, 12 * 32 * 64, 32 * 64, skew, eager};
   }
   hipError_t err = launch(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
                           mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
@@ -955,6 +986,7 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* 
                                "NUTLS_FUSED_STREAMS=1 selects the one-stream plan)");
   if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("fused step launch: ") + hipGetErrorString(err));
   if (base) e->d_step_stale = true;      // ring position of the dilated-dense history went in by value: one launch per step
+  e->states_stale = !eager;              // (materialised on demand: states_materialize)
   return NUTLS_OK;
 }
 
@@ -1460,6 +1492,8 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   const bool direct = e->mode == 3;      // the fused kernel takes the caller's buffers as they are
   if (!direct && mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
   const int par = e->next_parity;
+  if (e->mode != 3)
+    if (int rc = states_materialize(e, s)) return rc;      // (the per-layer kernels read every conv-input state)
   if (e->mode == 3) {
     int rc = run_fused(e, par, s, false, mag_in, mag_out);
     if (rc) return rc;
@@ -1588,6 +1622,7 @@ int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n
   int rc = state_lookup(e, name, n_floats, &st);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
+  if (int rcm = states_materialize(e, nullptr)) return rcm;      // (lazily written states: brought up to date before anything outside the kernel looks)
   HIP_TRY(hipDeviceSynchronize());
   if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), host_buf, true, 0);
   rc = copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), host_buf, true);
@@ -1602,6 +1637,7 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
   int rc = state_lookup(e, name, n_floats, &st);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
+  if (int rcm = states_materialize(e, nullptr)) return rcm;      // (lazily written states: brought up to date before anything outside the kernel looks)
   HIP_TRY(hipDeviceSynchronize());
   if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), const_cast<float*>(host_buf), false, 0);
   e->ys_dirty = true;      // a conv-input state changed under the fused kernel's carried partial sums: rebuilt before its next step
@@ -1630,6 +1666,7 @@ int nutls_state_get_all(nutls_handle* h, int stream_idx, float* host_buf, size_t
   for (const StateTensor& st : e->states) total += st.per_stream();
   if (n_floats != total) return fail(NUTLS_ERR_ARG, "nutls_state_get_all: expected " + std::to_string(total) + " floats");
   HIP_TRY(hipSetDevice(e->device));
+  if (int rcm = states_materialize(e, nullptr)) return rcm;      // (lazily written states: brought up to date before anything outside the kernel looks)
   HIP_TRY(hipDeviceSynchronize());
   // Only what is asked for crosses the bus: the buffers of the `prev`-side parity are one contiguous block of the stream's
   // arena slice (allocate_states), the baseline's history rings a second one -- one copy per run of adjacent buffers, then
@@ -1668,6 +1705,7 @@ int nutls_reset(nutls_handle* h, int stream_idx) {
   if (stream_idx >= e->B) return fail(NUTLS_ERR_ARG, "nutls_reset: stream index out of range");
   if (e->offline) stream_idx = 0;    // one utterance: the carried state lives in arena slot 0
   HIP_TRY(hipSetDevice(e->device));
+  if (int rcm = states_materialize(e, nullptr)) return rcm;      // (lazily written states: brought up to date before anything outside the kernel looks)
   HIP_TRY(hipDeviceSynchronize());
   // a stream's whole slice of the arena (state of both parities + scratch) is contiguous
   if (stream_idx < 0) HIP_TRY(hipMemset(e->arena, 0, e->sstride * sizeof(float) * e->B));
@@ -1706,6 +1744,7 @@ int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n
       if (!src) return fail(NUTLS_ERR_ARG, "debug tensor not allocated yet: " + nm);
       if (n_floats != per * e->B) return fail(NUTLS_ERR_ARG, "size mismatch for debug tensor " + nm);
       HIP_TRY(hipSetDevice(e->device));
+      if (int rcm = states_materialize(e, nullptr)) return rcm;      // (lazily written states: brought up to date before anything outside the kernel looks)
       HIP_TRY(hipDeviceSynchronize());
       HIP_TRY(hipMemcpy(host_buf, src, n_floats * sizeof(float), hipMemcpyDeviceToHost));
       return NUTLS_OK;
@@ -1796,6 +1835,7 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   std::vector<hipEvent_t> ev(plan.size() + 1);
   for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
   if (int rc = sync_step_counter(e, e->stream)) return rc;
+  if (int rc = states_materialize(e, e->stream)) return rc;
   e->ys_dirty = true;
   HIP_TRY(hipEventRecord(ev[0], e->stream));
   for (size_t i = 0; i < plan.size(); ++i) {

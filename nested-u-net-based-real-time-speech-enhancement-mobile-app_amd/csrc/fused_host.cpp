@@ -71,6 +71,7 @@ const char* fused_scratch_name(int variant, int i) { return FZ_BY_VARIANT(fused_
 int fused_scratch_off(int variant, int i) { return FZ_BY_VARIANT(fused_scratch_off(i)); }
 int fused_ys_block(int variant) { return FZ_BY_VARIANT(fused_ys_block()); }
 int fused_ys_off(int variant) { return FZ_BY_VARIANT(fused_ys_off()); }
+void fused_lazy_table(int variant, std::vector<LazyCopy>* tab) { FZ_BY_VARIANT(fused_lazy_table(tab)); }
 // (packed plans -- streams per workgroup > 1, LSTM variant -- share the arena layout of the one-stream plan; what differs is the tiling,
 //  hence the blob and the layout of the carried partial sums)
 #define FZ_BY_PLAN(call) \

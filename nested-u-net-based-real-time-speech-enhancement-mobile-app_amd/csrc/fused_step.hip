@@ -113,7 +113,10 @@ struct Ctx {
   unsigned long long* prof;
   const DdbParams* ddb;        // baseline variant: the 13 dilated-dense blocks of this step's parity
   int stream, step;            // step: frame counter (position in the dilated-dense history rings)
+  int eager;                   // write the state tensors nothing here reads too (OpD::d0_on = 2; FzTa::eager)
 };
+// does the launch write destination 0 of op d?  (d0_on 2: a conv-input state the kernel never reads -- only when the handle wants eager states)
+#define FZ_D0(d, cx) ((d).d0_on == 1 || ((d).d0_on == 2 && (cx).eager != 0))
 // byte offset of stream slot g's arena slice relative to the workgroup's first stream (added to the 32-bit offset of a load / store)
 __device__ __forceinline__ unsigned gofs(const Ctx& cx, int g) {
   if constexpr (NSTREAMS == 1) return 0u;
@@ -826,7 +829,7 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
       const int row = pos * d.row_mul + d.row_add + r;
       const unsigned go = gofs(cx, d.g0 + gi);
       if constexpr (CSUM) cs += v;
-      if constexpr (d.d0_on && !(FZ_ABL & 4)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v);
+      if constexpr (d.d0_on && !(FZ_ABL & 4)) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v); }
       if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v);
       if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, 4 * li, v); }
       if constexpr (feeds_x(I)) lds4(d.xcopy_b + gi * 1024 + (row * GC + 4 * li) * 4) = v;
@@ -1138,7 +1141,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
           const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
           const int cc = c0 + 8 * q + 4 * h;
           if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, cc, v); }
-          if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v);
+          if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v); }
           if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4) + go, v);
         }
       }
@@ -1248,7 +1251,9 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
       lds4(PART + gi * SGB + (sl * 21 + u) * 16) = a;
     }
   }
+  FZ_WSTAMP(I, 3);
   lds_barrier();
+  FZ_WSTAMP(I, 4);
   widen_next<I, ROLE, 0, 2>(tid, c, n);    // (waves 4..7, while 21 threads evaluate the gates: the bf16 weights of the role op that follows, first half)
   if (tid < 21 * GS) {          // thread (stream slot gi, unit uu): the unit's four gates
     const int gi = GS > 1 ? tid / 21 : 0, uu = GS > 1 ? tid % 21 : tid;
@@ -1264,7 +1269,9 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
     stb1(cx.sbc, static_cast<unsigned>((d.h_off + uu) * 4) + so, h_new);
     lds1(HN + gi * SGB + uu * 4) = h_new;
   }
+  FZ_WSTAMP(I, 5);
   lds_barrier();
+  FZ_WSTAMP(I, 6);
   widen_next<I, ROLE, 1, 2>(tid, c, n);    // (second half, beside the Dense rows of the low waves)
   // Dense: output n of stream gi by thread (gi * dout + n) mod 512 (its row of the Dense kernel arrived in the carry: 512 is a multiple
   // of dout, so a thread's row is the same in every pass)
@@ -1311,30 +1318,27 @@ __device__ __forceinline__ void ddb_op(const Ctx& cx, int tid, Carry<I>& c) {
 }
 #endif
 
-// 64 -> 16 (ReLU) -> 64 perceptron of the CTFA gates, evaluated by ONE wave without barriers (lane c = channel c)
-__device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1)[4], float b1_u, const f32x4 (&w2)[4], float b2, int scr_b, int lane) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) lds4(scr_b + (lane * 20 + 4 * q) * 4) = w1[q] * in;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int u = lane & 15, qtr = lane >> 4;
+// 64 -> 16 (ReLU) -> 64 perceptron of the CTFA gates, evaluated by ONE wave without barriers and without LDS (lane c = channel c).
+// First layer: lane (u = lane & 15, q = lane >> 4) forms the partial sum of hidden unit u over the 16 input channels of row q -- those
+// channels ARE the 16 lanes of its own row, so DPP row_share hands them over inside the FMA's operand fetch (w1x: the lane's 16 weights
+// w1[u][16 q + i], the blob stores them lane-major) -- and two lane swaps add the four rows.  Second layer: hidden unit k sits in lane k
+// of every row; row_share again.  (Rounds 2-4 went through LDS for the first layer: products written [channel][unit], read back
+// [unit][channel] -- two LDS round trips in the middle of a dependent chain, twice per CTFA.)
+__device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1x)[4], float b1_u, const f32x4 (&w2)[4], float b2) {
   float h0 = 0.f, h1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; i += 2) {
-    h0 += lds1(scr_b + ((qtr * 16 + i) * 20 + u) * 4);
-    h1 += lds1(scr_b + ((qtr * 16 + i + 1) * 20 + u) * 4);
-  }
-  float hsum = h0 + h1;
-  hsum = xor32_sum(xor16_sum(hsum));
+  sfor<8>([&](auto kk) {
+    constexpr int k = 2 * decltype(kk)::value;
+    h0 = fmaf(w1x[k >> 2][k & 3], dpp_mov<0x150 + k>(in), h0);
+    h1 = fmaf(w1x[(k + 1) >> 2][(k + 1) & 3], dpp_mov<0x150 + k + 1>(in), h1);
+  });
+  const float hsum = xor32_sum(xor16_sum(h0 + h1));
   const float hid = fmaxf(hsum + b1_u, 0.f);
   float a0 = b2, a1 = 0.f;
-  // hidden unit k sits in lane k of every row of 16 (the sums above made the four rows equal): DPP row_share hands it to the whole
-  // row inside the FMA's operand fetch (a v_readlane per unit went through an SGPR, with its wait states)
   sfor<8>([&](auto kk) {
     constexpr int k = 2 * decltype(kk)::value;
     a0 = fmaf(w2[k >> 2][k & 3], dpp_mov<0x150 + k>(hid), a0);
     a1 = fmaf(w2[(k + 1) >> 2][(k + 1) & 3], dpp_mov<0x150 + k + 1>(hid), a1);
   });
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   return a0 + a1;
 }
 
@@ -1400,11 +1404,11 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Car
 #pragma unroll
     for (int r = 0; r < 8; ++r) m += lds1(PARTR + sb + (r * 64 + lane) * 4);
     m = m * (1.0f / d.F);
-    const float ta = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t, MSCR + sb, lane));
+    const float ta = fast_sigmoid(gate_mlp(m, w1t, b1t, w2t, b2t));
     FZ_STAMP(I, 2);
     // (frame mode: ta_prev = 0 and the ring is one dump row -- proposed.py:179-183 with T = 1; causal32: the offline model's 32-frame
     //  average, proposed.py:143-147, the history in a ring of 32 rows per stage outside the arena, engine.cpp nutls_set_ctfa_mode)
-    const float fa = fast_sigmoid(gate_mlp((ta_prev + ta) * (1.0f / 32.0f), w1f, b1f, w2f, b2f, MSCR + sb, lane));
+    const float fa = fast_sigmoid(gate_mlp((ta_prev + ta) * (1.0f / 32.0f), w1f, b1f, w2f, b2f));
     stb1(cx.ta_ring, static_cast<unsigned>(((cx.stream + d.g0 + wave) * cx.ta_ring_sstride + d.bidx * cx.ta_ring_gstride + lane) * 4), ta);
     lds1(GATE + sb + lane * 4) = fa * ta;
   }
@@ -1638,11 +1642,13 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
   //  all ops -- the 4-stream build spills it and re-loads it in every op prologue.  200 scratch loads fewer there, no change in its step
   //  time; the one-stream kernel 1 % slower (0.3777 -> 0.3813 ms, four alternating runs on one box).  Dropped.)
   if (PROF && cx.prof && tid == 0) cx.prof[I] = wall_clock64();
+  FZ_WSTAMP(I, 0);
   // Drain point of an LSTM / CTFA op: every wave waits for its own earlier HBM stores BEFORE it issues this op's loads (a
   // wait at the end of the op would also wait for those loads -- a full HBM round trip per drain point); the op's own
   // barriers then order the completed stores before every load a later op issues (the planner's hand-off rule).
   constexpr bool DRAIN_FIRST = d.drain && (d.type == T_LSTM || d.type == T_CTFA);
   if constexpr (DRAIN_FIRST) drain_vm();
+  FZ_WSTAMP(I, 2);
   // loads in the order they are needed: parts this op stores itself, its epilogue parameters, what the next op needs first
   f32x4 p1[cmax(1, nxt_regs(I, 1))];
   f32x4 p3[cmax(1, own_regs(I, 3))];
@@ -1669,6 +1675,7 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
   prefetch_y<I + 2>(cx, tid, n.yp2);
   sched_pin();
   FZ_STAMP(I, 0);
+  FZ_WSTAMP(I, 1);
 
   if constexpr (d.type == T_INPUT) {
     input_op<I>(cx, tid);
@@ -1692,7 +1699,9 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
     }
   }
   if constexpr (d.drain && !DRAIN_FIRST) drain_vm();
+  FZ_WSTAMP(I, 9);
   lds_barrier();
+  FZ_WSTAMP(I, 10);
 }
 
 // ROLE: the program this instantiation belongs to -- 0 serving waves (0..3), 1 matrix waves (4..7) of a kernel whose plan has role ops
@@ -1824,6 +1833,7 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.ta_sum_gstride = a.ta.sum_gstride;
   cx.ta_ring_sstride = a.ta.ring_sstride;
   cx.ta_ring_gstride = a.ta.ring_gstride;
+  cx.eager = a.ta.eager;
 #if FZ_BASE
   {
     // one pass over the 13 parameter records of the dilated-dense ops: they stay in the scalar cache for the rest of

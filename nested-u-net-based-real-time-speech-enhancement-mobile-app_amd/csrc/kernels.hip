@@ -952,6 +952,25 @@ hipError_t launch_ta_sum(const float* ring, float* sum, int slot, int B, hipStre
   return hipGetLastError();
 }
 
+// Lazily written state tensors of the fused kernel (fused_plan.hpp OpD::d0_on = 2, engine.cpp states_materialize): the input state of a
+// strided conv holds the same rows as the skip-connection slice of the stage's sub-pixel conv input, which the kernel does write.
+// grid = (entries, B), 256 threads: float4 copies of rows x width floats.
+__global__ __launch_bounds__(256) void lazy_states_kernel(float* arena, long long sstride, int block_off, const LazyCopy* tab) {
+  const LazyCopy c = tab[blockIdx.x];
+  float* base = arena + static_cast<size_t>(blockIdx.y) * sstride + block_off;
+  const int w4 = c.width / 4, n = c.rows * w4;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = i / w4, q = i % w4;
+    *reinterpret_cast<float4*>(base + c.dst_off + r * c.dst_ld + 4 * q) = *reinterpret_cast<const float4*>(base + c.src_off + r * c.src_ld + 4 * q);
+  }
+}
+
+hipError_t launch_lazy_states(float* arena, long long sstride, int block_off, const LazyCopy* tab, int n, int B, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lazy_states_kernel, dim3(n, B), dim3(256), 0, s, arena, sstride, block_off, tab);
+  return hipGetLastError();
+}
+
 __global__ void set_step_kernel(int* step, int value) { *step = value; }
 
 hipError_t launch_set_step(int* step, int value, hipStream_t s) {

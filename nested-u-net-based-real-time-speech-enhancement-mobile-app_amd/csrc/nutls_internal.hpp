@@ -199,7 +199,13 @@ struct FzTa {
   // (rides along: start skew of the workgroups, in units of 64 clocks -- workgroup w sleeps (w mod 4) * skew before its first op, so that
   //  the HBM bursts of the op sequence, which all workgroups of a launch walk in lock step, spread out; 0 = off.  NUTLS_FUSED_SKEW.)
   int skew;
+  // (rides along too: 1 = the launch also writes the state tensors nothing in the kernel reads -- the input states of the strided convs,
+  //  OpD::d0_on = 2 --, 0 = it leaves them to engine.cpp states_materialize, which rebuilds them from their second copy when asked)
+  int eager;
 };
+// the lazily written state tensors of a fused plan: P rows x 32 channels, copied from the skip-connection slice the kernel does write
+struct LazyCopy { int src_off, src_ld, dst_off, dst_ld, rows, width; };      // float offsets inside a parity block of the arena
+hipError_t launch_lazy_states(float* arena, long long sstride, int block_off, const LazyCopy* tab, int n, int B, hipStream_t s);
 hipError_t launch_ta_sum(const float* ring, float* sum, int slot, int B, hipStream_t s);
 hipError_t launch_fused_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
                              unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
@@ -207,6 +213,7 @@ hipError_t launch_fused_base_step(float* arena, long long sstride, const float* 
                                   unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
 hipError_t fused_step_set_attributes();
 hipError_t fused_base_step_set_attributes();
+void fused_lazy_table(int variant, std::vector<LazyCopy>* tab);      // (one-stream plans; empty when the plan writes every state)
 enum FusedPack : int { FZ_PACK_OK = 0, FZ_PACK_NOT_INT8 = 1, FZ_PACK_MALFORMED = 2 };
 int fused_pack_blob(int variant, const WeightMap& wm, std::vector<float>* out, std::string* err, int streams = 1);      // -> FusedPack
 // packed plans (several streams per workgroup, fused_plan.hpp OpD::gs): the LSTM variant has one for 2 streams (fused_step_g2.hip).  Same

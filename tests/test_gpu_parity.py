@@ -179,6 +179,30 @@ def test_torch_device_tensors_zero_copy(clip):
     eng.close(); host.close()
 
 
+def test_lazily_written_states_match_eager_ones(clip, monkeypatch):
+    """The fused kernel leaves the 40 conv-input states it never reads unwritten (fused_plan.hpp OpD::d0_on = 2) and the library rebuilds them
+    from their second copy when a state accessor / another mode looks: every state tensor, after every one of several frames, must be
+    bit-identical to what a handle that writes everything on every frame holds -- and a per-layer step taken from such a handle must see
+    the same inputs (same output)."""
+    monkeypatch.setenv("NUTLS_EAGER_STATES", "1")
+    eager = NutlsEngine(batch=3)
+    monkeypatch.delenv("NUTLS_EAGER_STATES")
+    lazy = NutlsEngine(batch=3)
+    names = [n for n, _ in lazy.state_specs()]
+    for i in range(5):
+        x = clip["mags_in"][i:i + 3]
+        a, b = eager.step(x), lazy.step(x)
+        assert np.array_equal(a, b)
+        if i in (0, 3, 4):          # (frames 1 and 2 go by without anybody looking: two stale parities behind the accessors)
+            for n in names:
+                assert np.array_equal(eager.state_get(n), lazy.state_get(n)), (i, n)
+    lazy.step(clip["mags_in"][5:8]); eager.step(clip["mags_in"][5:8])
+    lazy.set_mode("launches"); eager.set_mode("launches")      # the per-layer kernels read every conv-input state
+    x = clip["mags_in"][6:9]
+    assert np.array_equal(eager.step(x), lazy.step(x))
+    eager.close(); lazy.close()
+
+
 def test_state_get_set_reset_round_trip(clip):
     eng = NutlsEngine(batch=2)
     for i in range(3):

@@ -29,17 +29,21 @@ def plan_tag(variant, G=1):
     return ("lstm" if variant == "lstm" else "base") + ("" if G == 1 else "_g%d" % G)
 
 
+OUT_DIR = os.environ.get("NUTLS_PLAN_OUT")      # developer knob (tools/exp/build_role_lib.sh): write the plans (and their dumps) here, not into the tree
+
+
 def inc_path(variant, G=1):
-    return os.path.join(PKG, "csrc", "fused_plan_%s.inc" % plan_tag(variant, G))
+    return os.path.join(OUT_DIR or os.path.join(PKG, "csrc"), "fused_plan_%s.inc" % plan_tag(variant, G))
 
 
 def json_path(variant, G=1):
-    return os.path.join(ROOT, "tests", "golden", "fused_plan_%s.json" % plan_tag(variant, G))
+    return os.path.join(OUT_DIR or os.path.join(ROOT, "tests", "golden"), "fused_plan_%s.json" % plan_tag(variant, G))
 
 
 # the plans that are built into the library: (variant, streams per workgroup)
 PLANS = [("lstm", 1), ("baseline", 1), ("lstm", 2), ("lstm", 4)]
 KFIRST = os.environ.get("NUTLS_PLAN_KFIRST", "1") != "0"    # K-split-first tilings of the small layers (developer knob: 0 = the round-4 tilings)
+LAZY = os.environ.get("NUTLS_PLAN_LAZY", "1") != "0"        # strided convs' input states written lazily (OpD::d0_on = 2)
 ROLES = os.environ.get("NUTLS_PLAN_ROLES", "0") != "0"      # role ops in the one-stream plans (developer knob: 0 = the round-4 tilings)
 
 # (prefix, depth, f0, conv state tag, sub-pixel state tag, resample layer)   converter_proposed.py:221-727
@@ -898,6 +902,37 @@ def build_for(variant, G, cls):
             assert len(prod) == 1, (o["name"], "producer of the residual rows")
             issue = o["idx"] - 2
             assert ensure_drained(prod[0], issue), (o["name"], "no drain point between", prod[0], "and the prefetch in", issue)
+    # ---- lazily written states (one-stream plans): the output rows of a strided conv go to TWO state tensors -- the input state of the next
+    # strided conv (d0: `*_prev{i+1}`, the signature's echo of that conv's input) and the skip-connection slice of the sub-pixel conv's input
+    # state (d1).  The kernel reads the second one (a staged part of the decoder side); the first one it never reads: the next strided conv
+    # takes the rows from LDS.  Such a d0 is marked `lazy` (OpD::d0_on = 2): a launch writes it only when the handle asks for eager states;
+    # otherwise the library rebuilds it from the d1 copy when somebody outside the kernel looks (engine.cpp states_materialize).
+    for o in ops:
+        o["lazy0"] = 0
+    if G == 1 and LAZY:
+        def overlap(a, b):      # (off, rows, ld, width): row-strided regions of floats
+            (ao, ar, al, aw), (bo, br, bl, bw) = a, b
+            if ao + (ar - 1) * al + aw <= bo or bo + (br - 1) * bl + bw <= ao:
+                return False
+            if al != bl:
+                return True          # (different pitches: the coarse answer)
+            d = bo - ao              # b's first element relative to a's, in a's row grid
+            r, c = d // al, d % al   # (floor: c in [0, ld))
+            cols = c < aw or c + bw > al          # b's columns [c, c + bw) meet a's [0, aw) -- directly or wrapped into the next row
+            rows = r < ar and r + br > 0 if c < aw else r + 1 < ar and r + 1 + br > 0
+            return cols and rows
+        readers = []
+        for q in ops:
+            for pp in q.get("parts", []):
+                if pp["src"] in (S_CUR, S_PREV):
+                    readers.append((pp["off"], pp["rows"], pp["ld"], 4 * pp["c4s"]))
+            if q["type"] == T_CTFA:
+                readers.append((q["e0_off"], q["F"], q["e0_ld"], 64))
+        for o in ops:
+            if o["type"] == T_CONV and o["kind"] == K_EL and o["d0"] and o["d1"] and o["d0"][0] == S_CUR and o["d1"][0] == S_CUR and o["R"] == 1:
+                a = (o["d0"][1], o["P"], o["d0"][2], o["N"])
+                if not any(overlap(a, b) for b in readers):
+                    o["lazy0"] = 1
     return A, W, ops
 
 
@@ -927,8 +962,8 @@ def c_fwd(f):
                                            f["gstride_b"], f["mask"])
 
 
-def c_dst(d):
-    return "0,0,0,0" if d is None else "1,%d,%d,%d" % d
+def c_dst(d, lazy=0):
+    return "0,0,0,0" if d is None else "%d,%d,%d,%d" % ((2 if lazy else 1,) + tuple(d))
 
 
 def pad(lst, n):
@@ -957,7 +992,7 @@ def emit(A, W, ops, G=1):
                "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d, /*role*/ %d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
-            o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
+            o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"], o["lazy0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
             c_fwd(o["fwd"]), c_img(o), o["nxt"],
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
             1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["x_fmt"], o["x_plane_b"], o["lw_off"],
