@@ -243,6 +243,21 @@ def other_config_records(local_rank):
                "ms_per_step": round(ms, 4), "steps": k, "window_ms": round(1e3 * dt, 2), "streams_per_workgroup": getattr(eng, "streams_per_workgroup", 1),
                "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBS, 4),
                             "algorithmic_bytes_per_launch": alg}}
+        # measured HBM traffic of the launch (PMC record of THIS kernel: profiles/pmc_traffic_baseline.json / pmc_traffic_g<streams>.json)
+        spw = rec["streams_per_workgroup"]
+        tpath = pmc_traffic_path(variant, spw)
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if t.get("variant", "lstm") == variant and t.get("kernel_source_sha16") == kernel_source_sha16("fused", variant, spw) and t.get("batch"):
+                traffic = int(round(t["traffic_bytes"] * B / t["batch"]))
+                rec["roofline"]["traffic"] = traffic
+                tg = traffic / (ms * 1e-3) / 1e9
+                rec["roofline"]["hbm_measured"] = {"achieved": round(tg, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(tg / PEAK_HBM_GBS, 4),
+                                                   "over_algorithmic": round(traffic / alg, 3)}
+                if t["batch"] != B:
+                    rec["roofline"]["hbm_measured"]["note"] = "scaled by the stream count from the PMC record at B = %d" % t["batch"]
+                if host_io:
+                    rec["roofline"]["hbm_measured"]["note"] = (rec["roofline"]["hbm_measured"].get("note", "") + "; the launch time of this configuration includes the two PCIe copies").lstrip("; ")
         if host_io:
             rec["step_latency_ms"] = rec["ms_per_step"]
             rec["real_time_budget_ms"] = 16.0

@@ -380,11 +380,28 @@ constexpr int ext_sf(int i) {
   return (extra > 0 && extra <= EXT_MAX) ? extra : 0;
 }
 
+// CTFA column sums in the epilogue of the stage's last sub-pixel conv (converter_proposed.py:257-263: the CTFA averages that conv's output
+// over frequency): the row-wise epilogue has every output row in registers, so each thread adds its rows up, the four lanes of a wave that
+// hold the same channel quad meet through two lane swaps, and every wave leaves one partial row in the CTFA's scratch (above the
+// epilogue's own parameter block).  The CTFA op then starts at its gate perceptrons: no pass over the image to form the sums, one
+// barrier less.  One-stream plans, 16x16-tile producers (the two 32x32-tile ones would need 160 lane-exchange steps per wave).
+constexpr int CSUM_OFF_B = 1792;       // inside the CTFA's scratch: 8 waves x 64 floats
+constexpr bool feeds_ctfa_sums(int i) {
+  return FZ_CTFA_PRESUM && NSTREAMS == 1 && i >= 0 && i + 1 < kNumOps && kOps[i + 1].type == T_CTFA && kOps[i].type == T_CONV && kOps[i].path == P_X16B &&
+         kOps[i].gc == 64 && !role_of(kOps[i]) && nparams(kOps[i]) * 4 <= CSUM_OFF_B;
+}
+// ... and such a CTFA op has nothing left to hide the fetch of its gate perceptrons behind (the column-sum pass did): they are requested at the
+// END of the conv op before it -- late enough to cost that op's MFMA loop no registers -- and travel in the Carry.
+#ifndef FZ_EARLY_GATES
+#define FZ_EARLY_GATES 1
+#endif
+constexpr bool early_gates(int i) { return FZ_EARLY_GATES && i >= 1 && i < kNumOps && kOps[i].type == T_CTFA && feeds_ctfa_sums(i - 1); }
 // What travels in registers from op I-1 to op I: the first weight fragments of op I (or the LSTM's input
 // weights / the CTFA's residual rows and gate matrices) and the far-ahead staged parts of the image op I completes.
 template <int I>
 struct Carry {
   f32x4 w[cmax(1, carry_w(I))];
+  f32x4 cg[early_gates(I) ? 17 : 1];      // CTFA whose column sums come with the rows: its gate perceptrons (16 float4 of the wave that evaluates them + biases), requested at the END of the op before
   f32x4 wb[cmax(1, role_nf(I))];          // role op whose predecessor is a role op: ALL its fragments as bf16 (matrix waves), widened by the op before
   f32x4 p[cmax(1, nxt_regs(I, 2))];
   f32x4 p4[cmax(1, own_regs(I, 4))];      // the previous-frame tap of op I's own two-round image, requested by op I-1 (all threads hold it)
@@ -765,16 +782,6 @@ __device__ __forceinline__ bool fwd_has(int gi) {
   if constexpr (!d.fwd.on || d.fwd.mask == 0) return false;
   else if constexpr (fwd_all(d)) return true;
   else return ((d.fwd.mask >> gi) & 1) != 0;
-}
-// CTFA column sums in the epilogue of the stage's last sub-pixel conv (converter_proposed.py:257-263: the CTFA averages that conv's output
-// over frequency): the row-wise epilogue has every output row in registers, so each thread adds its rows up, the four lanes of a wave that
-// hold the same channel quad meet through two lane swaps, and every wave leaves one partial row in the CTFA's scratch (above the
-// epilogue's own parameter block).  The CTFA op then starts at its gate perceptrons: no pass over the image to form the sums, one
-// barrier less.  One-stream plans, 16x16-tile producers (the two 32x32-tile ones would need 160 lane-exchange steps per wave).
-constexpr int CSUM_OFF_B = 1792;       // inside the CTFA's scratch: 8 waves x 64 floats
-constexpr bool feeds_ctfa_sums(int i) {
-  return FZ_CTFA_PRESUM && NSTREAMS == 1 && i >= 0 && i + 1 < kNumOps && kOps[i + 1].type == T_CTFA && kOps[i].type == T_CONV && kOps[i].path == P_X16B &&
-         kOps[i].gc == 64 && !role_of(kOps[i]) && nparams(kOps[i]) * 4 <= CSUM_OFF_B;
 }
 // does op I feed an LSTM / dilated-dense op (which reads its rows as fp32 from XCOPY_B)?
 constexpr bool feeds_x(int i) { return i + 1 < kNumOps && (kOps[i + 1].type == T_LSTM || kOps[i + 1].type == T_DDB); }
@@ -1182,6 +1189,16 @@ __device__ __forceinline__ void input_op(const Ctx& cx, int tid) {
   }
 }
 
+// what op I requests for the ops after it: the far-ahead staged parts of the next image but one, the first weights / parameters / carried
+// sums of op I + 2
+template <int I>
+__device__ __forceinline__ void late_loads(const Ctx& cx, int tid, Carry<I + 1>& n) {
+  stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
+  stage_load<I + 1, 4, THREADS>(cx, tid, n.p4);
+  prefetch_w<I + 2>(cx, tid, n.w2, n.prm2);
+  prefetch_y<I + 2>(cx, tid, n.yp2);
+}
+
 // An LSTM / CTFA op in front of a role op: waves 4..7 -- the role op's matrix waves -- widen its int8 weights (requested two ops ago, in
 // c.w2) to bf16 while a few threads of the low waves evaluate the gates.  ROLE: 1 the matrix waves' program of a two-program kernel, 2 the
 // one program of a kernel that branches per role op, 0 the serving waves' program (nothing to do).
@@ -1254,6 +1271,7 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
   FZ_WSTAMP(I, 3);
   lds_barrier();
   FZ_WSTAMP(I, 4);
+  if constexpr (ROLE == 1) { late_loads<I>(cx, tid, n); sched_pin(); }
   widen_next<I, ROLE, 0, 2>(tid, c, n);    // (waves 4..7, while 21 threads evaluate the gates: the bf16 weights of the role op that follows, first half)
   if (tid < 21 * GS) {          // thread (stream slot gi, unit uu): the unit's four gates
     const int gi = GS > 1 ? tid / 21 : 0, uu = GS > 1 ? tid % 21 : tid;
@@ -1342,6 +1360,29 @@ __device__ __forceinline__ float gate_mlp(float in, const f32x4 (&w1x)[4], float
   return a0 + a1;
 }
 
+// gate perceptrons of CTFA op J (the wave that evaluates them -- wave gi for stream slot gi -- holds, per lane, 16 weights of each of the four
+// matrices): g[0..3] ta first layer (lane-major), [4..7] ta second layer, [8..11] / [12..15] the same for fa, g[16] = (b1t, b2t, b1f, b2f)
+template <int J>
+__device__ __forceinline__ void gates_load(const Ctx& cx, int tid, f32x4 (&g)[17]) {
+  constexpr OpD d = kOps[J];
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave < d.gs) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      g[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + lane * 16 + 4 * q) * 4));
+      g[4 + q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 1040 + lane * 16 + 4 * q) * 4));
+      g[8 + q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + lane * 16 + 4 * q) * 4));
+      g[12 + q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 3168 + lane * 16 + 4 * q) * 4));
+    }
+    g[16][0] = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 1024 + (lane & 15)) * 4));
+    g[16][1] = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2064 + lane) * 4));
+    g[16][2] = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 1024 + (lane & 15)) * 4));
+    g[16][3] = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 2064 + lane) * 4));
+  } else {
+    opaque_regs(g);
+  }
+}
+
 // ---- CTFA gate + residual (ctfa_rt, proposed.py:162-196), in place on the next image; the network's last
 //      one also applies the output 1x1 conv (proposed.py:65) and writes the enhanced magnitudes ---------------------------
 template <int I, int ROLE>
@@ -1356,18 +1397,19 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Car
   // sub-pixel conv 64 registers.)
   float b1t = 0.f, b1f = 0.f, b2t = 0.f, b2f = 0.f, ta_prev = 0.f;
   f32x4 w1t[4], w2t[4], w1f[4], w2f[4];
-  if (wave < GS) {
+  {
+    f32x4 g[17];
+    if constexpr (early_gates(I)) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      w1t[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + lane * 16 + 4 * q) * 4));                  // ta w1T [64][16]
-      w2t[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 1040 + lane * 16 + 4 * q) * 4));           // ta w2  [64][16]
-      w1f[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + lane * 16 + 4 * q) * 4));           // fa w1T
-      w2f[q] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 3168 + lane * 16 + 4 * q) * 4));           // fa w2
+      for (int k = 0; k < 17; ++k) g[k] = c.cg[k];
+    } else {
+      gates_load<I>(cx, tid, g);
     }
-    b1t = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 1024 + (lane & 15)) * 4));
-    b2t = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2064 + lane) * 4));
-    b1f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 1024 + (lane & 15)) * 4));
-    b2f = ldb1(cx.wb, static_cast<unsigned>((d.cw_off + 2128 + 2064 + lane) * 4));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { w1t[q] = g[q]; w2t[q] = g[4 + q]; w1f[q] = g[8 + q]; w2f[q] = g[12 + q]; }
+    b1t = g[16][0]; b2t = g[16][1]; b1f = g[16][2]; b2f = g[16][3];
+  }
+  if (wave < GS) {
     // frequency branch: the sum of the time attention over the 31 frames before this one (causal32 mode; a vector of zeros in the
     // default frame mode, where the branch sees TA / 32 -- SURVEY F7), stage d.bidx of this wave's stream
     ta_prev = ldb1(cx.ta_sum, static_cast<unsigned>(((cx.stream + d.g0 + wave) * cx.ta_sum_sstride + d.bidx * cx.ta_sum_gstride + lane) * 4));
@@ -1397,6 +1439,7 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Car
     FZ_STAMP(I, 5);
   }
   FZ_STAMP(I, 1);
+  if constexpr (ROLE == 1) { late_loads<I>(cx, tid, n); sched_pin(); }
   widen_next<I, ROLE>(tid, c, n);            // (waves 4..7, while wave 0 evaluates the gate perceptrons)
   if (wave < GS) {
     const int sb = wave * SGB;          // this wave's stream slot
@@ -1664,15 +1707,16 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
       stage_load<I, 3, ST>(cx, tid - (THREADS - ST), p3);
     }
   }
-  stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
-  stage_load<I + 1, 4, THREADS>(cx, tid, n.p4);
+  // (matrix waves' program of a run of role ops, LSTM / CTFA op: what the next ops need from these waves is requested in the shadow of the
+  //  gates instead -- late_loads --: their prologue is the heavier one (all fragments of a role op's task, the staged parts dealt from the
+  //  top) and made them 400 cycles late for the op's first barrier)
+  constexpr bool LATE = ROLE == 1 && is_gate_op(I);
+  if constexpr (!LATE) late_loads<I>(cx, tid, n);
 #pragma unroll
   for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
   n.prm = c.prm2;
 #pragma unroll
   for (int k = 0; k < cmax(1, yp_regs(I + 1)); ++k) n.yp[k] = c.yp2[k];
-  prefetch_w<I + 2>(cx, tid, n.w2, n.prm2);
-  prefetch_y<I + 2>(cx, tid, n.yp2);
   sched_pin();
   FZ_STAMP(I, 0);
   FZ_WSTAMP(I, 1);
@@ -1699,6 +1743,7 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
     }
   }
   if constexpr (d.drain && !DRAIN_FIRST) drain_vm();
+  if constexpr (early_gates(I + 1)) gates_load<I + 1>(cx, tid, n.cg);      // (the next op is a CTFA that starts at its gate perceptrons)
   FZ_WSTAMP(I, 9);
   lds_barrier();
   FZ_WSTAMP(I, 10);
