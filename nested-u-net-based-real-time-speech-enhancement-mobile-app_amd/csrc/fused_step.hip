@@ -313,6 +313,9 @@ constexpr bool is_gate_op(int i) { return i >= 0 && i < kNumOps && (kOps[i].type
 #ifndef FZ_SETPRIO
 #define FZ_SETPRIO 1
 #endif
+#ifndef FZ_LDS_FIRST
+#define FZ_LDS_FIRST 1
+#endif
 #ifndef FZ_CTFA_PRESUM
 #define FZ_CTFA_PRESUM 1
 #endif
@@ -389,6 +392,19 @@ constexpr int CSUM_OFF_B = 1792;       // inside the CTFA's scratch: 8 waves x 6
 constexpr bool feeds_ctfa_sums(int i) {
   return FZ_CTFA_PRESUM && NSTREAMS == 1 && i >= 0 && i + 1 < kNumOps && kOps[i + 1].type == T_CTFA && kOps[i].type == T_CONV && kOps[i].path == P_X16B &&
          kOps[i].gc == 64 && !role_of(kOps[i]) && nparams(kOps[i]) * 4 <= CSUM_OFF_B;
+}
+// The skip-connection copy of a 32x32-tile sub-pixel conv's output in front of a CTFA (msfe6_en_spconv6: 128 rows x 128 channels) leaves the
+// conv's epilogue as 16-byte pieces of 32 different rows per store instruction -- 3.3 us of memory-pipe time in that one op (its epilogue 4.9 us
+// against 1.6 us for its decoder twin, which has no such copy).  The CTFA op re-reads every row anyway when it applies the gates, one row per
+// 16 lanes: it writes the copy from there, 256 contiguous bytes per row.  MEASURED (profiles/r05_role_dev_log.txt `dd0`): the conv's epilogue
+// 19.1 -> 15.5 us over the 32x32-tile ops, the CTFA's gate application 7.2 -> 10.3 us -- the cost is the 16 MB burst of all workgroups at once,
+// not the shape of the stores.  Off.
+#ifndef FZ_DEFER_D0
+#define FZ_DEFER_D0 0
+#endif
+constexpr bool defer_d0(int i) {
+  return FZ_DEFER_D0 && NSTREAMS == 1 && i >= 0 && i + 1 < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32B && kOps[i].d0_on == 1 && !kOps[i].d1_on &&
+         kOps[i].d0_src == S_CUR && kOps[i].gc == 64 && kOps[i + 1].type == T_CTFA && !kOps[i + 1].last;
 }
 // ... and such a CTFA op has nothing left to hide the fetch of its gate perceptrons behind (the column-sum pass did): they are requested at the
 // END of the conv op before it -- late enough to cost that op's MFMA loop no registers -- and travel in the Carry.
@@ -836,10 +852,13 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
       const int row = pos * d.row_mul + d.row_add + r;
       const unsigned go = gofs(cx, d.g0 + gi);
       if constexpr (CSUM) cs += v;
-      if constexpr (d.d0_on && !(FZ_ABL & 4)) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v); }
-      if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v);
+      // (the rows of the next image first: the next op's MFMAs wait for them behind the barrier; the HBM copies are nobody's critical path,
+      //  and a store that has to queue behind the op's prefetches at the memory pipe would hold the LDS writes back with it)
       if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, 4 * li, v); }
       if constexpr (feeds_x(I)) lds4(d.xcopy_b + gi * 1024 + (row * GC + 4 * li) * 4) = v;
+      if constexpr (FZ_LDS_FIRST) sched_pin();
+      if constexpr (d.d0_on && !(FZ_ABL & 4)) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v); }
+      if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v);
     }
   });
   if constexpr (CSUM) {
@@ -1148,7 +1167,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
           const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
           const int cc = c0 + 8 * q + 4 * h;
           if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, cc, v); }
-          if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v); }
+          if constexpr (d.d0_on && !defer_d0(I)) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v); }
           if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4) + go, v);
         }
       }
@@ -1465,7 +1484,9 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Car
     for (int i = 0; i < NI; ++i) {
       const int f = rg + 32 * i;
       if (f < d.F) {
-        const f32x4 y = fwd_ld4g<I>(gi, f, 4 * c4) * g4 + c.w[gi * NI + i];      // (re-read: cheaper than 32 registers held across the gates)
+        const f32x4 x = fwd_ld4g<I>(gi, f, 4 * c4);      // (re-read: cheaper than 32 registers held across the gates)
+        if constexpr (defer_d0(I - 1)) stb(cx.sbc, static_cast<unsigned>((kOps[I - 1].d0_off + f * kOps[I - 1].d0_ld + 4 * c4) * 4), x);      // (the conv's skip-connection copy, see defer_d0)
+        const f32x4 y = x * g4 + c.w[gi * NI + i];
         if constexpr (d.last) {
           const float s = group_sum<16>(y[0] * ow[0] + y[1] * ow[1] + y[2] * ow[2] + y[3] * ow[3]);
           if (c4 == 0) cx.io_out[(d.g0 + gi) * 256 + f] = s + ob;
