@@ -313,6 +313,16 @@ constexpr bool is_gate_op(int i) { return i >= 0 && i < kNumOps && (kOps[i].type
 #ifndef FZ_SETPRIO
 #define FZ_SETPRIO 1
 #endif
+// LSTM ops of the one-stream plans: the 21 gate threads sit on wave 7 (which has no K slice of the first phase), and what the op requests
+// for the ops after it goes out in the shadow of the gates (waves 0..6) and of the Dense rows (wave 7) instead of in front of the first
+// phase -- profiles/r05_v4_wave_trace.txt: 650 cycles of load issue on the waves that hold the last K slices, in front of the op's first barrier.
+// MEASURED (profiles/r05_role_dev_log.txt `w7`): the LSTM ops 19.1 -> 16.7 us in the profiling twin, but the ops behind them wait longer for
+// what was requested later (wwait 5.4 -> 6.6 us) and the production build is 1 % SLOWER (0.364-0.366 against 0.359-0.362 ms): its ops are
+// tighter than the twin's (no stamps), a prefetch issued 1 us later arrives late.  Off.
+#ifndef FZ_LSTM_W7
+#define FZ_LSTM_W7 0
+#endif
+constexpr int lstm_gate_tid0(const OpD& d) { return (FZ_LSTM_W7 && kStreams == 1 && d.gs == 1 && d.dout <= 448) ? 448 : 0; }
 #ifndef FZ_LDS_FIRST
 #define FZ_LDS_FIRST 1
 #endif
@@ -658,7 +668,8 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
         constexpr int j = decltype(jj)::value;
         w[S0 + 2 + j] = ldb(cx.wb, static_cast<unsigned>((WD + drow * 24 + 4 * j) * 4));
       });
-      const int u21 = d.gs > 1 ? (tid < 21 * d.gs ? tid % 21 : 20) : (tid < 21 ? tid : 20);
+      constexpr int GT0 = lstm_gate_tid0(d);      // first gate thread (one-stream plans: on wave 7)
+      const int u21 = d.gs > 1 ? (tid < 21 * d.gs ? tid % 21 : 20) : ((tid >= GT0 && tid < GT0 + 21) ? tid - GT0 : 20);
       const int g21 = d.gs > 1 ? (tid < 21 * d.gs ? tid / 21 : d.gs - 1) : 0;          // the stream slot whose cell state this thread updates
       w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((BIAS + 4 * u21) * 4));
       w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4) + gofs(cx, d.g0 + g21));
@@ -1290,13 +1301,23 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
   FZ_WSTAMP(I, 3);
   lds_barrier();
   FZ_WSTAMP(I, 4);
+  constexpr int GT0 = lstm_gate_tid0(d);
+  constexpr bool W7 = GT0 != 0 && ROLE == 2;      // (see lstm_gate_tid0: the op's prefetches in the shadow of its gates / Dense rows)
   if constexpr (ROLE == 1) { late_loads<I>(cx, tid, n); sched_pin(); }
+  if constexpr (W7) {
+    static_assert(d.dout <= 448, "wave 7 has no Dense row");
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) != 7) late_loads<I>(cx, tid, n);
+    sched_pin();
+  }
   widen_next<I, ROLE, 0, 2>(tid, c, n);    // (waves 4..7, while 21 threads evaluate the gates: the bf16 weights of the role op that follows, first half)
-  if (tid < 21 * GS) {          // thread (stream slot gi, unit uu): the unit's four gates
-    const int gi = GS > 1 ? tid / 21 : 0, uu = GS > 1 ? tid % 21 : tid;
-    f32x4 z = c.w[S0 + 8];
+  if (tid >= GT0 && tid < GT0 + 21 * GS) {          // thread (stream slot gi, unit uu): the unit's four gates
+    const int gi = GS > 1 ? tid / 21 : 0, uu = GS > 1 ? tid % 21 : tid - GT0;
+    f32x4 zz[4];
 #pragma unroll
-    for (int s2 = 0; s2 < 20; ++s2) z += lds4(PART + gi * SGB + (s2 * 21 + uu) * 16);
+    for (int q = 0; q < 4; ++q) zz[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 20; ++s2) zz[s2 & 3] += lds4(PART + gi * SGB + (s2 * 21 + uu) * 16);      // (four chains: the twenty partial rows are not one dependent sum)
+    const f32x4 z = c.w[S0 + 8] + ((zz[0] + zz[1]) + (zz[2] + zz[3]));
     const float c_old = c.w[S0 + 9][0];
     const float gi_ = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
     const float c_new = gf * c_old + gi_ * gg;
@@ -1309,6 +1330,10 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
   FZ_WSTAMP(I, 5);
   lds_barrier();
   FZ_WSTAMP(I, 6);
+  if constexpr (W7) {
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 7) late_loads<I>(cx, tid, n);      // (the gate wave's share, beside the Dense rows)
+    sched_pin();
+  }
   widen_next<I, ROLE, 1, 2>(tid, c, n);    // (second half, beside the Dense rows of the low waves)
   // Dense: output n of stream gi by thread (gi * dout + n) mod 512 (its row of the Dense kernel arrived in the carry: 512 is a multiple
   // of dout, so a thread's row is the same in every pass)
@@ -1731,7 +1756,7 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
   // (matrix waves' program of a run of role ops, LSTM / CTFA op: what the next ops need from these waves is requested in the shadow of the
   //  gates instead -- late_loads --: their prologue is the heavier one (all fragments of a role op's task, the staged parts dealt from the
   //  top) and made them 400 cycles late for the op's first barrier)
-  constexpr bool LATE = ROLE == 1 && is_gate_op(I);
+  constexpr bool LATE = (ROLE == 1 && is_gate_op(I)) || (ROLE == 2 && d.type == T_LSTM && lstm_gate_tid0(d) != 0);
   if constexpr (!LATE) late_loads<I>(cx, tid, n);
 #pragma unroll
   for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
