@@ -58,7 +58,9 @@ int nutls_create(const void* weights, size_t n_bytes, int variant, int batch, in
 
 /* nutls_create with the fused kernel's plan chosen by the caller: streams_per_workgroup = 0 (the library's choice, = nutls_create), 1, 2 or
  * 4 (see nutls_streams_per_workgroup).  An explicit count the batch is not a multiple of, or one the variant has no plan for (3, 8, ...;
- * the baseline variant has the one-stream plan only) is NUTLS_ERR_ARG -- an explicit request never silently becomes another plan. */
+ * the baseline variant has the one-stream plan only) is NUTLS_ERR_ARG; an explicit count (1, 2, 4) with a container the fused kernel
+ * cannot run -- conv kernels not stored as int8 -- is NUTLS_ERR_WEIGHTS with the reason in nutls_last_error (nutls_create would run such a
+ * container on the per-layer kernels, mode 1).  An explicit request never silently becomes another plan or another kernel family. */
 int nutls_create_plan(const void* weights, size_t n_bytes, int variant, int batch, int device, int streams_per_workgroup,
                       nutls_handle** out);
 
@@ -159,7 +161,11 @@ int nutls_use_graph(nutls_handle* h, int enable);
  * (The fused kernel does not write the 40 conv-input states it never reads itself -- the echoes of the strided convs' inputs,
  * converter_proposed.py:226-231 -- on every frame: their rows exist a second time as skip-connection slices of other states, and the
  * library rebuilds them from there before any of the accessors below, a step of another mode or nutls_reset looks at the states.
- * What a caller sees is what the reference's runner returns, frame by frame; NUTLS_EAGER_STATES=1 makes every launch write everything.) */
+ * What a caller sees is what the reference's runner returns, frame by frame; NUTLS_EAGER_STATES=1 makes every launch write everything.)
+ * nutls_state_set and the causal32 CTFA of a streaming handle: the 31-frame time-attention history (nutls_set_ctfa_mode) is library state
+ * outside the signature's tensors and nutls_state_set does not touch it -- the buffers are [B, ...], so "get, change stream b's row, set"
+ * leaves the other B - 1 live streams exactly as they were.  To start a NEW utterance in stream b from loaded states, call
+ * nutls_reset(h, b) first (zeroes b's states and its history), then set. */
 int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
 int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, size_t n_floats);
 

@@ -143,7 +143,6 @@ struct Engine {
   bool off_bf16 = false;          // block mode: convs on the bf16 matrix pipe where the container holds int8 kernels (NUTLS_OFFLINE_FP32=1: the fp32-MFMA kernels)
   float* zx = nullptr;   // [offline + kScanReadAhead][84] LSTM input products of a block
   int ctfa_causal = 0;   // offline handles: 1 = true 32-frame causal average in the CTFA frequency branch (proposed.py:143-147)
-  bool ta_ring_cleared_by_set = false;   // streaming causal32: nutls_state_set cleared the history ring since the last step
   float* ta_hist = nullptr;   // [12 stages][31 + offline][64] time-attention history (causal mode)
   // block pipeline of an offline handle: the block is cut into chunks of consecutive frames, chunk c runs on its own
   // HIP stream one bottleneck behind chunk c-1 (every layer is causal in time: frame t needs frames <= t only)
@@ -895,6 +894,10 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
     // does not match ... -- is not an error of the handle: the per-layer modes only need the de-quantised floats, the handle
     // runs on them (hipGraph replay, mode 1, chosen at the end of nutls_create), and nutls_set_mode(3) reports the reason kept here.
     e->fz_reason = err;
+    // ... unless the caller asked for a plan of the fused kernel by name (nutls_create_plan): that request never silently becomes another
+    // plan or another kernel family
+    if (e->fz_streams_req > 0)
+      return fail(NUTLS_ERR_WEIGHTS, "nutls_create_plan: the container cannot run on the fused kernel (" + err + "); nutls_create picks the per-layer kernels for it");
     return NUTLS_OK;
   }
   void* p = nullptr;
@@ -1006,8 +1009,8 @@ static int capture_graphs(Engine* e) {
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     int rc = run_plan(e, par, e->stream);
     hipError_t ee = hipStreamEndCapture(e->stream, &g);
-    if (rc) return rc;
-    if (ee != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }      // (a launch failed during capture: the half-built graph is not kept)
+    if (ee != hipSuccess) { if (g) (void)hipGraphDestroy(g); return fail(NUTLS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee)); }
     hipError_t ie = hipGraphInstantiate(&e->gexec[par], g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
@@ -1511,7 +1514,6 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   if (!direct && mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
   e->next_parity = 1 - par;
   e->steps += 1;
-  e->ta_ring_cleared_by_set = false;
   return NUTLS_OK;
 }
 
@@ -1641,12 +1643,9 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
   HIP_TRY(hipDeviceSynchronize());
   if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), const_cast<float*>(host_buf), false, 0);
   e->ys_dirty = true;      // a conv-input state changed under the fused kernel's carried partial sums: rebuilt before its next step
-  // causal32 CTFA: the 31-frame time-attention history is state that is not among the ABI's tensors; a caller that loads states starts new
-  // utterances (the migration path), which must not inherit the previous occupants' history (nutls.h, nutls_set_ctfa_mode)
-  if (e->fz_ta_ring && e->ctfa_causal && !e->ta_ring_cleared_by_set) {
-    HIP_TRY(hipMemset(e->fz_ta_ring, 0, static_cast<size_t>(e->B) * 12 * 32 * 64 * sizeof(float)));
-    e->ta_ring_cleared_by_set = true;      // (once per burst of nutls_state_set calls: the next step re-arms it)
-  }
+  // (causal32 CTFA: the 31-frame time-attention history of a streaming handle is library state outside the ABI's tensors.  It is NOT touched
+  //  here: nutls_state_set takes [B, ...] buffers, and the per-stream workflow -- get, change one stream's row, set -- must leave the other
+  //  B - 1 live streams alone.  A caller that loads a new utterance into stream b calls nutls_reset(h, b) first: nutls.h, nutls_state_set.)
   if (st->ring_d > 1) {
     std::vector<float> tmp(host_buf, host_buf + n_floats);
     rotate_ring(e, *st, tmp.data(), false);
@@ -1848,7 +1847,6 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n) {
   for (auto& x : ev) (void)hipEventDestroy(x);
   e->next_parity = 1 - par;
   e->steps += 1;
-  e->ta_ring_cleared_by_set = false;
   return NUTLS_OK;
 }
 
@@ -1923,7 +1921,6 @@ int nutls_profile_fused(nutls_handle* h, double* us, int n) {
   for (int i = 0; i < n; ++i) us[i] = static_cast<double>(t[i + 1] - t[i]) * 1000.0 / khz;
   e->next_parity = 1 - par;
   e->steps += 1;
-  e->ta_ring_cleared_by_set = false;
   if (const char* wt = getenv("NUTLS_FUSED_WTRACE")) {       // debugging aid: the raw per-wave trace [8 waves][ops][12] of an FZ_WTRACE build (zeros otherwise)
     std::vector<unsigned long long> tr(static_cast<size_t>(n) * 8 * 12);
     HIP_TRY(hipMemcpy(tr.data(), e->fz_prof + static_cast<size_t>(n) * 9 + 1, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

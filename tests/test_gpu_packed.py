@@ -48,6 +48,15 @@ def test_plan_choice_follows_the_stream_count():
     eng = NutlsEngine(batch=8, streams_per_workgroup=4)
     assert eng.streams_per_workgroup == 4
     eng.close()
+    # a container the fused kernel cannot run (float conv kernels): the library's own choice falls to the per-layer kernels, an explicit
+    # plan request says why it cannot be met (include/nutls.h, nutls_create_plan)
+    from nunet_amd.weights import synthetic_weights, write_blob
+    float_blob = write_blob(synthetic_weights("lstm", seed=3))
+    eng = NutlsEngine(batch=2, weights=float_blob)
+    assert eng.mode != "fused"
+    eng.close()
+    with pytest.raises(RuntimeError, match="fused kernel"):
+        NutlsEngine(batch=2, weights=float_blob, streams_per_workgroup=1)
 
 
 @pytest.mark.parametrize("G", [2, 4])
