@@ -36,8 +36,18 @@ FLOPS_PER_FRAME = 2 * 73_967_252
 PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (2.4 GHz)
 PEAK_HBM_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
-# SURVEY.md section 8(d), end-to-end minimum per frame and stream: state read once + written once + frame I/O
-ALG_BYTES_PER_FRAME = {"lstm": 2 * 820_360 + 2 * 1_024, "baseline": 2 * 1_647_616 + 2 * 1_024}
+# SURVEY.md section 8(d), end-to-end minimum per frame and stream: state read once + written once + frame I/O.
+# Baseline variant: SURVEY's figure (2 x 1 647 616 B) charges the WHOLE dilated-dense history in and out every frame -- what the reference's
+# functional state protocol moves (converter_nunet_tls.py:1420-1427 shifts every ring by one frame).  A design that keeps the histories as
+# in-place rings -- this one, and any sensible one -- must move, per bottleneck and frame, prev_in [F, C], prev_out [F, G] and ONE slot
+# [F, k G] of each of the six rings, read once and written once: 2 F (C + G + 21 G) floats = 24 F C with G = C / 2; the 12 stage bottlenecks
+# (C = 32, F = 4 4 4 2 1 1 | 1 1 2 4 4 4) and the central one (C = 64, F = 4): 24 x (32 x 32 + 4 x 64) = 30 720 floats.  The conv states
+# are the LSTM variant's without its 26 h / c vectors (204 544 floats, read once + written once).  Charging the whole history credited the
+# kernel with bytes it never moves (round 5: `over_algorithmic` 0.69).
+BASELINE_CONV_STATE_FLOATS = 204_544
+BASELINE_RING_FLOATS_PER_FRAME = 24 * (32 * 32 + 4 * 64)
+ALG_BYTES_PER_FRAME = {"lstm": 2 * 820_360 + 2 * 1_024,
+                       "baseline": 4 * (2 * BASELINE_CONV_STATE_FLOATS + BASELINE_RING_FLOATS_PER_FRAME) + 2 * 1_024}
 HOP_SECONDS = 0.016
 PKG = os.path.join(ROOT, "nested-u-net-based-real-time-speech-enhancement-mobile-app_amd")
 
@@ -66,6 +76,15 @@ def pmc_traffic_path(variant="lstm", streams=1):
     if streams > 1:
         return os.path.join(ROOT, "profiles", "pmc_traffic_g%d.json" % streams)
     return os.path.join(ROOT, "profiles", "pmc_traffic.json" if variant == "lstm" else "pmc_traffic_%s.json" % variant)
+
+
+def scale_traffic(t, B, blob_bytes):
+    """HBM bytes per launch at B streams from a PMC record taken at t["batch"] streams: only the per-stream part scales -- the weight
+    blob is read once per launch whatever the stream count."""
+    if t["batch"] == B:
+        return int(t["traffic_bytes"])
+    per_stream = (t["traffic_bytes"] - blob_bytes) / t["batch"]
+    return int(round(per_stream * B + blob_bytes))
 
 
 def fused_kernel_name(variant, streams=1):
@@ -249,13 +268,13 @@ def other_config_records(local_rank):
         if os.path.exists(tpath):
             t = json.load(open(tpath))
             if t.get("variant", "lstm") == variant and t.get("kernel_source_sha16") == kernel_source_sha16("fused", variant, spw) and t.get("batch"):
-                traffic = int(round(t["traffic_bytes"] * B / t["batch"]))
+                traffic = scale_traffic(t, B, eng.weight_blob_bytes())
                 rec["roofline"]["traffic"] = traffic
                 tg = traffic / (ms * 1e-3) / 1e9
                 rec["roofline"]["hbm_measured"] = {"achieved": round(tg, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(tg / PEAK_HBM_GBS, 4),
                                                    "over_algorithmic": round(traffic / alg, 3)}
                 if t["batch"] != B:
-                    rec["roofline"]["hbm_measured"]["note"] = "scaled by the stream count from the PMC record at B = %d" % t["batch"]
+                    rec["roofline"]["hbm_measured"]["note"] = "per-stream part scaled by the stream count from the PMC record at B = %d (the weight blob counted once)" % t["batch"]
                 if host_io:
                     rec["roofline"]["hbm_measured"]["note"] = (rec["roofline"]["hbm_measured"].get("note", "") + "; the launch time of this configuration includes the two PCIe copies").lstrip("; ")
         if host_io:
@@ -415,6 +434,18 @@ def main():
     # steady clocks (tools/gpu_cold_start.py), and the driver's window -- 5 warm-up + 20 timed steps -- is 10 ms.  The
     # metric is a steady-state rate, so the device is brought to steady clocks with the same step before the W warm-up steps; the timed
     # region below is still exactly --steps steps behind exactly --warmup warm-up steps.
+    # ... and the same W + K steps are timed once BEFORE the conditioning (`value_unconditioned`: what the driver's arguments measure on a GPU
+    # that was idle), so that every line shows what the conditioning is worth on its box
+    uncond = None
+    if args.condition_ms > 0 and not selftest and world == 1:
+        for s in range(args.warmup):
+            one_step(s)
+        sync()
+        tu = time.perf_counter()
+        for s in range(args.steps):
+            one_step(s)
+        sync()
+        uncond = time.perf_counter() - tu
     cond_steps = 0
     if args.condition_ms > 0 and not selftest:
         tc = time.perf_counter()
@@ -468,6 +499,9 @@ def main():
             # `roofline` below re-times the kernel over its own >= 100 ms window
             "timed_window_ms": round(1e3 * max_elapsed, 3), "short_window": bool(max_elapsed < 0.1),
             "conditioning_ms": args.condition_ms if cond_steps else 0, "conditioning_steps": cond_steps,
+            # the same --warmup + --steps window on the GPU as this process found it, before any conditioning
+            "value_unconditioned": round(B * args.steps / uncond, 1) if uncond else None,
+            "ms_per_step_unconditioned": round(1e3 * uncond / args.steps, 4) if uncond else None,
             "collective": {"backend": proof["backend"], "ranks_reduced": proof["ranks_reduced"],
                            "per_rank_frames_per_s": [round(x, 1) for x in proof["per_rank"]]},
         }
@@ -535,8 +569,8 @@ def kernel_report(args, eng, pool, out, B, mode):
                 elif spw > 1 and t.get("batch"):
                     # packed plans: one record (B = 1024); the traffic of a launch is per-stream state traffic + the L2-resident weight blob,
                     # so another multiple of the plan's round of workgroups scales with the stream count
-                    traffic = int(round(t["traffic_bytes"] * B / t["batch"]))
-                    traffic_note = "scaled by the stream count from the PMC record at B = %d" % t["batch"]
+                    traffic = scale_traffic(t, B, eng.weight_blob_bytes())
+                    traffic_note = "per-stream part scaled by the stream count from the PMC record at B = %d (the weight blob counted once)" % t["batch"]
         # Lower bounds of one launch: HBM = SURVEY 8(d)'s end-to-end minimum (every state tensor read once and
         # written once, + the frame I/O) x streams + the weight blob once, at 8 TB/s; MFMA = the conv FLOPs on the pipe the
         # kernel actually uses.  The fused kernel computes every fp32 product as THREE bf16 MFMAs (error-free split of the

@@ -183,7 +183,17 @@ int nutls_reset(nutls_handle* h, int stream_idx);
 
 /* Copy the last step's value of an internal activation to the host (testing / debugging):
  * "<stage>.y" (CTFA output [B,F0,64]), "<stage>.up" (decoder up-sampled input [B,F0,128]),
- * "input_layer" ([B,256,64]). */
+ * "input_layer" ([B,256,64]).  Per-layer modes (0 / 1): the last stage's tensors ("msfe6_de.y", "msfe6_de.up": the layers share one scratch
+ * tensor per kind) and "input_layer".  Fused mode: these tensors never leave LDS; with nutls_debug_trace(h, 1) every step of a one-stream
+ * fused handle (<= 64 streams) runs on the library's profiling build of the step kernel, which copies them out -- "<stage>.y" of all 12
+ * stages, "<stage>.up" of the 6 decoder stages, "input_layer" of the LAST step -- for layer-by-layer comparison with a reference trace
+ * (tests/test_gpu_trace.py).  Testing / debugging only: the profiling build is a few percent slower. */
+int nutls_debug_trace(nutls_handle* h, int enable);
+/* Developer knobs of a handle (timing experiments; no effect on results).  "skew": start skew of the fused kernel's workgroups -- workgroup w
+ * sleeps (w mod 4) * value * 64 clocks before its first op (0 = off, the default; NUTLS_FUSED_SKEW sets it at creation).  Experiment builds
+ * of the step kernel (tools/exp/build_plan_lib.sh ... -DFZ_STOPAT=1) read the same field as "stop after this many ops", which is how
+ * tools/exp/prod_timeline.py times the UN-instrumented kernel op by op.  Unknown names: NUTLS_ERR_ARG. */
+int nutls_debug_knob(nutls_handle* h, const char* name, int value);
 int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
 
 int nutls_batch(nutls_handle* h);

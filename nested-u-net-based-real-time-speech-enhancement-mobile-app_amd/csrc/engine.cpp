@@ -161,6 +161,9 @@ struct Engine {
   // CTFA frequency branch of the fused kernel (nutls_internal.hpp FzTa): fz_ta_zero = 64 zeros + a dump row (frame mode); causal32 mode of a
   // streaming handle (nutls_set_ctfa_mode): history ring [B][12][32][64] and the per-step sums [B][12][64]
   float *fz_ta_zero = nullptr, *fz_ta_ring = nullptr, *fz_ta_sum = nullptr;
+  float* fz_dbg_buf = nullptr;
+  int fz_skew = 0;             // FzTa::skew of the fused launches (start skew of the workgroups; experiment builds of the kernel: see nutls_debug_knob)
+  float* fz_dbg = nullptr;     // activation trace [B][kDbgSlots][kDbgSlotFloats] (nutls_debug_trace): steps then run on the profiling build, which fills it
   std::string fz_reason;                 // why there is none (what the packer said), for nutls_set_mode(3)
   unsigned long long* fz_prof = nullptr; // op boundary stamps of workgroup 0 (profiling build)
   int n_cu = 256;
@@ -940,6 +943,7 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
     e->d_lazy = static_cast<LazyCopy*>(lz);
   }
   if (const char* ev = getenv("NUTLS_EAGER_STATES")) e->eager_states = atoi(ev) != 0;      // (developer knob: every launch writes every state)
+  if (const char* ev = getenv("NUTLS_FUSED_SKEW")) e->fz_skew = atoi(ev);
   return NUTLS_OK;
 }
 
@@ -973,13 +977,15 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* 
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
   if (int rc = ysum_refresh(e, par, s)) return rc;
   auto launch = base ? launch_fused_base_step : (e->fz_streams == 4 ? launch_fused_step_g4 : (e->fz_streams == 2 ? launch_fused_step_g2 : launch_fused_step));
-  static const int skew = [] { const char* v = getenv("NUTLS_FUSED_SKEW"); return v ? atoi(v) : 0; }();
+  const int skew = e->fz_skew;      // (NUTLS_FUSED_SKEW at creation, nutls_debug_knob(h, "skew", v) later)
   const int eager = (e->eager_states || !e->n_lazy) ? 1 : 0;
-  FzTa ta{e->fz_ta_zero, e->fz_ta_zero + 64, 0, 0, 0, 0, skew, eager};
+  float* const dbg = prof ? e->fz_dbg : nullptr;      // (activation trace: the profiling builds only)
+  const long long dbg_ss = static_cast<long long>(kDbgSlots) * kDbgSlotFloats;
+  FzTa ta{e->fz_ta_zero, e->fz_ta_zero + 64, 0, 0, 0, 0, skew, eager, dbg, dbg_ss};
   if (e->ctfa_causal && e->fz_ta_ring) {
     const int slot = static_cast<int>(e->steps & 31);          // this frame's row of the history: the sums leave it out, the step overwrites it
     HIP_TRY(launch_ta_sum(e->fz_ta_ring, e->fz_ta_sum, slot, e->B, s));
-    ta = FzTa{e->fz_ta_sum, e->fz_ta_ring + slot * 64, 12 * 64, 64, 12 * 32 * 64, 32 * 64, skew, eager};
+    ta = FzTa{e->fz_ta_sum, e->fz_ta_ring + slot * 64, 12 * 64, 64, 12 * 32 * 64, 32 * 64, skew, eager, dbg, dbg_ss};
   }
   hipError_t err = launch(e->arena, static_cast<long long>(e->sstride), e->fz_blob, mag_in ? mag_in : e->io_in,
                           mag_out ? mag_out : e->io_out, e->B, par, prof ? e->fz_prof : nullptr,
@@ -1498,7 +1504,7 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   if (e->mode != 3)
     if (int rc = states_materialize(e, s)) return rc;      // (the per-layer kernels read every conv-input state)
   if (e->mode == 3) {
-    int rc = run_fused(e, par, s, false, mag_in, mag_out);
+    int rc = run_fused(e, par, s, e->fz_dbg != nullptr, mag_in, mag_out);
     if (rc) return rc;
   } else if (e->mode == 1) {
     e->ys_dirty = true;
@@ -1749,12 +1755,56 @@ int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n
       return NUTLS_OK;
     }
   }
+  if (e->fz_dbg && e->mode == 3) {
+    // activation trace of the fused kernel's profiling build (nutls_debug_trace): "<stage>.y" of all 12 stages, "<stage>.up" of the 6
+    // decoder stages, "input_layer" -- tensors the fused kernel keeps in LDS
+    const std::string nm(name);
+    int slot = -1;
+    size_t per = 0;
+    if (nm == "input_layer") { slot = 0; per = 256 * 64; }
+    for (int s = 0; s < 6 && slot < 0; ++s) {
+      if (nm == std::string(kEncoder[s].prefix) + ".y") { slot = 1 + s; per = static_cast<size_t>(kEncoder[s].f0) * 64; }
+      else if (nm == std::string(kDecoder[s].prefix) + ".y") { slot = 7 + s; per = static_cast<size_t>(kDecoder[s].f0) * 64; }
+      else if (nm == std::string(kDecoder[s].prefix) + ".up") { slot = 13 + s; per = static_cast<size_t>(kDecoder[s].f0) * 128; }
+    }
+    if (slot >= 0) {
+      if (n_floats != per * e->B) return fail(NUTLS_ERR_ARG, std::string("size mismatch for debug tensor ") + name);
+      HIP_TRY(hipSetDevice(e->device));
+      HIP_TRY(hipDeviceSynchronize());
+      for (int b = 0; b < e->B; ++b)
+        HIP_TRY(hipMemcpy(host_buf + per * b, e->fz_dbg + (static_cast<size_t>(b) * kDbgSlots + slot) * kDbgSlotFloats, per * sizeof(float), hipMemcpyDeviceToHost));
+      return NUTLS_OK;
+    }
+  }
   auto it = e->debug.find(name);
   if (it == e->debug.end()) return fail(NUTLS_ERR_ARG, std::string("unknown debug tensor: ") + name);
   if (n_floats != it->second.second * e->B) return fail(NUTLS_ERR_ARG, std::string("size mismatch for debug tensor ") + name);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
   return copy_stream_tensor(e, it->second.first, it->second.second, host_buf, true);
+}
+
+int nutls_debug_knob(nutls_handle* h, const char* name, int value) {
+  if (!h || !name) return fail(NUTLS_ERR_ARG, "nutls_debug_knob: null pointer");
+  Engine* e = &h->eng;
+  if (std::strcmp(name, "skew") == 0) { e->fz_skew = value; return NUTLS_OK; }
+  return fail(NUTLS_ERR_ARG, std::string("nutls_debug_knob: unknown knob ") + name);
+}
+
+int nutls_debug_trace(nutls_handle* h, int enable) {
+  if (!h) return fail(NUTLS_ERR_ARG, "nutls_debug_trace: null handle");
+  Engine* e = &h->eng;
+  if (!enable) { e->fz_dbg = nullptr; return NUTLS_OK; }      // (the buffer stays allocated with the handle)
+  if (e->offline || !e->fz_blob) return fail(NUTLS_ERR_ARG, "nutls_debug_trace: the activation trace is the fused kernel's (streaming handle, int8 container)");
+  if (e->fz_streams != 1) return fail(NUTLS_ERR_ARG, "nutls_debug_trace: the packed plans have no profiling build in the library (nutls_create_plan(..., 1) for the one-stream plan)");
+  if (e->B > 64) return fail(NUTLS_ERR_ARG, "nutls_debug_trace: at most 64 streams (2.5 MB of trace per stream)");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->fz_dbg_buf) {
+    int rc = dev_alloc(e, static_cast<size_t>(e->B) * kDbgSlots * kDbgSlotFloats, &e->fz_dbg_buf, true);
+    if (rc) return rc;
+  }
+  e->fz_dbg = e->fz_dbg_buf;
+  return NUTLS_OK;
 }
 
 static const char* family_name(const Launch& L, int B) {

@@ -80,7 +80,8 @@ struct OpD {
   // ---- all -------------------------------------------------------------------------------------
   int drain;                               // every wave drains its memory counter before the op's last barrier
   int bidx;                                // T_DDB (baseline variant): which of the 13 dilated-dense bottlenecks (uses x_cols, y_b, x_pitch_b);
-                                           // T_CTFA: which of the 12 CTFAs (encoder stages 0..5, decoder stages 6..11): row of FzTa::sum / ring
+                                           // T_CTFA: which of the 12 CTFAs (encoder stages 0..5, decoder stages 6..11): row of FzTa::sum / ring;
+                                           // up-sampling convs: which decoder stage (slot of the layer's output in the activation trace, FzTa::dbg)
   // ---- carried partial sums (two-tap convs) ------------------------------------------------------
   int ys;                                  // 1: y_t = W[tap 1] x_t + S_{t-1} with S_t = W[tap 0] x_t: the image holds x_t only, S travels through HBM as
                                            // P x N fp32 ([pos][packed channel], unscaled integer-weight sums), block kYsOff + parity * kYsBlock
@@ -98,12 +99,28 @@ struct OpD {
   int xcopy_b;                             // fp32 copy of the rows an LSTM / dilated-dense op reads, stream i at xcopy_b + i * 1024 (one-stream plans: XCOPY_B)
   int x_gstride_b;                         // LSTM: LDS bytes between the sub-images (of the conv that follows) it writes its streams' rows into
   int layer;                               // index of the layer (= op index of the one-stream plan) this op is an instance of
-  // ---- role ops (one-stream plans; fused_step.hip run_role_op) -----------------------------------------
-  // 1: a small 16x16-tile conv op (one position tile, <= 4 channel tiles) whose four wave tasks run on waves 4..7 -- B reads, MFMAs,
-  // partial tiles; their weights arrive as bf16 fragments, widened by those waves at the end of the op before -- while waves 0..3
-  // issue the staging loads, run the row-wise epilogue and complete the next image.
-  int role;
+  // ---- small 16x16-tile conv ops (planner: tools/gen_fused_plan.py conv_op) ---------------------------------------------------------
+  // epl 1: row-wise epilogue with ONE output element per lane (a row of gc channels = gc consecutive lanes) for layers with at most 512
+  // outputs: the K-slice sums, LayerNorm, PReLU and the three-plane split are ~50 dependent VALU instructions per wave instead of ~110
+  // on the one or two waves that hold all rows as float4 (epl 4) -- the epilogue is the critical path of a small op
+  int epl;
 };
+// ---- blob layout of an LSTM + Dense op (OpD::lw_off; kernel: prefetch_w / lstm_op, host: fused_host_impl.inc, planner: gen_fused_plan.py) --
+// The reference's .tflite stores the LSTM kernels int8 with one scale per tensor (FULLY_CONNECTED, hybrid) and so does the blob: four
+// times fewer bytes through the CU's memory pipe than fp32 (an LSTM's 51 KB of fp32 parameters were a 1 us burst in the op that prefetches
+// them).  z = b + s_x (Qx x) + s_h (Qh h): the scale is applied to the K-slice sums, as in the convs.
+//   gates  : [20 K slices][21 units][NRP dwords], dword j = the (i, f, g, o) int8 weights of the unit for row j of the slice -- slices 0..15: KN =
+//            din / 16 rows of x each, 16..19: 6 rows of h each (rows 21..23 zero); NRP = the row count rounded up to whole float4s
+//   record : [21][4] fp32 bias (i, f, g, o) | s_x, s_h, 0, 0
+//   dense  : per output n 8 dwords -- 24 int8 (21 weights, 3 zero) | fp32 bias | fp32 scale (dout >= 64: the tensors TF-Lite quantises, >= 1024
+//            elements), or 24 fp32 (21 weights, bias, 0, 0) for the 32 x 21 ones it leaves in fp32
+constexpr int lstm_kn(int din) { return din / 16; }
+constexpr int lstm_nrp(int din) { return ((lstm_kn(din) > 6 ? lstm_kn(din) : 6) + 3) / 4 * 4; }
+constexpr bool lstm_dense_i8(int dout) { return dout >= 64; }
+constexpr int lstm_gates_f(int din) { return 20 * 21 * lstm_nrp(din); }
+constexpr int lstm_rec_f() { return 88; }
+constexpr int lstm_dense_row_f(int dout) { return lstm_dense_i8(dout) ? 8 : 24; }
+constexpr int lstm_blob_f(int din, int dout) { return lstm_gates_f(din) + lstm_rec_f() + lstm_dense_row_f(dout) * dout; }
 constexpr int DDB_LDS_B = 64 * 1024;       // LDS scratch of a dilated-dense block op (17 920 floats), above the image it completes
 
 }  // namespace fz

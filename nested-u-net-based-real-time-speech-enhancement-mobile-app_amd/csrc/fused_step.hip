@@ -45,19 +45,15 @@
 #ifndef FZ_PROF
 #define FZ_PROF 0
 #endif
+// FZ_STOPAT (experiment builds only): FzTa::skew is read as "end the launch in front of op <skew>" -- the production instruction stream plus one
+// scalar compare per op: launches of growing length time the UN-instrumented kernel op by op (tools/exp/prod_timeline.py)
+#ifndef FZ_STOPAT
+#define FZ_STOPAT 0
+#endif
 // FZ_BASE = 1: the baseline variant's build (fused_base.hip): same ops, the LSTM + Dense bottlenecks replaced by the
 // dilated-dense blocks of models/nunet_tls.py:277-359 (plan fused_plan_base.inc)
 #ifndef FZ_BASE
 #define FZ_BASE 0
-#endif
-// FZ_ABL: timing experiments only (tools/exp): bit mask of parts that are compiled OUT -- the results are garbage, the step time
-// tells what the part costs.  1 halo zeroing, 2 staging (HBM -> image), 4 HBM stores of the row-wise epilogue, 16 LayerNorm / PReLU
-// of the row-wise epilogue, 32 LSTM body, 64 CTFA body, 128 workgroup barriers, 256 MFMA loops of the 16x16x32 path, 512 partial-sum
-// reads of the row-wise epilogue, 2048 weight prefetch of the conv ops (MFMAs kept, on garbage), 4096 MFMA loops of the 32x32x16 path,
-// 8192 previous-frame tap staging of the strided convs (the upper bound of carrying that tap as a partial sum instead); round 5, inside the
-// 16x16-tile MFMA loops: 0x10000 no int8 -> bf16 conversion of the weights, 0x20000 no LDS reads of the B fragments, 0x40000 no MFMAs
-#ifndef FZ_ABL
-#define FZ_ABL 0
 #endif
 // FZ_STREAMS = 2 / 4: the packed builds (fused_step_g2.hip / _g4.hip, plans fused_plan_lstm_g2.inc / _g4.inc): a workgroup owns that many
 // consecutive streams -- the layers whose images fit LDS that often run them side by side on one virtual position axis (one weight
@@ -114,7 +110,14 @@ struct Ctx {
   const DdbParams* ddb;        // baseline variant: the 13 dilated-dense blocks of this step's parity
   int stream, step;            // step: frame counter (position in the dilated-dense history rings)
   int eager;                   // write the state tensors nothing here reads too (OpD::d0_on = 2; FzTa::eager)
+  gcb_t dbg;                   // profiling builds: activation trace of this workgroup's first stream (FzTa::dbg), null = off
+  unsigned dbg_sstride_b;
+  int stop_at;                 // experiment builds (-DFZ_STOPAT=1, tools/exp/prod_timeline.py): the launch ends in front of this op
 };
+// Activation trace (profiling builds, nutls_debug_trace): the tensors the fused kernel keeps in LDS -- input layer, CTFA outputs, up-sampling
+// outputs -- are also copied to the trace buffer, slot `slot`, row-major [row][ld floats].  Compiled out of the production kernels.
+#define FZ_TRACE4(cx, g, slot, row, ld, c, v) do { if constexpr (FZ_PROF != 0) { if ((cx).dbg) \
+    stb((cx).dbg, static_cast<unsigned>((g) * (cx).dbg_sstride_b) + static_cast<unsigned>(((slot) * kDbgSlotFloats + (row) * (ld) + (c)) * 4), (v)); } } while (0)
 // does the launch write destination 0 of op d?  (d0_on 2: a conv-input state the kernel never reads -- only when the handle wants eager states)
 #define FZ_D0(d, cx) ((d).d0_on == 1 || ((d).d0_on == 2 && (cx).eager != 0))
 // byte offset of stream slot g's arena slice relative to the workgroup's first stream (added to the 32-bit offset of a load / store)
@@ -145,11 +148,7 @@ __device__ __forceinline__ float& lds1(int boff) { return *reinterpret_cast<floa
 __device__ __forceinline__ u32x2& lds2u(int boff) { return *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(lds) + boff); }
 __device__ __forceinline__ unsigned short& lds_h(int boff) { return *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(lds) + boff); }
 // workgroup barrier that orders LDS traffic only (global loads / stores stay in flight across it)
-#if FZ_ABL & 128
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 __device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <class F, int... Is>
@@ -192,6 +191,7 @@ __device__ __forceinline__ float group_sum(float s) {      // sum over LPG conse
   if (LPG >= 8) s += dpp_mov<0x141>(s);   // row_half_mirror
   if (LPG >= 16) s += dpp_mov<0x140>(s);  // row_mirror
   if (LPG >= 32) s = xor16_sum(s);
+  if (LPG >= 64) s = xor32_sum(s);
   return s;
 }
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -285,53 +285,12 @@ constexpr int ex_slices(const OpD& d) { return ksl(d) * (x16_both(d) ? 2 : 1); }
 constexpr int ex_group(const OpD& d) { return d.ys ? ex_slices(d) / 2 : ex_slices(d); }           // ... that add up to one result
 constexpr int nparams(const OpD& d) { return 2 * ntot(d) + 2 * d.gc + 1; }      // bias | weight scale | gamma | beta | alpha
 constexpr int conv_nsf(const OpD& d) { return (conv_nf(d) + 1) / 2; }             // "super-fragments": 2 int8 fragments = one dwordx4 per lane
-// Role ops (OpD::role, run_role_op): the four wave tasks of a small conv op run on waves 4..7 (the "matrix" waves), each with ALL the
-// fragments of its task in registers (no ring); waves 0..3 (the "serving" waves) issue the loads and run the row-wise epilogue.
-// (FZ_NOROLES / FZ_FORCE_SPLIT: timing experiments -- the role ops as plain conv ops with their four wave tasks on waves 0..3; the two
-//  programs without a role op in them)
-#ifndef FZ_NOROLES
-#define FZ_NOROLES 0
-#endif
-#ifndef FZ_FORCE_SPLIT
-#define FZ_FORCE_SPLIT 0
-#endif
-constexpr bool role_of(const OpD& d) { return !FZ_NOROLES && d.role != 0; }
-constexpr int ring_sf(const OpD& d) { return role_of(d) ? conv_nsf(d) : cmin(conv_nsf(d), d.path == P_R32B ? RING_SF_R32 : RING_SF); }
-constexpr bool is_role(int i) { return i >= 0 && i < kNumOps && kOps[i].type == T_CONV && role_of(kOps[i]); }
-// the weights of role op i arrive widened to bf16 (Carry::wb) when the op before it is a role op too: its matrix waves idle during the epilogue
-// (... or an LSTM / CTFA op, whose waves 4..7 idle while a few threads evaluate the gates)
-#ifndef FZ_WIDEN_GATES
-#define FZ_WIDEN_GATES 1
-#endif
-constexpr bool role_pre(int i) { return is_role(i) && (is_role(i - 1) || (FZ_WIDEN_GATES && i >= 1 && (kOps[i - 1].type == T_LSTM || kOps[i - 1].type == T_CTFA))); }
-constexpr int role_nf(int i) { return role_pre(i) ? conv_nf(kOps[i]) : 0; }
-constexpr bool is_gate_op(int i) { return i >= 0 && i < kNumOps && (kOps[i].type == T_LSTM || kOps[i].type == T_CTFA); }
-// FZ_SPLIT 1: two programs, one per wave role (every op instantiated twice); 0: one program, a wave branch inside every role op
-#ifndef FZ_SPLIT
-#define FZ_SPLIT 0
-#endif
-#ifndef FZ_SETPRIO
-#define FZ_SETPRIO 1
-#endif
-// LSTM ops of the one-stream plans: the 21 gate threads sit on wave 7 (which has no K slice of the first phase), and what the op requests
-// for the ops after it goes out in the shadow of the gates (waves 0..6) and of the Dense rows (wave 7) instead of in front of the first
-// phase -- profiles/r05_v4_wave_trace.txt: 650 cycles of load issue on the waves that hold the last K slices, in front of the op's first barrier.
-// MEASURED (profiles/r05_role_dev_log.txt `w7`): the LSTM ops 19.1 -> 16.7 us in the profiling twin, but the ops behind them wait longer for
-// what was requested later (wwait 5.4 -> 6.6 us) and the production build is 1 % SLOWER (0.364-0.366 against 0.359-0.362 ms): its ops are
-// tighter than the twin's (no stamps), a prefetch issued 1 us later arrives late.  Off.
-#ifndef FZ_LSTM_W7
-#define FZ_LSTM_W7 0
-#endif
-constexpr int lstm_gate_tid0(const OpD& d) { return (FZ_LSTM_W7 && kStreams == 1 && d.gs == 1 && d.dout <= 448) ? 448 : 0; }
-#ifndef FZ_LDS_FIRST
-#define FZ_LDS_FIRST 1
-#endif
-#ifndef FZ_CTFA_PRESUM
-#define FZ_CTFA_PRESUM 1
-#endif
-#ifndef FZ_MLOADS
-#define FZ_MLOADS 2
-#endif
+// The epilogue parameter block travels from L2 to LDS through one register per thread.  A vector load costs the CU's memory pipe by its WIDTH,
+// whatever its lanes fetch (tools/ubench/ta_cost.hip, profiles/r06_ubench_ta_cost.txt: a dwordx4 wave-load 14-18 cycles also when 63 lanes
+// re-fetch the last item, a dword wave-load 5.7), and every wave issues every load of a prefetch (no branch around a load): with at most 512
+// parameters each thread loads ONE float -- 8 dword wave-loads instead of 8 dwordx4 of which one or two carry anything.
+constexpr bool prm_dword(const OpD& d) { return nparams(d) <= THREADS; }
+constexpr int ring_sf(const OpD& d) { return cmin(conv_nsf(d), d.path == P_R32B ? RING_SF_R32 : RING_SF); }
 // staging classes of a part: 1 loaded and stored by the op that builds the image, 2 loaded one op earlier (carried); second-round parts
 // of a two-round image (stored in the middle of the op that OWNS the image): 3 loaded at the start of that op, 4 loaded one op earlier
 constexpr int part_cls(const Part& p) { return p.round2 ? (p.la == 2 ? 4 : 3) : p.la; }
@@ -340,7 +299,6 @@ constexpr int part_cls(const Part& p) { return p.round2 ? (p.la == 2 ? 4 : 3) : 
 // queue behind the staging loads on the (in-order) memory counter, and the staging waves' waits cost the MFMA waves nothing.
 // Class-2 parts (loaded one op before they are stored) stay with all threads: both ops must agree on who holds what.
 constexpr int stg_threads(int i) {
-  if (is_role(i)) return 256;      // (the serving waves 0..3: run_role_op)
   return (i >= 0 && i < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32B && kOps[i].PG * kOps[i].CG == 4 && !kOps[i].ys) ? 256 : THREADS;
 }
 constexpr int part_items(const Part& p) { return p.ng * p.rows * p.c4s; }      // (packed plans: the block once per stream)
@@ -364,9 +322,9 @@ constexpr int ctfa_ni(const OpD& d) { return (d.F + 31) / 32; }
 constexpr int yp_regs(int i) {
   if (i < 0 || i >= kNumOps || kOps[i].type != T_CONV || !kOps[i].ys) return 0;
   const OpD& d = kOps[i];
-  return d.path == P_R32B ? d.PT * d.NT * 4 : (d.gs * d.P * ntot(d) / 4 + THREADS - 1) / THREADS;
+  return d.path == P_R32B ? d.PT * d.NT * 4 : (d.epl == 1 ? 1 : (d.gs * d.P * ntot(d) / 4 + THREADS - 1) / THREADS);      // (epl 1: one float per thread)
 }
-constexpr int lstm_s0(const OpD& d) { return cmax(d.din / 16, 6); }      // carry slots of the gate weights (see lstm_op)
+constexpr int lstm_s0(const OpD& d) { return lstm_nrp(d.din) / 4; }      // carry slots of the gate weights: NRP int8x4 rows = NRP / 4 float4 (see lstm_op)
 constexpr int carry_w(int i) {
   if (i >= kNumOps) return 0;
   const OpD& d = kOps[i];
@@ -400,35 +358,18 @@ constexpr int ext_sf(int i) {
 // barrier less.  One-stream plans, 16x16-tile producers (the two 32x32-tile ones would need 160 lane-exchange steps per wave).
 constexpr int CSUM_OFF_B = 1792;       // inside the CTFA's scratch: 8 waves x 64 floats
 constexpr bool feeds_ctfa_sums(int i) {
-  return FZ_CTFA_PRESUM && NSTREAMS == 1 && i >= 0 && i + 1 < kNumOps && kOps[i + 1].type == T_CTFA && kOps[i].type == T_CONV && kOps[i].path == P_X16B &&
-         kOps[i].gc == 64 && !role_of(kOps[i]) && nparams(kOps[i]) * 4 <= CSUM_OFF_B;
+  return NSTREAMS == 1 && i >= 0 && i + 1 < kNumOps && kOps[i + 1].type == T_CTFA && kOps[i].type == T_CONV && kOps[i].path == P_X16B &&
+         kOps[i].gc == 64 && nparams(kOps[i]) * 4 <= CSUM_OFF_B && (kOps[i].epl != 1 || kOps[i].P * ntot(kOps[i]) == THREADS);
 }
-// The skip-connection copy of a 32x32-tile sub-pixel conv's output in front of a CTFA (msfe6_en_spconv6: 128 rows x 128 channels) leaves the
-// conv's epilogue as 16-byte pieces of 32 different rows per store instruction -- 3.3 us of memory-pipe time in that one op (its epilogue 4.9 us
-// against 1.6 us for its decoder twin, which has no such copy).  The CTFA op re-reads every row anyway when it applies the gates, one row per
-// 16 lanes: it writes the copy from there, 256 contiguous bytes per row.  MEASURED (profiles/r05_role_dev_log.txt `dd0`): the conv's epilogue
-// 19.1 -> 15.5 us over the 32x32-tile ops, the CTFA's gate application 7.2 -> 10.3 us -- the cost is the 16 MB burst of all workgroups at once,
-// not the shape of the stores.  Off.
-#ifndef FZ_DEFER_D0
-#define FZ_DEFER_D0 0
-#endif
-constexpr bool defer_d0(int i) {
-  return FZ_DEFER_D0 && NSTREAMS == 1 && i >= 0 && i + 1 < kNumOps && kOps[i].type == T_CONV && kOps[i].path == P_R32B && kOps[i].d0_on == 1 && !kOps[i].d1_on &&
-         kOps[i].d0_src == S_CUR && kOps[i].gc == 64 && kOps[i + 1].type == T_CTFA && !kOps[i + 1].last;
-}
-// ... and such a CTFA op has nothing left to hide the fetch of its gate perceptrons behind (the column-sum pass did): they are requested at the
+// Such a CTFA op has nothing left to hide the fetch of its gate perceptrons behind (the column-sum pass did): they are requested at the
 // END of the conv op before it -- late enough to cost that op's MFMA loop no registers -- and travel in the Carry.
-#ifndef FZ_EARLY_GATES
-#define FZ_EARLY_GATES 1
-#endif
-constexpr bool early_gates(int i) { return FZ_EARLY_GATES && i >= 1 && i < kNumOps && kOps[i].type == T_CTFA && feeds_ctfa_sums(i - 1); }
+constexpr bool early_gates(int i) { return i >= 1 && i < kNumOps && kOps[i].type == T_CTFA && feeds_ctfa_sums(i - 1); }
 // What travels in registers from op I-1 to op I: the first weight fragments of op I (or the LSTM's input
 // weights / the CTFA's residual rows and gate matrices) and the far-ahead staged parts of the image op I completes.
 template <int I>
 struct Carry {
   f32x4 w[cmax(1, carry_w(I))];
   f32x4 cg[early_gates(I) ? 17 : 1];      // CTFA whose column sums come with the rows: its gate perceptrons (16 float4 of the wave that evaluates them + biases), requested at the END of the op before
-  f32x4 wb[cmax(1, role_nf(I))];          // role op whose predecessor is a role op: ALL its fragments as bf16 (matrix waves), widened by the op before
   f32x4 p[cmax(1, nxt_regs(I, 2))];
   f32x4 p4[cmax(1, own_regs(I, 4))];      // the previous-frame tap of op I's own two-round image, requested by op I-1 (all threads hold it)
   f32x4 yp[cmax(1, yp_regs(I))];          // last frame's partial sums of op I (two-tap convs), requested two ops ahead like the weights
@@ -456,12 +397,12 @@ template <int NTHR>
 __device__ __forceinline__ int stage_slot(int tid, int shift) { return (2 * NTHR - 1 - tid - shift) & (NTHR - 1); }
 template <int J, int CLS, int NTHR, int NR>
 __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR]) {
-  if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 2)) {
+  if constexpr (J >= 0 && J < kNumOps) {
     constexpr Img g = kOps[J].img;
     sfor<g.nparts>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
       constexpr Part p = g.parts[K];
-      if constexpr (part_cls(p) == CLS && !((FZ_ABL & 8192) && p.src == S_PREV && kOps[J].kind == K_EL)) {
+      if constexpr (part_cls(p) == CLS) {
         constexpr int items = part_items(p), per = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s), NG = p.ng, PG0 = p.g0;
         const gcb_t src = p.src == S_PREV ? cx.sbp : (p.src == S_CUR ? cx.sbc : cx.sbs);
         const int slot = stage_slot<NTHR>(tid, part_shift(g, CLS, K, NTHR));
@@ -480,12 +421,12 @@ __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR
 }
 template <int J, int CLS, int NTHR, int NR>
 __device__ __forceinline__ void stage_store(int tid, const f32x4 (&r)[NR]) {
-  if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 2)) {
+  if constexpr (J >= 0 && J < kNumOps) {
     constexpr Img g = kOps[J].img;
     sfor<g.nparts>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
       constexpr Part p = g.parts[K];
-      if constexpr (part_cls(p) == CLS && !((FZ_ABL & 8192) && p.src == S_PREV && kOps[J].kind == K_EL)) {
+      if constexpr (part_cls(p) == CLS) {
         constexpr int items = part_items(p), per = p.rows * p.c4s, base = part_base(g, CLS, K, NTHR), cs = clog2(p.c4s), NG = p.ng;
         const int slot = stage_slot<NTHR>(tid, part_shift(g, CLS, K, NTHR));
         sfor<part_n(p, NTHR)>([&](auto ii) {
@@ -508,7 +449,7 @@ constexpr int zero_first(const Img& g) { return cmin(THREADS / 2, THREADS - zero
 constexpr int zero_start(const Img& g, int k) { int n = zero_first(g); for (int kk = 0; kk < k; ++kk) n += g.zero[kk].n4; return n; }
 template <int J>
 __device__ __forceinline__ void zero_halos(int tid) {
-  if constexpr (J >= 0 && J < kNumOps && !(FZ_ABL & 1)) {
+  if constexpr (J >= 0 && J < kNumOps) {
     constexpr Img g = kOps[J].img;
     static_assert(zero_total(g) <= THREADS, "halo blocks: one float4 per thread");
     if constexpr (g.nzero > 0) {
@@ -570,10 +511,8 @@ __device__ __forceinline__ void pin_regs(f32x4 (&r)[N]) {
   for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
 }
 
-// "Defined, contents unknown" without an instruction.  In a one-program kernel a role op assigns some carried registers in one of its two
-// wave branches only; on the other path they would be undefined -- and LLVM folds anything computed from phi(value, undef) into the block
-// that defines the value: the byte extraction of carried int8 weights moved up to their loads (a full memory round trip on the spot) and
-// travelled on as 16 separate byte registers.  An opaque definition on the other path keeps the phi a plain register phi.
+// "Defined, contents unknown" without an instruction: registers only one wave-branch loads (gates_load) get an opaque definition on the other path,
+// so that what is computed from them later stays a plain register phi (LLVM folds anything computed from phi(value, undef) into the defining block).
 template <int N>
 __device__ __forceinline__ void opaque_regs(f32x4 (&r)[N]) {
 #pragma unroll
@@ -586,7 +525,7 @@ template <int I>
 __device__ __forceinline__ Task conv_task(int wave) {
   constexpr OpD d = kOps[I];
   Task t;
-  t.active = role_of(d) ? wave >= 4 : (ntask(d) >= 8 ? 1 : wave < ntask(d));      // (a compile-time fact where all 8 waves have a task: no branch around their loads; role ops: the task of wave 4 + k is task k)
+  t.active = ntask(d) >= 8 ? 1 : wave < ntask(d);      // (a compile-time fact where all 8 waves have a task: no branch around their loads)
   if constexpr (d.path == P_R32B) {
     t.a = wave & (d.PG - 1);                    // position group
     t.b = (wave >> clog2(d.PG)) & (d.CG - 1);   // channel group
@@ -603,26 +542,12 @@ __device__ __forceinline__ Task conv_task(int wave) {
 }
 
 // ---- prefetch of what op I needs first (issued by op I-1) ---------------------------------------------------------
-// WHO (the caller is one wave role's branch of a role op, run_role_op): 0 all threads, 1 the serving waves (the weights of a role op are
-// not theirs: not loaded, "defined" without an instruction), 2 the matrix waves (the same for a role op's epilogue parameters)
-template <int I, int WHO = 0, int NW>
+template <int I, int NW>
 __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW], f32x4& prm) {
   if constexpr (I < kNumOps) {
     constexpr OpD d = kOps[I];
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if constexpr (d.type == T_CONV && is_role(I) && WHO == 1) {
-      opaque_regs(w);
-      constexpr int NP4 = (nparams(d) + 3) / 4;
-      prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>((tid < NP4 ? tid : NP4 - 1) * 16));
-    } else if constexpr (d.type == T_CONV && is_role(I) && WHO == 2) {
-      const Task t = conv_task<I>(wave);
-      const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
-      sfor<carry_w(I)>([&](auto ff) {
-        constexpr int sf = decltype(ff)::value;
-        w[sf] = ldb(wbase + static_cast<unsigned long long>(sf * 1024), static_cast<unsigned>(lane * 16));
-      });
-      asm volatile("" : "=v"(prm));
-    } else if constexpr (d.type == T_CONV) {
+    if constexpr (d.type == T_CONV) {
       // Every load of a prefetch is issued by EVERY thread (indices clamped, no branch around a load): the compiler counts
       // outstanding loads per control-flow path, and after a branch that holds loads it must assume the path without them --
       // a later wait for an OLDER load then also drains the ones just issued (seen in the disassembly as `vmcnt(1)` in front
@@ -631,30 +556,28 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
       // wave-uniform base (SGPR pair) + lane offset (VGPR) + immediate: no 64-bit vector address arithmetic
       // (a wave without a task fetches the fragments of task wave mod ntask and never uses them)
       const gcb_t wbase = cx.wb + static_cast<unsigned long long>(static_cast<unsigned>((d.w_off + t.wbase_f) * 4));
-      sfor<(FZ_ABL & 2048) ? 0 : carry_w(I)>([&](auto ff) {
+      sfor<carry_w(I)>([&](auto ff) {
         constexpr int sf = decltype(ff)::value;
         w[sf] = ldb(wbase + static_cast<unsigned long long>(sf * 1024), static_cast<unsigned>(lane * 16));
       });
-      if constexpr ((FZ_ABL & 2048) != 0) {
-#pragma unroll
-        for (int k = 0; k < NW; ++k) asm volatile("" : "=v"(w[k]));      // (undefined contents, but "defined" for the optimiser)
+      if constexpr (prm_dword(d)) {
+        prm[0] = ldb1(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>((tid < nparams(d) ? tid : nparams(d) - 1) * 4));
+      } else {
+        constexpr int NP4 = (nparams(d) + 3) / 4;
+        prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>((tid < NP4 ? tid : NP4 - 1) * 16));
       }
-      constexpr int NP4 = (nparams(d) + 3) / 4;
-      prm = ldb(cx.wb + static_cast<unsigned long long>(d.p_off * 4), static_cast<unsigned>((tid < NP4 ? tid : NP4 - 1) * 16));
     } else if constexpr (d.type == T_LSTM) {
-      // everything lstm_op needs from memory (slot map there), one op ahead; branch-free (see above): thread (u, sl) loads
-      // the KN weight rows of x slice sl (sl < 16) or the 6 rows + 6 values of h slice sl - 16 (16 <= sl < 20; the rest
-      // re-load slice 19), every thread a Dense row (clamped) and a bias / cell-state element (clamped)
-      constexpr int KN = d.din / 16, S0 = lstm_s0(d), WB = d.lw_off, BIAS = WB + (d.din + 24) * 84, WD = BIAS + 84;
-      constexpr int NR = KN > 6 ? KN : 6;
-      const int u = tid % 21, sl = tid / 21;
+      // everything lstm_op needs from memory (slot map there), one op ahead; branch-free (see above): thread (u, sl) loads the NRP int8x4 rows
+      // of its K slice as NRP / 4 float4 (fused_plan.hpp: blob layout of an LSTM op; sl >= 20 re-loads slice 19), the 6 values of h of an h
+      // slice, every thread the Dense row of its output (clamped: 2 float4 int8 / 6 float4 fp32) and the record of its unit (clamped)
+      constexpr int NRP = lstm_nrp(d.din), S0 = lstm_s0(d), WB = d.lw_off, REC = WB + lstm_gates_f(d.din), WD = REC + lstm_rec_f();
+      constexpr int DROW = lstm_dense_row_f(d.dout);
+      const int u = tid % 21, sl = tid / 21 < 20 ? tid / 21 : 19;
       const bool xs = sl < 16;
-      const int hs = sl < 20 ? sl - 16 : 3;
-      const int row0 = xs ? sl * KN : d.din + 6 * hs;
-      sfor<NR>([&](auto jj) {
+      const int hs = sl - 16;
+      sfor<NRP / 4>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
-        const int jr = xs ? (j < KN ? j : KN - 1) : (j < 6 ? j : 5);
-        w[j] = ldb(cx.wb, static_cast<unsigned>((WB + (row0 + jr) * 84 + 4 * u) * 4));
+        w[j] = ldb(cx.wb, static_cast<unsigned>((WB + (sl * 21 + u) * NRP + 4 * j) * 4));
       });
       const int h0 = xs ? 0 : 6 * hs;
       sfor<6 * d.gs>([&](auto jj) {
@@ -664,15 +587,16 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
       // (packed plans: gates and Dense outputs are dealt to threads as (stream, unit) / (stream, output): thread tid owns unit tid % 21 of
       //  stream tid / 21 and output tid % dout -- of stream (tid + 512 pass) / dout)
       const int drow = d.gs > 1 ? (tid & (d.dout - 1)) : (tid < d.dout ? tid : d.dout - 1);
-      sfor<6>([&](auto jj) {
+      sfor<DROW / 4>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
-        w[S0 + 2 + j] = ldb(cx.wb, static_cast<unsigned>((WD + drow * 24 + 4 * j) * 4));
+        w[S0 + 2 + j] = ldb(cx.wb, static_cast<unsigned>((WD + drow * DROW + 4 * j) * 4));
       });
-      constexpr int GT0 = lstm_gate_tid0(d);      // first gate thread (one-stream plans: on wave 7)
-      const int u21 = d.gs > 1 ? (tid < 21 * d.gs ? tid % 21 : 20) : ((tid >= GT0 && tid < GT0 + 21) ? tid - GT0 : 20);
+      const int u21 = d.gs > 1 ? (tid < 21 * d.gs ? tid % 21 : 20) : (tid < 21 ? tid : 20);
       const int g21 = d.gs > 1 ? (tid < 21 * d.gs ? tid / 21 : d.gs - 1) : 0;          // the stream slot whose cell state this thread updates
-      w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((BIAS + 4 * u21) * 4));
+      w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((REC + 4 * u21) * 4));
       w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4) + gofs(cx, d.g0 + g21));
+      w[S0 + 9][1] = ldb1(cx.wb, static_cast<unsigned>((REC + 84) * 4));      // s_x
+      w[S0 + 9][2] = ldb1(cx.wb, static_cast<unsigned>((REC + 85) * 4));      // s_h
 #if FZ_BASE
     } else if constexpr (d.type == T_DDB) {
       ddbz_prefetch<THREADS, d.x_cols / 2, d.din / d.x_cols>(ddbz_load_rec(cx.ddb + d.bidx), cx.stream, cx.step, tid, w);
@@ -718,11 +642,9 @@ __device__ __forceinline__ unsigned x16_ys_off(const Ctx& cx, int item) {
 }
 
 // last frame's partial sums of op I ([pos][packed channel] fp32), in the layout its epilogue wants them
-template <int I, int WHO = 0, int NY>
+template <int I, int NY>
 __device__ __forceinline__ void prefetch_y(const Ctx& cx, int tid, f32x4 (&yp)[NY]) {
-  if constexpr (yp_regs(I) > 0 && is_role(I) && WHO == 2) {
-    opaque_regs(yp);
-  } else if constexpr (yp_regs(I) > 0) {
+  if constexpr (yp_regs(I) > 0) {
     constexpr OpD d = kOps[I];
     if constexpr (d.path == P_R32B) {
       const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -733,6 +655,11 @@ __device__ __forceinline__ void prefetch_y(const Ctx& cx, int tid, f32x4 (&yp)[N
         //  store is 1 KB contiguous; a [pos][channel] layout costs 32 partial lines per instruction)
         yp[i] = ldb(cx.ysr, r32_ys_off<I>(cx, t, pt, n, q) + static_cast<unsigned>(lane * 16));
       });
+    } else if constexpr (d.epl == 1) {
+      // one output element per lane (x_epilogue1): element e = [virtual position][packed channel], the thread's own
+      constexpr int total = d.gs * d.P * ntot(d);
+      const int e = tid < total ? tid : total - 1;
+      yp[0][0] = ldb1(cx.ysr, x16_ys_off<I>(cx, e >> 2) + static_cast<unsigned>((e & 3) * 4));
     } else {
       constexpr int per = d.P * ntot(d) / 4, total = d.gs * per;
       sfor<yp_regs(I)>([&](auto ii) {
@@ -815,7 +742,6 @@ constexpr bool feeds_x(int i) { return i + 1 < kNumOps && (kOps[i + 1].type == T
 
 // ---- row-wise epilogue of the X16B path ---------------------------------------------------------------------------
 // LPG lanes per output row (float4 each): K-slice sum + bias, LayerNorm over the row's channels, PReLU, stores.
-// NTHR: the threads that run it -- all, or the 256 of the serving waves of a role op (run_role_op)
 template <int I, int NTHR = THREADS, int NY>
 __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (&yp)[NY]) {
   constexpr OpD d = kOps[I];
@@ -846,10 +772,10 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
       const int gi = d.gs > 1 ? vpos >> clog2(d.P) : 0, pos = d.gs > 1 ? vpos & (d.P - 1) : vpos;      // stream slot, position inside the stream
       const int eb = d.ex_b + vpos * OPB + (r * GC + 4 * li) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      sfor<(FZ_ABL & 512) ? 1 : KS>([&](auto kk) { v += lds4(eb + (K0 + decltype(kk)::value) * (VP * OPB)); });
+      sfor<KS>([&](auto kk) { v += lds4(eb + (K0 + decltype(kk)::value) * (VP * OPB)); });
       if constexpr (d.ys != 0) v += yp[ps];      // W[tap 0] x_{t-1}, computed by this op one frame ago
       v = v * wsc + bias;
-      if constexpr (d.ln && !(FZ_ABL & 16)) {
+      if constexpr (d.ln) {
         const float mean = group_sum<LPG>(v[0] + v[1] + v[2] + v[3]) * (1.0f / GC);
         v -= mean;
         const float q = group_sum<LPG>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
@@ -862,14 +788,15 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
       }
       const int row = pos * d.row_mul + d.row_add + r;
       const unsigned go = gofs(cx, d.g0 + gi);
+      if constexpr (is_up(d)) FZ_TRACE4(cx, d.g0 + gi, 13 + d.bidx, row, 128, 4 * li, v);
       if constexpr (CSUM) cs += v;
       // (the rows of the next image first: the next op's MFMAs wait for them behind the barrier; the HBM copies are nobody's critical path,
       //  and a store that has to queue behind the op's prefetches at the memory pipe would hold the LDS writes back with it)
       if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, 4 * li, v); }
       if constexpr (feeds_x(I)) lds4(d.xcopy_b + gi * 1024 + (row * GC + 4 * li) * 4) = v;
-      if constexpr (FZ_LDS_FIRST) sched_pin();
-      if constexpr (d.d0_on && !(FZ_ABL & 4)) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v); }
-      if constexpr (d.d1_on && !(FZ_ABL & 4)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v);
+      sched_pin();
+      if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v); }
+      if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v);
     }
   });
   if constexpr (CSUM) {
@@ -889,9 +816,71 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
         const int eb = d.ex_b + (u >> clog2(R)) * OPB + ((u & (R - 1)) * GC + 4 * l2) * 4;
         f32x4 y = {0.f, 0.f, 0.f, 0.f};
         sfor<KS>([&](auto kk) { y += lds4(eb + decltype(kk)::value * (VP * OPB)); });
-        if constexpr (!(FZ_ABL & 4)) stb(cx.ysw, x16_ys_off<I>(cx, item), y);
+        stb(cx.ysw, x16_ys_off<I>(cx, item), y);
       }
     });
+  }
+}
+
+// The same with ONE output element per lane (OpD::epl 1; layers with at most 512 outputs): an output row of GC channels is GC consecutive
+// lanes, so the K-slice sums, scale + bias, the two LayerNorm sums (DPP inside a row of 16 lanes, lane swaps across rows), PReLU and the
+// three-plane split are ~50 dependent VALU instructions on EVERY wave that holds a row instead of ~110 on the one or two waves that hold
+// all rows as float4 -- this chain is the critical path of a small op (profiles/r05_v0_wave_trace.txt: 1 000 of its 2 800 cycles).
+template <int I, int NY>
+__device__ __forceinline__ void x_epilogue1(const Ctx& cx, int tid, const f32x4 (&yp)[NY]) {
+  constexpr OpD d = kOps[I];
+  constexpr int GC = d.gc, R = d.R, NTOT = ntot(d), KS = ex_group(d), K0 = d.ys ? KS : 0, OPB = (NTOT + 4) * 4;
+  constexpr int VP = d.gs * d.P, total = VP * NTOT;
+  static_assert(total <= THREADS && (GC == 32 || GC == 64) && !is_up(d), "epl 1: at most one output element per thread, rows of 32 / 64 lanes");
+  static_assert(total % GC == 0 && (total % 64 == 0 || total == 32), "epl 1: whole rows per wave (the LayerNorm sums are lane exchanges)");
+  const int cch = tid & (GC - 1);                 // channel inside the output row
+  const int u = tid >> clog2(GC);                 // output row: virtual position x sub-row
+  const int r = u & (R - 1);
+  constexpr bool CSUM = feeds_ctfa_sums(I);
+  if (total == THREADS || FZ_LIKELY(tid < total)) {
+    const float bias = lds1(SCR_B + (r * GC + cch) * 4), wsc = lds1(SCR_B + (NTOT + r * GC + cch) * 4);
+    float gm = 0.f, bt = 0.f, alpha = 0.f;
+    if constexpr (d.ln) {
+      gm = lds1(SCR_B + (2 * NTOT + cch) * 4);
+      bt = lds1(SCR_B + (2 * NTOT + GC + cch) * 4);
+      alpha = lds1(SCR_B + (2 * NTOT + 2 * GC) * 4);
+    }
+    const int vpos = u >> clog2(R);
+    const int gi = d.gs > 1 ? vpos >> clog2(d.P) : 0, pos = d.gs > 1 ? vpos & (d.P - 1) : vpos;
+    const int eb = d.ex_b + vpos * OPB + (r * GC + cch) * 4;
+    float v = 0.f;
+    sfor<KS>([&](auto kk) { v += lds1(eb + (K0 + decltype(kk)::value) * (VP * OPB)); });
+    if constexpr (d.ys != 0) v += yp[0][0];      // W[tap 0] x_{t-1}, computed by this op one frame ago
+    v = v * wsc + bias;
+    if constexpr (d.ln) {
+      const float mean = group_sum<GC>(v) * (1.0f / GC);
+      v -= mean;
+      const float rstd = __builtin_amdgcn_rsqf(group_sum<GC>(v * v) * (1.0f / GC) + FZ_LN_EPS);
+      const float y = v * rstd * gm + bt;
+      v = y >= 0.f ? y : alpha * y;
+    }
+    const int row = pos * d.row_mul + d.row_add + r;
+    const unsigned go = gofs(cx, d.g0 + gi);
+    if constexpr (d.fwd.on) {
+      if (fwd_has<I>(gi)) img_st1<d.fwd.fmt>(fwd_addr<I>(row, cch) + (d.gs > 1 ? gi * d.fwd.gstride_b : 0), d.fwd.plane_b, v);
+    }
+    if constexpr (feeds_x(I)) lds1(d.xcopy_b + gi * 1024 + (row * GC + cch) * 4) = v;
+    if constexpr (CSUM) lds1(kOps[I + 1].scr_b + CSUM_OFF_B + tid * 4) = v;      // (every wave holds one output row of 64 channels: the CTFA adds the eight up)
+    sched_pin();
+    if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb1(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cch) * 4) + go, v); }
+    if constexpr (d.d1_on) stb1(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cch) * 4) + go, v);
+  }
+  if constexpr (d.ys != 0) {
+    // next frame's partial sums W[tap 0] x_t: K slices summed, stored raw ([pos][packed channel]) as float4 items dealt from the top of the workgroup
+    constexpr int items = total / 4, LPG4 = GC / 4;
+    const int item = THREADS - 1 - tid;
+    if (FZ_LIKELY(item < items)) {
+      const int uu = item >> clog2(LPG4), l2 = item & (LPG4 - 1);
+      const int eb = d.ex_b + (uu >> clog2(R)) * OPB + ((uu & (R - 1)) * GC + 4 * l2) * 4;
+      f32x4 y = {0.f, 0.f, 0.f, 0.f};
+      sfor<KS>([&](auto kk) { y += lds4(eb + decltype(kk)::value * (VP * OPB)); });
+      stb(cx.ysw, x16_ys_off<I>(cx, item), y);
+    }
   }
 }
 
@@ -939,28 +928,19 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
   bf16x8 bfr[PT][3];
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
-    if (t.active) {
-      sfor<(FZ_ABL & 256) ? 0 : hi - lo>([&](auto ff) {
+    if (FZ_LIKELY(t.active)) {
+      sfor<hi - lo>([&](auto ff) {
         constexpr int f = lo + decltype(ff)::value;
         constexpr int nt = f % NT, r = f / NT, s = r / GW, g = r % GW;
         constexpr int sf = f / 2;
-        bf16x8 a;
-        if constexpr ((FZ_ABL & 0x10000) != 0) a = as_bf(c.w[sf % CW]);      // (timing experiment: the raw bytes as the A operand, no conversion)
-        else a = wfrag(c.w[sf % CW], f % 2);
+        const bf16x8 a = wfrag(c.w[sf % CW], f % 2);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
-            if constexpr (nt == 0) {
-              if constexpr ((FZ_ABL & 0x20000) != 0) { f32x4 bz = {0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(bz)); bfr[pt][pl] = as_bf(bz); }      // (timing experiment: no B reads)
-              else bfr[pt][pl] = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 64 + pl * d.img.plane_b));
-            }
-            if constexpr ((FZ_ABL & 0x40000) != 0) {      // (timing experiment: operands formed, no MFMA)
-              asm volatile("" :: "v"(a), "v"(bfr[pt][pl]));
-            } else {
-              if constexpr ((UP && s == 2) || (BOTH && s < 3)) acco[pt][nt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[pt][pl], acco[pt][nt][pl], 0, 0, 0);
-              else acc[pt][nt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[pt][pl], acc[pt][nt][pl], 0, 0, 0);
-            }
+            if constexpr (nt == 0) bfr[pt][pl] = as_bf(lds4(lane_b[pt] + d.seg_b[s] + g * 64 + pl * d.img.plane_b));
+            if constexpr ((UP && s == 2) || (BOTH && s < 3)) acco[pt][nt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[pt][pl], acco[pt][nt][pl], 0, 0, 0);
+            else acc[pt][nt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[pt][pl], acc[pt][nt][pl], 0, 0, 0);
           }
         }
         if constexpr ((f % 2 == 1 || f + 1 == NF) && sf + CW < NSF) {
@@ -980,7 +960,7 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
   } else {
     half(std::integral_constant<int, 0>{}, std::integral_constant<int, NF>{});
   }
-  if (t.active) {
+  if (FZ_LIKELY(t.active)) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       const int pos = 16 * (t.a * PT + pt) + j;
@@ -995,11 +975,13 @@ __device__ __forceinline__ void conv_x16b(const Ctx& cx, int tid, Carry<I>& c, c
       }
     }
   }
-  if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
+  if constexpr (prm_dword(d)) { if (FZ_LIKELY(tid < nparams(d))) lds1(SCR_B + tid * 4) = c.prm[0]; }
+  else { if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm; }
   FZ_STAMP(I, 1);
   lds_barrier();
   FZ_STAMP(I, 2);
-  x_epilogue<I>(cx, tid, c.yp);
+  if constexpr (d.epl == 1) x_epilogue1<I>(cx, tid, c.yp);
+  else x_epilogue<I>(cx, tid, c.yp);
   FZ_STAMP(I, 3);
   build_next<I>(tid, p1, c.p);
   FZ_STAMP(I, 4);
@@ -1046,8 +1028,8 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
   bf16x8 b[PT][3];
   auto half = [&](auto lo_, auto hi_) {
     constexpr int lo = decltype(lo_)::value, hi = decltype(hi_)::value;
-    if (t.active) {
-      sfor<(FZ_ABL & 4096) ? 0 : hi - lo>([&](auto ff) {
+    if (FZ_LIKELY(t.active)) {
+      sfor<hi - lo>([&](auto ff) {
         constexpr int f = lo + decltype(ff)::value;
         constexpr int nt = f % NT, sg = f / NT, s = sg / G, g = sg % G;
         constexpr int na = UP ? (s == 2 ? 1 : 0) : nt;
@@ -1110,7 +1092,8 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
             for (int e = 0; e < 4; ++e) acc[pt][n][4 * q + e] += c.yp[(pt * NT + n) * 4 + q][e];
     }
   }
-  if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
+  if constexpr (prm_dword(d)) { if (FZ_LIKELY(tid < nparams(d))) lds1(SCR_B + tid * 4) = c.prm[0]; }
+  else { if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm; }
   FZ_STAMP(I, 1);
   lds_barrier();                      // every wave is done with this op's image; parameters are in LDS
   FZ_STAMP(I, 2);
@@ -1177,8 +1160,9 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
           const int cc = c0 + 8 * q + 4 * h;
+          if constexpr (UP) FZ_TRACE4(cx, d.g0 + gi, 13 + d.bidx, row, 128, cc, v);
           if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, cc, v); }
-          if constexpr (d.d0_on && !defer_d0(I)) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v); }
+          if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v); }
           if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4) + go, v);
         }
       }
@@ -1216,6 +1200,7 @@ __device__ __forceinline__ void input_op(const Ctx& cx, int tid) {
       o[e] = v >= 0.f ? v : alpha * v;
     }
     fwd_st4<I>(pos, 4 * c4, o);
+    FZ_TRACE4(cx, d.g0, 0, pos, 64, 4 * c4, o);
   }
 }
 
@@ -1229,48 +1214,25 @@ __device__ __forceinline__ void late_loads(const Ctx& cx, int tid, Carry<I + 1>&
   prefetch_y<I + 2>(cx, tid, n.yp2);
 }
 
-// An LSTM / CTFA op in front of a role op: waves 4..7 -- the role op's matrix waves -- widen its int8 weights (requested two ops ago, in
-// c.w2) to bf16 while a few threads of the low waves evaluate the gates.  ROLE: 1 the matrix waves' program of a two-program kernel, 2 the
-// one program of a kernel that branches per role op, 0 the serving waves' program (nothing to do).
-// PART of NPARTS: an LSTM op has two shadows (gates, Dense), each shorter than the whole widening.
-template <int I, int ROLE, int PART = 0, int NPARTS = 1>
-__device__ __forceinline__ void widen_next(int tid, Carry<I>& c, Carry<I + 1>& n) {
-  if constexpr (ROLE != 0 && role_pre(I + 1)) {
-    constexpr int NFN = role_nf(I + 1), F0 = NFN * PART / NPARTS, F1 = NFN * (PART + 1) / NPARTS;
-    auto body = [&]() {
-      if constexpr (PART == 0) pin_regs(c.w2);
-#pragma unroll
-      for (int f = F0; f < F1; ++f) {
-        const bf16x8 wv = wfrag(c.w2[f / 2], f % 2);
-        n.wb[f] = __builtin_bit_cast(f32x4, wv);
-        asm volatile("" : "+v"(n.wb[f]));      // (widened HERE: nothing of it sinks into the next op)
-      }
-    };
-    if constexpr (ROLE == 1) {
-      body();
-    } else {
-      if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) {
-        body();
-      } else {
-#pragma unroll
-        for (int f = F0; f < F1; ++f) asm volatile("" : "=v"(n.wb[f]));
-      }
-    }
-  }
-}
-
 // ---- LSTM cell + Dense (proposed.py:70-119; converter_proposed.py:234-237), in place on the next conv's image ------------
-template <int I, int ROLE>
+// the four int8 weights of a dword (gates i, f, g, o of one K row of a unit) as floats
+__device__ __forceinline__ f32x4 sbytes4(float packed) {
+  const int v = __builtin_bit_cast(int, packed);
+  return f32x4{static_cast<float>(static_cast<signed char>(v)), static_cast<float>(static_cast<signed char>(v >> 8)),
+               static_cast<float>(static_cast<signed char>(v >> 16)), static_cast<float>(static_cast<signed char>(v >> 24))};
+}
+template <int I>
 __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Carry<I + 1>& n) {
-  // z = [x ; h] . [Wx ; Wh] + b with the gate columns interleaved (column 4 u + g: gate g of unit u), so that one float4
-  // is (i, f, g, o) of a unit.  K is cut into 16 slices of x (threads (u, slice), tid < 336) and 4 slices of h
-  // (tid 336..419); every operand arrived in the carry (slot map: [0, S0) weight rows of the thread's slice,
-  // [S0, S0+2) its h values, [S0+2, S0+8) the Dense row of its output, S0+8 the unit's bias, S0+9 the cell state it updates; packed
+  // z = b + s_x (Qx x) + s_h (Qh h) with the gate columns interleaved (one dword = the int8 (i, f, g, o) weights of a unit for one K row:
+  // fused_plan.hpp, blob layout of an LSTM op).  K is cut into 16 slices of x (threads (u, slice), tid < 336) and 4 slices of h
+  // (tid 336..419); every operand arrived in the carry (slot map: [0, S0) the int8x4 rows of the thread's slice,
+  // [S0, S0+2) its h values, [S0+2, S0+8) the Dense row of its output, S0+8 the unit's bias, S0+9 (cell state it updates, s_x, s_h); packed
   // plans: the h values of stream slot gi >= 1 at S0 + 10 + 2 (gi - 1) + {0, 1} -- the weights serve every stream of the op; gates and
   // Dense outputs are dealt to the threads as (stream, unit) / (stream, output)).
   constexpr OpD d = kOps[I];
-  constexpr int KN = d.din / 16, XS = clog2(d.x_cols), S0 = lstm_s0(d), GS = d.gs;
+  constexpr int KN = lstm_kn(d.din), XS = clog2(d.x_cols), S0 = lstm_s0(d), GS = d.gs;
   constexpr int PART = d.scr_b, HN = d.scr_b + 20 * 21 * 16, SGB = d.scr_gstride_b;      // stream slot gi: + gi * SGB
+  constexpr bool DI8 = lstm_dense_i8(d.dout);
   const int u = tid % 21, sl = tid / 21;
   pin_regs(c.w);
   if (tid < 336) {
@@ -1280,44 +1242,56 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
 #pragma unroll
     for (int j = 0; j < KN; ++j) {
       const int k = sl * KN + j;
+      const f32x4 wq = sbytes4(c.w[j / 4][j % 4]);
 #pragma unroll
-      for (int gi = 0; gi < GS; ++gi) a[gi] += c.w[j] * lds1(d.xcopy_b + gi * 1024 + k * 4);        // (the conv op before left its rows here as fp32, [row][x_cols] = element k)
+      for (int gi = 0; gi < GS; ++gi) a[gi] += wq * lds1(d.xcopy_b + gi * 1024 + k * 4);        // (the conv op before left its rows here as fp32, [row][x_cols] = element k)
     }
 #pragma unroll
     for (int gi = 0; gi < GS; ++gi) lds4(PART + gi * SGB + (sl * 21 + u) * 16) = a[gi];
   } else if (tid < 420) {
+    f32x4 wq[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) wq[j] = sbytes4(c.w[j / 4][j % 4]);
 #pragma unroll
     for (int gi = 0; gi < GS; ++gi) {
       const int SH = gi == 0 ? S0 : S0 + 10 + 2 * (gi - 1);
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float hv = c.w[SH + j / 4][j % 4];
-        a += c.w[j] * hv;
-      }
+      for (int j = 0; j < 6; ++j) a += wq[j] * c.w[SH + j / 4][j % 4];
       lds4(PART + gi * SGB + (sl * 21 + u) * 16) = a;
     }
   }
   FZ_WSTAMP(I, 3);
   lds_barrier();
   FZ_WSTAMP(I, 4);
-  constexpr int GT0 = lstm_gate_tid0(d);
-  constexpr bool W7 = GT0 != 0 && ROLE == 2;      // (see lstm_gate_tid0: the op's prefetches in the shadow of its gates / Dense rows)
-  if constexpr (ROLE == 1) { late_loads<I>(cx, tid, n); sched_pin(); }
-  if constexpr (W7) {
-    static_assert(d.dout <= 448, "wave 7 has no Dense row");
-    if (__builtin_amdgcn_readfirstlane(tid >> 6) != 7) late_loads<I>(cx, tid, n);
-    sched_pin();
+  // the Dense row of this thread's output as floats -- widened here, beside the 21 gate threads, not behind the barrier they release
+  float wd[21], bd, sd = 1.0f;
+  if constexpr (DI8) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const f32x4 w4 = sbytes4(c.w[S0 + 2 + q / 4][q % 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (4 * q + e < 21) wd[4 * q + e] = w4[e];
+    }
+    bd = c.w[S0 + 3][2];
+    sd = c.w[S0 + 3][3];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) wd[k] = c.w[S0 + 2 + k / 4][k % 4];
+    bd = c.w[S0 + 2 + 5][1];
   }
-  widen_next<I, ROLE, 0, 2>(tid, c, n);    // (waves 4..7, while 21 threads evaluate the gates: the bf16 weights of the role op that follows, first half)
-  if (tid >= GT0 && tid < GT0 + 21 * GS) {          // thread (stream slot gi, unit uu): the unit's four gates
-    const int gi = GS > 1 ? tid / 21 : 0, uu = GS > 1 ? tid % 21 : tid - GT0;
+#pragma unroll
+  for (int k = 0; k < 21; ++k) asm volatile("" : "+v"(wd[k]));
+  if (tid < 21 * GS) {          // thread (stream slot gi, unit uu): the unit's four gates
+    const int gi = GS > 1 ? tid / 21 : 0, uu = GS > 1 ? tid % 21 : tid;
     f32x4 zz[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) zz[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s2 = 0; s2 < 20; ++s2) zz[s2 & 3] += lds4(PART + gi * SGB + (s2 * 21 + uu) * 16);      // (four chains: the twenty partial rows are not one dependent sum)
-    const f32x4 z = c.w[S0 + 8] + ((zz[0] + zz[1]) + (zz[2] + zz[3]));
+    for (int s2 = 0; s2 < 16; ++s2) zz[s2 & 3] += lds4(PART + gi * SGB + (s2 * 21 + uu) * 16);      // (four chains: the partial rows are not one dependent sum)
+    f32x4 zh = lds4(PART + gi * SGB + (16 * 21 + uu) * 16) + lds4(PART + gi * SGB + (17 * 21 + uu) * 16);
+    zh += lds4(PART + gi * SGB + (18 * 21 + uu) * 16) + lds4(PART + gi * SGB + (19 * 21 + uu) * 16);
+    const f32x4 z = c.w[S0 + 8] + ((zz[0] + zz[1]) + (zz[2] + zz[3])) * c.w[S0 + 9][1] + zh * c.w[S0 + 9][2];
     const float c_old = c.w[S0 + 9][0];
     const float gi_ = fast_sigmoid(z[0]), gf = fast_sigmoid(z[1]), gg = fast_tanh(z[2]), go = fast_sigmoid(z[3]);
     const float c_new = gf * c_old + gi_ * gg;
@@ -1330,11 +1304,6 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
   FZ_WSTAMP(I, 5);
   lds_barrier();
   FZ_WSTAMP(I, 6);
-  if constexpr (W7) {
-    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 7) late_loads<I>(cx, tid, n);      // (the gate wave's share, beside the Dense rows)
-    sched_pin();
-  }
-  widen_next<I, ROLE, 1, 2>(tid, c, n);    // (second half, beside the Dense rows of the low waves)
   // Dense: output n of stream gi by thread (gi * dout + n) mod 512 (its row of the Dense kernel arrived in the carry: 512 is a multiple
   // of dout, so a thread's row is the same in every pass)
   constexpr int DPASS = (d.dout * GS + THREADS - 1) / THREADS;
@@ -1343,13 +1312,15 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
     const int idx = tid + THREADS * ps;
     if (idx < d.dout * GS) {
       const int gi = GS > 1 ? idx >> clog2(d.dout) : 0, n = GS > 1 ? idx & (d.dout - 1) : tid;
-      float a = c.w[S0 + 2 + 5][1];          // bd
+      float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int q = 0; q < 5; ++q) {
-        const f32x4 h4 = lds4(HN + gi * SGB + 16 * q), w4 = c.w[S0 + 2 + q];
-        a += w4[0] * h4[0] + w4[1] * h4[1] + w4[2] * h4[2] + w4[3] * h4[3];
+        const f32x4 h4 = lds4(HN + gi * SGB + 16 * q);
+        a0 += wd[4 * q] * h4[0] + wd[4 * q + 1] * h4[1];
+        a1 += wd[4 * q + 2] * h4[2] + wd[4 * q + 3] * h4[3];
       }
-      a = fmaf(c.w[S0 + 2 + 5][0], lds1(HN + gi * SGB + 80), a);
+      a0 = fmaf(wd[20], lds1(HN + gi * SGB + 80), a0);
+      const float a = DI8 ? fmaf(a0 + a1, sd, bd) : (a0 + a1) + bd;
       const int f = n >> XS, cc = n & (d.x_cols - 1);
       img_st1<d.x_fmt>(d.y_b + gi * d.x_gstride_b + f * d.x_pitch_b + cc * esz_of(d.x_fmt), d.x_plane_b, a);
       if constexpr (d.ldst_on) stb1(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4) + gofs(cx, d.g0 + gi), a);
@@ -1429,12 +1400,12 @@ __device__ __forceinline__ void gates_load(const Ctx& cx, int tid, f32x4 (&g)[17
 
 // ---- CTFA gate + residual (ctfa_rt, proposed.py:162-196), in place on the next image; the network's last
 //      one also applies the output 1x1 conv (proposed.py:65) and writes the enhanced magnitudes ---------------------------
-template <int I, int ROLE>
+template <int I>
 __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Carry<I + 1>& n) {
   constexpr OpD d = kOps[I];
   constexpr int NI = ctfa_ni(d), GS = d.gs, SGB = d.scr_gstride_b;
   // scratch of stream slot gi at d.scr_b + gi * SGB: column sums of the 8 waves | gates | the perceptrons' exchange
-  constexpr int PART = d.scr_b, GATE = d.scr_b + 512 * 4, MSCR = GATE + 64 * 4;
+  constexpr int PART = d.scr_b, GATE = d.scr_b + 512 * 4;
   const int c4 = tid & 15, rg = tid >> 4, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // gate perceptrons (wave gi for stream slot gi -- wave 0 in a one-stream plan: lane c holds its 16 input / output weights of each
   // of the four matrices): requested now, used after the column sums.  (In the carry they would cost every wave of the preceding
@@ -1483,8 +1454,6 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Car
     FZ_STAMP(I, 5);
   }
   FZ_STAMP(I, 1);
-  if constexpr (ROLE == 1) { late_loads<I>(cx, tid, n); sched_pin(); }
-  widen_next<I, ROLE>(tid, c, n);            // (waves 4..7, while wave 0 evaluates the gate perceptrons)
   if (wave < GS) {
     const int sb = wave * SGB;          // this wave's stream slot
     float m = 0.f;
@@ -1510,8 +1479,8 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Car
       const int f = rg + 32 * i;
       if (f < d.F) {
         const f32x4 x = fwd_ld4g<I>(gi, f, 4 * c4);      // (re-read: cheaper than 32 registers held across the gates)
-        if constexpr (defer_d0(I - 1)) stb(cx.sbc, static_cast<unsigned>((kOps[I - 1].d0_off + f * kOps[I - 1].d0_ld + 4 * c4) * 4), x);      // (the conv's skip-connection copy, see defer_d0)
         const f32x4 y = x * g4 + c.w[gi * NI + i];
+        FZ_TRACE4(cx, d.g0 + gi, 1 + d.bidx, f, 64, 4 * c4, y);
         if constexpr (d.last) {
           const float s = group_sum<16>(y[0] * ow[0] + y[1] * ow[1] + y[2] * ow[2] + y[3] * ow[3]);
           if (c4 == 0) cx.io_out[(d.g0 + gi) * 256 + f] = s + ob;
@@ -1525,205 +1494,9 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Car
   }
 }
 
-// ---- role op: a small conv op (one position tile of 16x16x32 bf16 MFMAs, <= 4 channel tiles) on two instruction streams --------------
-// A small op is a latency chain -- B reads, a few dozen MFMAs, partial tiles through LDS, barrier, row-wise LayerNorm epilogue, barrier --
-// and in the general conv op every wave carries every link of it plus the bookkeeping around it: the loads of the next images and
-// weights in front of the MFMAs, the int8 -> bf16 widening inside the loop (profiles/r05_v0_wave_trace.txt: 300-700 cycles of load
-// issue and 600-1100 of "MFMA loop" per op for 150-600 cycles of MFMA issue).  Here the two halves of the chain get their own waves:
-//   waves 4..7 ("matrix" waves, one per SIMD, ROLE 1): B reads + MFMAs of wave task (wave - 4) with ALL its weight fragments already in
-//     registers as bf16, partial tile to the exchange buffer, barrier 1; then, while the epilogue runs: request the weights of op I+2, widen
-//     the weights of op I+1 (requested one op ago), store their share of the far-ahead staged parts, zero the halos; barrier 2;
-//   waves 0..3 ("serving" waves, ROLE 0): issue the staging loads and parameter / partial-sum prefetches while the MFMAs run, barrier 1;
-//     row-wise epilogue (x_epilogue on 256 threads: bias, scale, LayerNorm, PReLU, state stores, rows of the next image), staged parts;
-//     barrier 2.
-// The barriers and every LDS hand-off are those of conv_x16b; what travels in the Carry keeps its all-threads meaning, so the ops around a
-// run of role ops are unchanged.
-// The two roles are two PROGRAMS: a kernel whose plan has role ops branches ONCE, at its entry, into run_from<0, PROF, ROLE> for its wave
-// role, and every op is instantiated per program.  (First built as a branch per role op: at every join the compiler merges the two paths'
-// outstanding-load bookkeeping -- a register one path has a load in flight for is "in flight" for the other path too, so the matrix waves
-// drained their memory counter at the head of every op; registers only one path defines became phi(value, undef), into which LLVM folds
-// the byte extraction of the carried int8 weights, up to their loads; loads whose results only the other role uses are dead loads, whose
-// destination registers are re-used behind a wait.  0.39 ms/step against 0.36 before.  With one branch there is nothing to merge, and what a
-// program does not use of a prefetch is dead code in that program.)
-// matrix waves' half of role op I.  UNI: one-program kernel (this is one branch of `if (wave >= 4)`): nothing these waves do not own is
-// loaded, what only the other branch defines gets an opaque definition, and no load is left in flight at the join -- the compiler merges
-// the outstanding-load bookkeeping of the two branches there, so the serving waves' loads count as "in flight" for these waves too: with
-// their own counter at zero every wait it derives from that is free.
-template <int I, bool UNI, bool LAST = false>
-__device__ __forceinline__ void role_matrix(const Ctx& cx, int tid, Carry<I>& c, Carry<I + 1>& n) {
-  constexpr OpD d = kOps[I];
-  constexpr int NF = conv_nf(d), GW = gw(d), NTOT = ntot(d), OPB = (NTOT + 4) * 4, J = nxt_of(I);
-  constexpr int WHO = UNI ? 2 : 0;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Task t = conv_task<I>(wave);
-  const int ks_t = t.ks >> clog2(d.KSg), ks_g = t.ks & (d.KSg - 1);
-  const int j = lane & 15, h = lane >> 4;
-  const int pos = j < d.P ? j : d.P - 1;
-  const int lane_b = pos * d.img.pitch_b + 16 * h + ks_t * d.img.tap_b + ks_g * (GW * 64);
-  bf16x8 a[NF];
-  if constexpr (role_pre(I)) {
-#pragma unroll
-    for (int f = 0; f < NF; ++f) a[f] = as_bf(c.wb[f]);
-  } else {
-    pin_regs(c.w);
-#pragma unroll
-    for (int f = 0; f < NF; ++f) a[f] = wfrag(c.w[f / 2], f % 2);
-  }
-  FZ_WSTAMP(I, 2);
-  // Wave task = K slice (time tap, channel-group range of every segment) x channel group of NT tiles (the planner splits K first: the
-  // four waves then read disjoint B fragments).  Fragment f = (K step f / NT, tile f % NT); a B fragment serves the NT tiles of its K
-  // step.  All B reads of a batch of K steps are issued before its first MFMA (one wave per SIMD: nothing else hides the LDS latency),
-  // the next batch's reads behind the MFMAs of this one.
-  constexpr int NT = d.NT, NR = NF / NT;                  // K steps of the wave
-  constexpr int KB = 6, NB = (NR + KB - 1) / KB;          // K steps per batch: <= 18 reads = 72 registers
-  static_assert(NF == NR * NT && NB <= 2, "role op: K steps x channel tiles");
-  f32x4 acc[NT][3];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) acc[nt][pl] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 b[NB][KB][3];
-  auto rd = [&](auto bb) {
-    constexpr int B0 = decltype(bb)::value;
-    if constexpr (B0 < NB && !(FZ_ABL & 256)) {
-      sfor<cmin(KB, NR - B0 * KB)>([&](auto rr) {
-        constexpr int r = B0 * KB + decltype(rr)::value, sg = r / GW, g = r % GW;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[B0][r % KB][pl] = as_bf(lds4(lane_b + d.seg_b[sg] + g * 64 + pl * d.img.plane_b));
-      });
-    }
-  };
-  rd(std::integral_constant<int, 0>{});
-  // What the next ops need from these waves' threads.  A wave issues in order, so every load in front of the MFMAs delays them (all of them
-  // here, FZ_MLOADS 0: the MFMA phase of a role op 0.5 -> 1.1 us); but the loads that come from HBM -- the far-ahead staged parts of the next
-  // image but one: previous-frame rows -- and the large parameter block of an LSTM / CTFA op two ops ahead need the lead time: requested in
-  // the shadow of the epilogue they were not there when the run ended (the matrix waves wait for their loads at the join) or when the
-  // LSTM op started (13 LSTM ops 17 -> 23 us).  The weights of the next role ops (L2 hits, one op of slack) go out in the shadow.
-  constexpr bool EARLY_W = FZ_MLOADS == 0 || (FZ_MLOADS == 2 && is_gate_op(I + 2));
-  if constexpr (FZ_MLOADS != 1) stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
-  if constexpr (EARLY_W) {
-    prefetch_w<I + 2, WHO>(cx, tid, n.w2, n.prm2);
-    prefetch_y<I + 2, WHO>(cx, tid, n.yp2);
-  }
-  sfor<(FZ_ABL & 256) ? 0 : NB>([&](auto bb) {
-    constexpr int B0 = decltype(bb)::value;
-    rd(std::integral_constant<int, B0 + 1>{});
-    sched_pin();
-    sfor<cmin(KB, NR - B0 * KB)>([&](auto rr) {
-      constexpr int r = B0 * KB + decltype(rr)::value;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) acc[nt][pl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r * NT + nt], b[B0][r % KB][pl], acc[nt][pl], 0, 0, 0);
-    });
-  });
-  FZ_WSTAMP(I, 3);
-  if (j < d.P) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) lds4(d.ex_b + (t.ks * d.P + j) * OPB + (16 * (t.b * NT + nt) + 4 * h) * 4) = acc[nt][0] + (acc[nt][1] + acc[nt][2]);
-  }
-  FZ_WSTAMP(I, 4);
-  lds_barrier();                      // the partial tiles are in the exchange buffer; every matrix wave is done with this op's image
-  FZ_WSTAMP(I, 5);
-  // -- in the shadow of the epilogue: what the next ops need from these waves' threads is requested first.  The last op of a run waits for
-  // these loads at its end (below): the LSTM / CTFA op behind a run drains the memory counter at its start, and there the matrix waves'
-  // late loads made them late for its first barrier (13 LSTM ops 17 -> 23 us); here the wait sits beside the serving waves' epilogue
-  if constexpr (FZ_MLOADS == 1) stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
-  if constexpr (!EARLY_W) {
-    prefetch_w<I + 2, WHO>(cx, tid, n.w2, n.prm2);
-    prefetch_y<I + 2, WHO>(cx, tid, n.yp2);
-    sched_pin();
-  }
-  n.prm = c.prm2;
-#pragma unroll
-  for (int k = 0; k < cmax(1, yp_regs(I + 1)); ++k) n.yp[k] = c.yp2[k];
-  if constexpr (role_pre(I + 1)) {
-    widen_next<I, 1>(tid, c, n);
-  } else {
-#pragma unroll
-    for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
-  }
-  FZ_WSTAMP(I, 6);
-  stage_store<J, 2, THREADS>(tid, c.p);
-  zero_halos<J>(tid);
-  FZ_WSTAMP(I, 7);
-  if constexpr (UNI || LAST) drain_vm();      // (issued a whole MFMA phase + epilogue ago: nothing to wait for, but the bookkeeping is clean at the join)
-}
-
-// serving waves' half of role op I
-template <int I, bool UNI>
-__device__ __forceinline__ void role_serve(const Ctx& cx, int tid, Carry<I>& c, Carry<I + 1>& n) {
-  constexpr OpD d = kOps[I];
-  constexpr int J = nxt_of(I);
-  constexpr int WHO = UNI ? 1 : 0;
-  f32x4 p1[cmax(1, nxt_regs(I, 1))];
-  stage_load<J, 1, 256>(cx, tid, p1);
-  stage_load<nxt_of(I + 1), 2, THREADS>(cx, tid, n.p);
-  prefetch_w<I + 2, WHO>(cx, tid, n.w2, n.prm2);
-  prefetch_y<I + 2, WHO>(cx, tid, n.yp2);
-  sched_pin();
-  n.prm = c.prm2;
-#pragma unroll
-  for (int k = 0; k < cmax(1, yp_regs(I + 1)); ++k) n.yp[k] = c.yp2[k];
-  if constexpr (role_pre(I + 1)) {
-    if constexpr (UNI) opaque_regs(n.wb);
-  } else {
-#pragma unroll
-    for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
-  }
-  FZ_STAMP(I, 0);
-  FZ_STAMP(I, 5);
-  FZ_WSTAMP(I, 1);
-  if (FZ_LIKELY(tid < (nparams(d) + 3) / 4)) lds4(SCR_B + tid * 16) = c.prm;
-  FZ_STAMP(I, 1);
-  FZ_WSTAMP(I, 4);
-  lds_barrier();
-  FZ_STAMP(I, 2);
-  FZ_WSTAMP(I, 5);
-  if constexpr (FZ_SETPRIO) __builtin_amdgcn_s_setprio(3);      // (the epilogue is the op's critical path: ahead of the matrix wave of its SIMD, which widens weights)
-  x_epilogue<I, 256>(cx, tid, c.yp);
-  if constexpr (FZ_SETPRIO) __builtin_amdgcn_s_setprio(0);
-  FZ_STAMP(I, 3);
-  FZ_WSTAMP(I, 6);
-  stage_store<J, 1, 256>(tid, p1);
-  stage_store<J, 2, THREADS>(tid, c.p);
-  zero_halos<J>(tid);
-  FZ_STAMP(I, 4);
-  FZ_WSTAMP(I, 7);
-  if constexpr (d.drain != 0) drain_vm();      // (baseline variant: the dilated-dense op after it reads this op's rows from HBM; the stores are the serving waves')
-}
-
-// ROLE: 0 / 1 the serving / matrix waves' program (of a run of role ops, or -- FZ_SPLIT -- of the whole kernel), 2 one program that branches
-// here.  LAST: the last op of a run of role ops (the two programs join behind it).
-template <int I, bool PROF, int ROLE, bool LAST = false>
-__device__ __forceinline__ void run_role_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
-  constexpr OpD d = kOps[I];
-  constexpr int NSF = conv_nsf(d), NTOT = ntot(d);
-  static_assert(d.path == P_X16B && d.PT == 1 && d.PG == 1 && ntask(d) == 4 && d.rounds == 1 && !is_up(d) && !x16_both(d), "role op: four wave tasks of one 16-position tile");
-  static_assert(d.CG * d.NT * 16 == d.N, "role op: channel groups x tiles per task");
-  static_assert(d.gs == 1 && d.img.fmt == 1 && NSTREAMS == 1, "role ops exist in the one-stream plans");
-  static_assert(carry_w(I) == NSF && own_regs(I, 3) == 0 && own_regs(I, 4) == 0 && own_regs(I + 1, 4) == 0 && ext_sf(I) == 0, "role op: no ring, one round");
-  static_assert(d.P * NTOT / 4 <= 256 && (nparams(d) + 3) / 4 <= 256, "role op: one epilogue pass on the serving waves");
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  if (PROF && cx.prof && tid == 0) cx.prof[I] = wall_clock64();
-  FZ_WSTAMP(I, 0);
-  if constexpr (ROLE == 1) {
-    role_matrix<I, false, LAST>(cx, tid, c, n);
-  } else if constexpr (ROLE == 0) {
-    role_serve<I, false>(cx, tid, c, n);
-  } else {
-    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) role_matrix<I, true>(cx, tid, c, n);
-    else role_serve<I, true>(cx, tid, c, n);
-  }
-  FZ_WSTAMP(I, 9);
-  lds_barrier();
-  FZ_WSTAMP(I, 10);
-}
-
 // ---- one op -----------------------------------------------------------------------------------------------------------
-template <int I, bool PROF, int ROLE>
-__device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
+template <int I, bool PROF>
+__device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
   constexpr OpD d = kOps[I];
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));          // per-op thread id: nothing derived from it is hoisted across ops
@@ -1753,11 +1526,7 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
       stage_load<I, 3, ST>(cx, tid - (THREADS - ST), p3);
     }
   }
-  // (matrix waves' program of a run of role ops, LSTM / CTFA op: what the next ops need from these waves is requested in the shadow of the
-  //  gates instead -- late_loads --: their prologue is the heavier one (all fragments of a role op's task, the staged parts dealt from the
-  //  top) and made them 400 cycles late for the op's first barrier)
-  constexpr bool LATE = (ROLE == 1 && is_gate_op(I)) || (ROLE == 2 && d.type == T_LSTM && lstm_gate_tid0(d) != 0);
-  if constexpr (!LATE) late_loads<I>(cx, tid, n);
+  late_loads<I>(cx, tid, n);
 #pragma unroll
   for (int k = 0; k < cmax(1, carry_w(I + 1)); ++k) n.w[k] = c.w2[k];
   n.prm = c.prm2;
@@ -1774,13 +1543,13 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
     if constexpr (d.path == P_X16B) conv_x16b<I>(cx, tid, c, p1, p3);
     else conv_r32b<I>(cx, tid, c, p1, p3, wx);
   } else if constexpr (d.type == T_LSTM) {
-    if constexpr (!(FZ_ABL & 32)) lstm_op<I, ROLE>(cx, tid, c, n);
+    lstm_op<I>(cx, tid, c, n);
 #if FZ_BASE
   } else if constexpr (d.type == T_DDB) {
     ddb_op<I>(cx, tid, c);
 #endif
   } else {
-    if constexpr (!(FZ_ABL & 64)) ctfa_op<I, ROLE>(cx, tid, c, n);
+    ctfa_op<I>(cx, tid, c, n);
     if constexpr (nxt_of(I) >= 0) {
       // packed plans: an instance of the network's last CTFA that is followed by another stream's ops completes the image of the conv
       // after it (its loads went out in the prologue above) -- once every thread is done with the plain rows the image overlaps
@@ -1795,57 +1564,17 @@ __device__ __forceinline__ void run_plain_op(const Ctx& cx, Carry<I>& c, Carry<I
   FZ_WSTAMP(I, 10);
 }
 
-// ROLE: the program this instantiation belongs to -- 0 serving waves (0..3), 1 matrix waves (4..7) of a kernel whose plan has role ops
-// (run_role_op), 2 the only program of a kernel without
-template <int I, bool PROF, int ROLE>
-__device__ __forceinline__ void run_op(const Ctx& cx, Carry<I>& c, Carry<I + 1>& n) {
-  if constexpr (is_role(I)) run_role_op<I, PROF, ROLE>(cx, c, n);
-  else run_plain_op<I, PROF, ROLE>(cx, c, n);
-}
-
-// A RUN of consecutive role ops is executed as two programs, one per wave role: ONE branch in front of the run, one join behind it.
-// (A branch per role op loses to the compiler's bookkeeping of outstanding loads, which is merged -- conservatively -- at every join:
-// memory-counter drains at the head of every op.  Two programs for the whole kernel keep that bookkeeping exact but instantiate every
-// plain op twice, and two instruction streams per CU cost the plain ops 5-10 %: profiles/r05_role_dev_log.txt.)  At the join the matrix
-// waves have no load in flight (role_matrix LAST), so whatever the merged bookkeeping makes them wait for is free.
-// (An LSTM / CTFA op in front of a role op belongs to the run: in the matrix waves' program it widens that op's weights in the shadow
-// of its gates -- widen_next -- with no branch of its own.)
-constexpr bool in_run(int i) { return is_role(i) || (FZ_WIDEN_GATES && is_gate_op(i) && is_role(i + 1)); }
-constexpr int role_run_end(int i) { while (in_run(i)) ++i; return i; }
-template <int I, int E, bool PROF, int ROLE>
-__device__ __forceinline__ void run_roles(const Ctx& cx, Carry<I>& c, Carry<E>& out) {
-  // the matrix waves leave no load in flight behind the run (the join) and in front of an LSTM / CTFA op (which drains the counter at its start)
-  constexpr bool LAST = I + 1 == E || is_gate_op(I + 1);
-  auto one = [&](auto& nn) {
-    if constexpr (is_role(I)) run_role_op<I, PROF, ROLE, LAST>(cx, c, nn);
-    else run_plain_op<I, PROF, ROLE>(cx, c, nn);
-  };
-  if constexpr (I + 1 == E) {
-    one(out);
-  } else {
-    Carry<I + 1> n;
-    one(n);
-    run_roles<I + 1, E, PROF, ROLE>(cx, n, out);
-  }
-}
-
-template <int I, bool PROF, int ROLE>
+template <int I, bool PROF>
 __device__ __forceinline__ void run_from(const Ctx& cx, Carry<I>& c) {
   if constexpr (I < kNumOps) {
-    if constexpr (ROLE == 2 && in_run(I)) {
-      constexpr int E = role_run_end(I);
-      Carry<E> out;
-      if (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) >= 4) run_roles<I, E, PROF, 1>(cx, c, out);
-      else run_roles<I, E, PROF, 0>(cx, c, out);
-      run_from<E, PROF, ROLE>(cx, out);
-    } else {
-      Carry<I + 1> n;
-      run_op<I, PROF, ROLE>(cx, c, n);
-      run_from<I + 1, PROF, ROLE>(cx, n);
-    }
+#if FZ_STOPAT
+    if (cx.stop_at == I) return;      // (wave-uniform: one scalar compare per op)
+#endif
+    Carry<I + 1> n;
+    run_op<I, PROF>(cx, c, n);
+    run_from<I + 1, PROF>(cx, n);
   }
 }
-constexpr bool has_roles() { for (int i = 0; i < kNumOps; ++i) if (is_role(i)) return true; return FZ_FORCE_SPLIT != 0; }
 
 struct FzArgs {
   float* arena; long long sstride; const float* blob; const float* io_in; float* io_out; int B, par; unsigned long long* prof;
@@ -1854,9 +1583,6 @@ struct FzArgs {
   FzTa ta;                   // CTFA frequency branch: see nutls_internal.hpp
 };
 
-#ifndef FZ_PROF
-#define FZ_PROF 0
-#endif
 #if FZ_STREAMS == 2
 #define FZ_KERNEL nutls_fused_step_g2_kernel
 #define FZ_LAUNCH launch_fused_step_g2
@@ -1925,6 +1651,8 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
   cx.ta_ring_sstride = a.ta.ring_sstride;
   cx.ta_ring_gstride = a.ta.ring_gstride;
   cx.eager = a.ta.eager;
+  cx.dbg = (PROF && a.ta.dbg) ? (gcb_t)(unsigned long long)(a.ta.dbg + static_cast<size_t>(stream) * a.ta.dbg_sstride) : nullptr;
+  cx.dbg_sstride_b = static_cast<unsigned>(a.ta.dbg_sstride * 4);
 #if FZ_BASE
   {
     // one pass over the 13 parameter records of the dilated-dense ops: they stay in the scalar cache for the rest of
@@ -1943,7 +1671,12 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
         : "=&s"(t) : "s"(cx.ddb), "n"((13 * sizeof(DdbParams) + 63) / 64) : "memory");
   }
 #endif
+#if FZ_STOPAT
+  cx.stop_at = a.ta.skew;
+  if (false) {
+#else
   if (a.ta.skew > 0) {
+#endif
     // start skew (FzTa::skew): every workgroup of a launch walks the same op sequence, so their staging bursts hit HBM together
     const int n = (blockIdx.x & 3) * a.ta.skew;
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
@@ -1954,13 +1687,7 @@ __global__ __launch_bounds__(THREADS) void FZ_KERNEL(const FzArgs a) {
     prefetch_w<1>(cx, tid, c0.w2, c0.prm2);
     prefetch_y<1>(cx, tid, c0.yp2);
   }
-  if constexpr (has_roles() && (FZ_SPLIT || FZ_FORCE_SPLIT)) {
-    // two programs, one per wave role (run_role_op): the only branch on the role in the whole kernel
-    if (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) >= 4) run_from<0, PROF, 1>(cx, c0);
-    else run_from<0, PROF, 0>(cx, c0);
-  } else {
-    run_from<0, PROF, 2>(cx, c0);
-  }
+  run_from<0, PROF>(cx, c0);
   if (PROF && cx.prof && threadIdx.x == 0) cx.prof[kNumOps] = wall_clock64();
 }
 

@@ -202,7 +202,14 @@ struct FzTa {
   // (rides along too: 1 = the launch also writes the state tensors nothing in the kernel reads -- the input states of the strided convs,
   //  OpD::d0_on = 2 --, 0 = it leaves them to engine.cpp states_materialize, which rebuilds them from their second copy when asked)
   int eager;
+  // (and: activation trace of the PROFILING builds, nutls_debug_trace -- the outputs that never touch HBM in the fused kernel (input layer, the
+  //  12 CTFA outputs, the 6 up-sampling outputs) are copied to `dbg` + stream * dbg_sstride + slot * kDbgSlotFloats; null = off.  The
+  //  production kernels do not look at these fields.)
+  float* dbg; long long dbg_sstride;
 };
+// activation trace slots (floats per slot: the largest traced tensor, 256 x 128): 0 input layer [256][64]; 1 + k: output of CTFA k [F0][64]
+// (encoder stages 0..5, decoder stages 6..11); 13 + s: output of the up-sampling conv of decoder stage s [F0][128]
+constexpr int kDbgSlotFloats = 256 * 128, kDbgSlots = 19;
 // the lazily written state tensors of a fused plan: P rows x 32 channels, copied from the skip-connection slice the kernel does write
 struct LazyCopy { int src_off, src_ld, dst_off, dst_ld, rows, width; };      // float offsets inside a parity block of the arena
 hipError_t launch_lazy_states(float* arena, long long sstride, int block_off, const LazyCopy* tab, int n, int B, hipStream_t s);

@@ -35,7 +35,7 @@ NUTLS_ERR_ARG = -1
 ABI_SYMBOLS = (
     "nutls_create", "nutls_destroy", "nutls_step", "nutls_step_host", "nutls_io_buffers",
     "nutls_use_graph", "nutls_set_mode", "nutls_state_get", "nutls_state_set", "nutls_state_count",
-    "nutls_state_info", "nutls_reset", "nutls_debug_get", "nutls_batch",
+    "nutls_state_info", "nutls_reset", "nutls_debug_get", "nutls_debug_trace", "nutls_debug_knob", "nutls_batch",
     "nutls_launches_per_step", "nutls_launch_info", "nutls_profile_step",
     "nutls_last_error",
     "nutls_version",
@@ -81,6 +81,11 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_state_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_int), c.POINTER(c.c_int)]
     lib.nutls_reset.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_debug_get.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
+    dev_lib = p != _HERE_LIB      # (NUTLS_DEV=1 NUTLS_LIB=...: an experimental or OLDER build for an A/B run may lack the newest entry points)
+    if not dev_lib or hasattr(lib, "nutls_debug_trace"):
+        lib.nutls_debug_trace.argtypes = [c.c_void_p, c.c_int]
+    if not dev_lib or hasattr(lib, "nutls_debug_knob"):
+        lib.nutls_debug_knob.argtypes = [c.c_void_p, c.c_char_p, c.c_int]
     lib.nutls_batch.argtypes = [c.c_void_p]
     lib.nutls_streams_per_workgroup.argtypes = [c.c_void_p]
     lib.nutls_launches_per_step.argtypes = [c.c_void_p]
@@ -109,6 +114,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_last_error.restype = c.c_char_p
     lib.nutls_version.restype = c.c_char_p
     for name in ABI_SYMBOLS:
+        if dev_lib and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         if fn.restype is None or fn.restype is c.c_int:
             fn.restype = c.c_int
@@ -325,6 +332,15 @@ class NutlsEngine:
 
     def reset(self, stream_idx: int = -1) -> None:
         _check(self._lib, self._lib.nutls_reset(self._h, int(stream_idx)))
+
+    def debug_knob(self, name: str, value: int) -> None:
+        """Developer knobs of the handle (include/nutls.h nutls_debug_knob): "skew"."""
+        _check(self._lib, self._lib.nutls_debug_knob(self._h, name.encode(), int(value)))
+
+    def debug_trace(self, enable: bool = True) -> None:
+        """Fused mode: run every step on the profiling build of the step kernel, which also copies the tensors the kernel keeps in LDS
+        ("<stage>.y", "<stage>.up", "input_layer") to a trace buffer that ``debug_get`` reads (one-stream plan, <= 64 streams)."""
+        _check(self._lib, self._lib.nutls_debug_trace(self._h, 1 if enable else 0))
 
     def debug_get(self, name: str, per_stream_shape) -> np.ndarray:
         a = np.empty((self.batch,) + tuple(per_stream_shape), np.float32)

@@ -91,6 +91,20 @@ def _sigmoid(x):
     return np.where(x >= 0, 1.0 / (1.0 + e), e / (1.0 + e)).astype(F32)
 
 
+def _fake_quant_rows(x):
+    """TF-Lite's per-call activation quantisation of the hybrid kernels (`AsymmetricQuantizeFloats`, one batch row at a time): int8 codes
+    q = clamp(round(x / scale) + zp, -128, 127) with scale = (max(x, 0) - min(x, 0)) / 255, returned de-quantised, float32."""
+    x = np.asarray(x, dtype=F32)
+    flat = x.reshape(x.shape[0], -1).astype(np.float64)
+    lo = np.minimum(flat.min(axis=1, keepdims=True), 0.0)
+    hi = np.maximum(flat.max(axis=1, keepdims=True), 0.0)
+    scale = (hi - lo) / 255.0
+    scale[scale == 0.0] = 1.0
+    zp = np.clip(np.round(-128.0 - lo / scale), -128, 127)
+    q = np.clip(np.round(flat / scale) + zp, -128, 127)
+    return ((q - zp) * scale).astype(F32).reshape(x.shape)
+
+
 def _act(x, code):
     if code == 0:
         return x
@@ -159,10 +173,18 @@ class GraphOracle:
     ``torch.nn.functional`` -- third-party arithmetic for everything that carries FLOPs, so the goldens are not pinned to
     hand-written numpy alone (tests/test_oracle.py::test_oracle_a_numpy_ops_agree_with_torch_functional)."""
 
-    def __init__(self, path: str, backend: str = "numpy"):
+    def __init__(self, path: str, backend: str = "numpy", hybrid: bool = False):
+        """``hybrid``: emulate what the TF-Lite RUNTIME does beyond the float semantics of the graph: its hybrid CONV_2D (v5) and
+        FULLY_CONNECTED (v9) kernels quantise the ACTIVATIONS that meet an int8 weight tensor to int8 on every call (per batch row:
+        asymmetric, scale = (max - min) / 255 over the row, `tensor_utils::AsymmetricQuantizeFloats`), accumulate in int32 and scale
+        back.  Emulated as fake quantisation of those inputs (x -> (q - zp) * scale) in front of the float operator -- the same numbers
+        up to fp32 summation order.  This pins nothing (the runtime itself cannot run here); it turns "parity unpinned at the TF-Lite-
+        runtime level" into a number: how far ANY float execution of the shipped graph must be from that runtime
+        (tests/test_oracle.py::test_hybrid_quantisation_gap_of_the_tflite_runtime)."""
         if backend not in ("numpy", "torch"):
             raise ValueError("backend must be 'numpy' or 'torch'")
         self.backend = backend
+        self.hybrid = bool(hybrid)
         self.model = TFLiteModel(path)
         sig = self.model.signatures[0]
         self.key = sig.key
@@ -205,6 +227,13 @@ class GraphOracle:
                 return self._w(i) if t.dtype == np.int8 else self.consts[i]
             raise KeyError("tensor %d (%s) not computed" % (i, tensors[i].name))
 
+        def act_in(op_ins):
+            """input activations of a CONV_2D / FULLY_CONNECTED: as they are, or -- hybrid emulation, int8 weight constant -- fake-quantised"""
+            x = get(op_ins[0])
+            if not self.hybrid or tensors[op_ins[1]].dtype != np.int8:
+                return x
+            return _fake_quant_rows(x)
+
         tb = self.backend == "torch"
         if tb:
             import torch
@@ -215,12 +244,12 @@ class GraphOracle:
                 r = self._w(ins[0])
             elif tb and n == "CONV_2D":
                 b = get(ins[2]) if len(ins) > 2 and ins[2] >= 0 else None
-                r = _act(_conv2d_torch(get(ins[0]), get(ins[1]), b, o["stride_h"], o["stride_w"], o["padding"], o["dil_h"], o["dil_w"]), o["act"])
+                r = _act(_conv2d_torch(act_in(ins), get(ins[1]), b, o["stride_h"], o["stride_w"], o["padding"], o["dil_h"], o["dil_w"]), o["act"])
             elif tb and n == "TRANSPOSE_CONV":
                 b = get(ins[3]) if len(ins) > 3 and ins[3] >= 0 else None
                 r = _transpose_conv_torch(get(ins[0]), get(ins[1]), get(ins[2]), b, o["stride_h"], o["stride_w"], o["padding"])
             elif tb and n == "FULLY_CONNECTED":
-                x, w = get(ins[0]), get(ins[1])
+                x, w = act_in(ins), get(ins[1])
                 b = get(ins[2]) if len(ins) > 2 and ins[2] >= 0 else None
                 y = Fn.linear(torch.from_numpy(np.ascontiguousarray(x, dtype=F32)).reshape(-1, w.shape[1]), torch.from_numpy(np.ascontiguousarray(w, dtype=F32)),
                               None if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=F32))).numpy()
@@ -240,14 +269,14 @@ class GraphOracle:
                 r = Fn.prelu(torch.from_numpy(np.ascontiguousarray(x, dtype=F32)), torch.from_numpy(np.ascontiguousarray(a, dtype=F32)).reshape(-1)[:1]).numpy()
             elif n == "CONV_2D":
                 b = get(ins[2]) if len(ins) > 2 and ins[2] >= 0 else None
-                r = _act(_conv2d(get(ins[0]), get(ins[1]), b, o["stride_h"], o["stride_w"],
+                r = _act(_conv2d(act_in(ins), get(ins[1]), b, o["stride_h"], o["stride_w"],
                                  o["padding"], o["dil_h"], o["dil_w"]), o["act"])
             elif n == "TRANSPOSE_CONV":
                 b = get(ins[3]) if len(ins) > 3 and ins[3] >= 0 else None
                 r = _transpose_conv(get(ins[0]), get(ins[1]), get(ins[2]), b, o["stride_h"],
                                     o["stride_w"], o["padding"])
             elif n == "FULLY_CONNECTED":
-                x, w = get(ins[0]), get(ins[1])
+                x, w = act_in(ins), get(ins[1])
                 b = get(ins[2]) if len(ins) > 2 and ins[2] >= 0 else None
                 y = np.matmul(x.reshape(-1, w.shape[1]), w.T)
                 if b is not None:

@@ -101,6 +101,36 @@ def test_blob_packing_round_trips_the_container(variant, streams):
             assert np.array_equal(blk[2 * ntot + gc:2 * ntot + 2 * gc], W[o["wkey"] + ".beta"].reshape(-1))
             assert blk[2 * ntot + 2 * gc] == W[o["wkey"] + ".alpha"].reshape(-1)[0]
     assert n_conv == 128
+    # LSTM + Dense ops: the int8 gate kernels [K slice][unit][row] with the four gates of a unit in one dword, the record (bias | s_x, s_h), the
+    # Dense rows (int8 + bias + scale where the container holds them int8, fp32 otherwise) -- csrc/fused_plan.hpp "blob layout of an LSTM op"
+    n_lstm = 0
+    for o in plan["ops"]:
+        if o["type"] != 2 or o["g0"] != 0:
+            continue
+        n_lstm += 1
+        ln, dn = ("lstm", "dense") if o["wkey"] == "" else (o["wkey"] + "_lstm", o["wkey"] + "_dense")
+        din, dout = o["din"], o["dout"]
+        kn = din // 16
+        nrp = (max(kn, 6) + 3) // 4 * 4
+        gates = out[o["lw_off"]:o["lw_off"] + 420 * nrp].view(np.int8).reshape(20, 21, nrp, 4)
+        (qx, sx), (qh, sh) = Wq[ln + ".wx"], Wq[ln + ".wh"]
+        for g in range(4):          # Keras gate order i, f, g, o: rows g * 21 + u of the [84, K] kernels
+            assert np.array_equal(gates[:16, :, :kn, g].transpose(1, 0, 2).reshape(21, din), qx[g * 21:(g + 1) * 21]), ln
+            hpart = gates[16:, :, :6, g].transpose(1, 0, 2).reshape(21, 24)
+            assert np.array_equal(hpart[:, :21], qh[g * 21:(g + 1) * 21]) and not hpart[:, 21:].any(), ln
+        assert not gates[:16, :, kn:].any() and not gates[16:, :, 6:].any()
+        rec = out[o["lw_off"] + 420 * nrp:o["lw_off"] + 420 * nrp + 88]
+        assert np.array_equal(rec[:84].reshape(21, 4).T.reshape(-1), W[ln + ".b"]) and rec[84] == sx[0] and rec[85] == sh[0]
+        drow = out[o["lw_off"] + 420 * nrp + 88:]
+        if dout >= 64:
+            qd, sd = Wq[dn + ".w"]
+            rows = drow[:8 * dout].reshape(dout, 8)
+            assert np.array_equal(rows[:, :6].copy().view(np.int8).reshape(dout, 24)[:, :21], qd) and np.array_equal(rows[:, 6], W[dn + ".b"])
+            assert np.all(rows[:, 7] == sd[0])
+        else:
+            rows = drow[:24 * dout].reshape(dout, 24)
+            assert np.array_equal(rows[:, :21], W[dn + ".w"]) and np.array_equal(rows[:, 21], W[dn + ".b"])
+    assert n_lstm == (13 if variant == "lstm" else 0)
 
 
 @pytest.mark.parametrize("name,bottleneck", [("lstm", 2), ("base", 4)])

@@ -119,6 +119,40 @@ def test_oracle_a_live_reproduces_goldens(has_reference):
         g(input=np.zeros((1, 1, 256, 1), np.float32))
 
 
+@pytest.mark.reference
+def test_hybrid_quantisation_gap_of_the_tflite_runtime(has_reference):
+    """Build container only.  "Parity unpinned at the TF-Lite-runtime level" as a NUMBER: the reference's runtime quantises
+    the activations entering every int8-weight CONV_2D / FULLY_CONNECTED to int8 per call (hybrid kernels); `GraphOracle(hybrid=True)` emulates
+    that.  Over the first 40 frames of the golden clip its output is 3.0e-3 RMS away from the float execution of the same graph
+    (median per frame 1.3e-3, worst frame 1.5e-2; SURVEY measured 4.5e-3 over 100 frames) -- 15 000 x the distance between this repo's HIP kernels and
+    the float oracle (2e-7), and above the north-star's 1e-3: no float implementation can be within 1e-3 of that runtime, whatever it
+    does.  A maintainer with TensorFlow installed checks the emulation in one line:
+        tf.lite.Interpreter("nutls_lstm.tflite").get_signature_runner("nutls_lstm_sm")(**feeds)  vs  GraphOracle(path, hybrid=True)(**feeds)"""
+    if not has_reference:
+        pytest.skip("/root/reference not present")
+    from oracle.graph_exec import GraphOracle, _fake_quant_rows
+    # the quantiser itself: codes are int8, zero is exact, the error is at most half a step
+    x = np.array([[-1.0, 0.0, 0.3, 2.0], [0.5, 0.25, 0.0, 0.125]], np.float32)
+    xq = _fake_quant_rows(x)
+    assert xq[0, 1] == 0.0 and np.all(np.abs(xq - x) <= np.array([[3.0 / 255 / 2], [0.5 / 255 / 2]]) + 1e-7)
+    gf, gh = GraphOracle(REFERENCE_TFLITE, backend="torch"), GraphOracle(REFERENCE_TFLITE, backend="torch", hybrid=True)
+    clip = np.load(os.path.join(GOLDEN, "clip_4s.npz"))
+    of, oh = SE.zero_state(), SE.zero_state()
+    se, n, per_frame = 0.0, 40, []
+    for i in range(n):
+        m = clip["mags_in"][i].reshape(1, 1, 256, 1)
+        of = gf(**SE.feeds_from_outputs(of, m))
+        oh = gh(**SE.feeds_from_outputs(oh, m))
+        d = (of["model_out"] - oh["model_out"]).reshape(-1).astype(np.float64)
+        per_frame.append(float(np.sqrt(np.mean(d * d))))
+        se += float(np.mean(d * d))
+    gap = float(np.sqrt(se / n))
+    print("hybrid-quantisation gap over %d frames: %.3e RMS (median per frame %.3e, max %.3e)" % (n, gap, float(np.median(per_frame)), max(per_frame)))
+    assert 1e-3 < gap < 2e-2
+    # and the float execution is the one the goldens hold (the emulation did not leak into it)
+    assert rms(of["model_out"].reshape(-1), clip["mags_out"][n - 1]) < 1e-6
+
+
 # ------------------------------------------------------------------------------------------------
 #  Baseline variant (dilated-dense bottleneck, BASELINE config 3).  No trained weights / goldens
 #  exist anywhere (SURVEY.md F3), so the STREAMING restatement is pinned against an independent

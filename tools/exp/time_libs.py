@@ -15,14 +15,17 @@ pool = torch.from_numpy((0.25 * np.abs(rng.standard_normal((8, B, 256)))).astype
 out = torch.empty(B, 256, device="cuda")
 for s in range(32): eng.step(pool[s %% 8], out)
 torch.cuda.synchronize()
-best = 1e9
-for rep in range(3):
+for s in range(600): eng.step(pool[s %% 8], out)          # (steady clocks)
+torch.cuda.synchronize()
+ts = []
+for rep in range(7):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
-    for s in range(200): eng.step(pool[s %% 8], out)
+    for s in range(300): eng.step(pool[s %% 8], out)
     ev[1].record(); torch.cuda.synchronize()
-    best = min(best, ev[0].elapsed_time(ev[1]) / 200)
-print("%%-16s %%.4f ms/step" %% (os.environ.get("EXP_NAME"), best))
+    ts.append(ev[0].elapsed_time(ev[1]) / 300)
+ts.sort()
+print("%%-16s %%.4f ms/step (min of 7 x 300; median %%.4f)" %% (os.environ.get("EXP_NAME"), ts[0], ts[3]))
 if os.environ.get("EXP_TIMELINE"):
     plan = eng.fused_plan()
     for _ in range(3): eng.profile_fused()

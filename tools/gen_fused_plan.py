@@ -29,7 +29,7 @@ def plan_tag(variant, G=1):
     return ("lstm" if variant == "lstm" else "base") + ("" if G == 1 else "_g%d" % G)
 
 
-OUT_DIR = os.environ.get("NUTLS_PLAN_OUT")      # developer knob (tools/exp/build_role_lib.sh): write the plans (and their dumps) here, not into the tree
+OUT_DIR = os.environ.get("NUTLS_PLAN_OUT")      # developer knob (tools/exp/build_plan_lib.sh): write the plans (and their dumps) here, not into the tree
 
 
 def inc_path(variant, G=1):
@@ -44,7 +44,7 @@ def json_path(variant, G=1):
 PLANS = [("lstm", 1), ("baseline", 1), ("lstm", 2), ("lstm", 4)]
 KFIRST = os.environ.get("NUTLS_PLAN_KFIRST", "1") != "0"    # K-split-first tilings of the small layers (developer knob: 0 = the round-4 tilings)
 LAZY = os.environ.get("NUTLS_PLAN_LAZY", "1") != "0"        # strided convs' input states written lazily (OpD::d0_on = 2)
-ROLES = os.environ.get("NUTLS_PLAN_ROLES", "0") != "0"      # role ops in the one-stream plans (developer knob: 0 = the round-4 tilings)
+EPL1 = os.environ.get("NUTLS_PLAN_EPL1", "1") != "0"        # one output element per lane in the row-wise epilogue of the layers with <= 512 outputs (OpD::epl)
 
 # (prefix, depth, f0, conv state tag, sub-pixel state tag, resample layer)   converter_proposed.py:221-727
 ENC = [("msfe6_en", 6, 256, "msfe6_ee", "msfe6_ed", "msfe6_down_sampling"),
@@ -155,6 +155,13 @@ class Blob:
         return off
 
 
+def lstm_blob_floats(din, dout):
+    """Blob floats of an LSTM + Dense op: int8 gate kernels [20 slices][21 units][NRP dwords] | record 88 | Dense rows (8 dwords each where
+    the container holds them int8 -- dout >= 64 -- else 24 fp32): mirrors fused_plan.hpp lstm_blob_f."""
+    nrp = (max(din // 16, 6) + 3) // 4 * 4
+    return 20 * 21 * nrp + 88 + (8 if dout >= 64 else 24) * dout
+
+
 def conv_geom(kind, side, i_or_j, D):
     """(cin, N, taps, kf, stride, ln, R, gc) of a conv op (models/proposed.py:198-265)."""
     if kind == K_IN:
@@ -199,8 +206,7 @@ def tiling(kind, N, P, cin, taps, rounds=1, gs=1, waves=8, fits=None, ys=0):
     LayerNorm groups per wave.  X16B: 16x16x32 bf16 tiles, wave task = (position group pg, channel tile ct, K slice
     (time tap ks_t, channel-group range ks_g)), PT tiles per wave; the K slices meet in the LDS exchange buffer.
     Packed plans: `gs` streams side by side -- the tiling is that of gs * P positions (32x32 tiles: whole tiles per stream).
-    None: no tiling for that many positions (the layer then runs one stream at a time).
-    waves = 4: the tiling of a "role" op (OpD.role): its wave tasks run on waves 4..7 only, waves 0..3 serve (staging, epilogue)."""
+    None: no tiling for that many positions (the layer then runs one stream at a time)."""
     per_stream = P
     P = gs * P
     table = {**R32_TABLE, **R32_TABLE_PACKED} if gs > 1 else R32_TABLE
@@ -213,19 +219,6 @@ def tiling(kind, N, P, cin, taps, rounds=1, gs=1, waves=8, fits=None, ys=0):
     assert P <= 64, (kind, N, P)
     CT = N // 16
     ptiles = (P + 15) // 16
-    if waves == 4:
-        # role op: four wave tasks, K split FIRST (time tap, then channel-group halves / quarters of every segment), every task all the
-        # channel tiles that are left (NT of them): the four matrix waves then read disjoint B fragments -- with one channel tile per
-        # wave each of them read the whole image, and the MFMA phase of a 36-MFMA op was LDS-bound (4 x 36 ds_read_b128 = 1150 cycles
-        # of LDS time for 612 of MFMA issue)
-        assert ptiles == 1 and kind != K_UP and rounds == 1
-        KSt = min(taps, 4)
-        KSg = 1
-        while KSt * KSg * 2 <= 4 and (cin // 32) % (KSg * 2) == 0:
-            KSg *= 2
-        CG = max(1, 4 // (KSt * KSg))
-        assert CT % CG == 0 and KSt * KSg * CG == 4, (kind, N, P, cin)
-        return dict(path=P_X16B, PT=1, NT=CT // CG, PG=1, CG=CG, KSt=KSt, KSg=KSg)
     if KFIRST and gs == 1 and kind != K_UP and rounds == 1 and ptiles == 1 and CT <= 4:
         # K split FIRST (one-stream plans): the waves of a position group that differ only in their channel tile read the SAME B
         # fragments -- eight waves x the whole K range of a 128-channel sub-pixel conv are 8 x 36 ds_read_b128 per position tile, and
@@ -472,7 +465,7 @@ def build_for(variant, G, cls):
                  d0=None, d1=None, row_mul=1, row_add=0, fwd=None, img=None, nxt=-1, parts=[],
                  din=0, dout=0, x_b=0, x_pitch_b=0, x_cols=0, y_b=0, h_off=0, c_off=0, ldst=None, lw_off=0,
                  F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0, x_fmt=0, x_plane_b=0, ys=0, ys_off=0, xs_off=0, xs_ld=0,
-                 gs=1, g0=0, scr_b=SCR_B, scr_gstride_b=0, xcopy_b=XCOPY_B, x_gstride_b=0, layer=-1, role=0)
+                 gs=1, g0=0, scr_b=SCR_B, scr_gstride_b=0, xcopy_b=XCOPY_B, x_gstride_b=0, layer=-1, epl=4)
         d.update(kw)
         d["gs"] = gs_of(d["name"])
         ops.append(d)
@@ -487,20 +480,13 @@ def build_for(variant, G, cls):
                    rounds=rounds, d0=d0, d1=d1, row_mul=row_mul, row_add=row_add, ys=ys)
         gs = o["gs"]
         VP = gs * P         # positions of the op's streams side by side
-        # Role ops (one-stream plans): a small layer -- one position tile, at most four channel tiles -- keeps its MFMA work on waves 4..7
-        # (four wave tasks, every weight fragment widened to bf16 by those waves in the shadow of the op BEFORE) while waves 0..3 issue the
-        # staging loads, run the row-wise epilogue and complete the next image: the two halves of a small op's latency chain get their
-        # own instruction streams (fused_step.hip run_role_op; profiles/r05_v0_wave_trace.txt is what it answers)
-        role = 1 if (ROLES and G == 1 and gs == 1 and P <= 16 and N // 16 <= 4 and kind != K_UP and rounds == 1) else 0
         ntot_ = N * (2 if kind == K_UP else 1)
         img_b = make_img(kind, P, cin, rounds, fmt=1, cps=ys)["bytes"]
 
         def fits(ks):      # image + exchange buffer of ks slices below the scratch
             return img_b <= (SCR_B - ks * P * (ntot_ + 4) * 4) // 256 * 256
-        o.update(tiling(kind, N, P, cin, taps, rounds, gs=gs, waves=4 if role else 8, fits=fits, ys=ys))
+        o.update(tiling(kind, N, P, cin, taps, rounds, gs=gs, fits=fits, ys=ys))
         assert not (ys and o["path"] == P_X16B and o["KSt"] == 1 and o["KSg"] > 1), name      # (both taps per wave: one K slice)
-        o["role"] = role if o["path"] == P_X16B else 0
-        assert o["role"] == role, name
         ntot = N * (2 if kind == K_UP else 1)
         x16 = o["path"] == P_X16B
         if x16:
@@ -538,6 +524,9 @@ def build_for(variant, G, cls):
         else:
             nf = segw * (cin // 16) * o["NT"]
             wtasks = o["CG"]
+        if x16:
+            # (fused_plan.hpp OpD::epl: one output element per lane in the row-wise epilogue where the layer has at most one element per thread)
+            o["epl"] = 1 if (EPL1 and VP * ntot <= 512 and gc in (32, 64) and kind != K_UP) else 4
         o["w_off"] = W.add(wtasks * ((nf + 1) // 2) * 256, "conv_w", wkey)
         o["p_off"] = W.add(2 * ntot + 2 * gc + 1, "conv_p", wkey)      # bias | per-channel weight scale | gamma | beta | alpha
         return o
@@ -574,7 +563,7 @@ def build_for(variant, G, cls):
         else:
             l = new_op(type=T_LSTM, name=p + "_lstm", wkey=p, din=fd * 32, dout=fd * 32, x_cols=32,
                        h_off=A.off[p + "_h"], c_off=A.off[p + "_c"], ldst=(S_CUR, st_off(stg, 1), 64), drain=1)
-            l["lw_off"] = W.add((l["din"] + 24) * 84 + 84 + 24 * l["dout"], "lstm", p)
+            l["lw_off"] = W.add(lstm_blob_floats(l["din"], l["dout"]), "lstm", p)
         lst.append(l)
         for j in range(1, D + 1):
             P = fd << (j - 1)
@@ -601,11 +590,12 @@ def build_for(variant, G, cls):
         cl = new_op(type=T_DDB, name="ddb", wkey="", din=256, dout=256, x_cols=64, bidx=6, drain=1, flops=ddb_flops(4, 64))
     else:
         cl = new_op(type=T_LSTM, name="lstm", wkey="", din=256, dout=256, x_cols=64, h_off=A.off["state_h"], c_off=A.off["state_c"], ldst=None, drain=1)
-        cl["lw_off"] = W.add((256 + 24) * 84 + 84 + 24 * 256, "lstm", "")
+        cl["lw_off"] = W.add(lstm_blob_floats(256, 256), "lstm", "")
     ups = {}
     for s in range(6):
         p, D, f0, ct, stg, rs = DEC[s]
         ups[s] = conv_op(rs, rs, K_UP, 1, 0, D, f0 // 2, row_mul=2)
+        ups[s]["bidx"] = s          # (up-sampling convs: which decoder stage -- the slot of its output in the activation trace of the profiling build)
         stage_ops[(1, s)] = stage(1, s)
     layers = ops
     for i, o in enumerate(layers):
@@ -989,7 +979,7 @@ def emit(A, W, ops, G=1):
         seg_b = ",".join(str(x) for x in pad(o["seg_b"], MAX_SEG))
         ldst = o["ldst"]
         row = ("{%d, /*conv*/ %d,%d,%d,%d,%d,%d,%d, %d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, %d,{%s}, %d, %d,%d, %s, %s, %d,%d, %s, %s, %d, "
-               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d, /*role*/ %d},   // %d %s") % (
+               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d, /*epl*/ %d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
             o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"], o["lazy0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
@@ -997,7 +987,7 @@ def emit(A, W, ops, G=1):
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
             1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["x_fmt"], o["x_plane_b"], o["lw_off"],
             o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["ys"], o["ys_off"], o["xs_off"], o["xs_ld"],
-            o["gs"], o["g0"], o["scr_b"], o["scr_gstride_b"], o["xcopy_b"], o["x_gstride_b"], o["layer"], o["role"], o["idx"], op_label(o))
+            o["gs"], o["g0"], o["scr_b"], o["scr_gstride_b"], o["xcopy_b"], o["x_gstride_b"], o["layer"], o["epl"], o["idx"], op_label(o))
         L.append("  " + row)
     L.append("};")
     # what the host needs to pack the blob / check the arena
