@@ -169,16 +169,25 @@ def bench_offline(args, rank, world, local_rank):
     import torch
     import nunet_amd
     T_ = args.offline
-    U = max(1, args.offline_utterances)      # independent utterances, one handle and one torch stream each
-    offs = [nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, pipeline=args.offline_chunks) for _ in range(U)]
-    pool = torch.from_numpy(synthetic_pool(T_, 4, 1234 + rank)).cuda()
-    outs = [torch.empty(T_, 256, device="cuda") for _ in range(U)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(U - 1)]
+    U = max(1, args.offline_utterances)      # independent utterances
+    batched = U > 1 and not args.offline_handles
+    if batched:
+        # ONE handle with a batch dimension (nutls_create_offline_batch): every layer one launch over the frames of all utterances
+        offs = [nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, utterances=U)]
+        pool = torch.from_numpy(np.stack([synthetic_pool(T_, 4, 1234 + rank + 7 * u) for u in range(U)], axis=1)).cuda()      # [4, U, T, 256]
+        outs = [torch.empty(U, T_, 256, device="cuda")]
+        streams = [torch.cuda.current_stream()]
+    else:
+        # (--offline-handles: one handle and one torch stream per utterance -- round 3's way of running several utterances)
+        offs = [nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, pipeline=args.offline_chunks) for _ in range(U)]
+        pool = torch.from_numpy(synthetic_pool(T_, 4, 1234 + rank)).cuda()
+        outs = [torch.empty(T_, 256, device="cuda") for _ in range(U)]
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(U - 1)]
     out = outs[0]
 
     def blocks(n):
         for s in range(n):
-            for u in range(U):
+            for u in range(len(offs)):
                 with torch.cuda.stream(streams[u]):
                     offs[u].process_block_device(pool[(s + u) % 4], outs[u])
 
@@ -214,8 +223,10 @@ def bench_offline(args, rank, world, local_rank):
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup // 8),
                           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic magnitudes 0.25*|N(0,1)|, trained weights",
-                          "config": {"workload": "offline / block mode: %s, %d consecutive frames per call (SURVEY 8f.2)" % ("ONE utterance" if U == 1 else "%d utterances side by side" % U, T_),
-                                     "frames_per_block": T_, "utterances": U, "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames, 3 from 768)",
+                          "config": {"workload": "offline / block mode: %s, %d consecutive frames per call (SURVEY 8f.2)" % (
+                                         "ONE utterance" if U == 1 else ("%d utterances in one handle ([U, T, 256] per call)" % U if batched else "%d utterances, one handle and stream each" % U), T_),
+                                     "frames_per_block": T_, "utterances": U, "batched_handle": batched,
+                                     "pipeline_chunks": "none (several utterances per launch)" if batched else (args.offline_chunks or "auto (2 from 256 frames, 3 from 768)"),
                                      "mode": "per-layer kernels, frame index as stream index, single-wavefront LSTM scan, block pipeline"},
                           "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6),
                           "host_enqueue_ms_per_block": round(1e3 * t_enq / args.steps, 4)}))
@@ -345,7 +356,8 @@ def main():
     ap.add_argument("--offline", type=int, default=0, metavar="T",
                     help="offline / block mode: ONE utterance, a step = one block of T consecutive frames (frames/s of that utterance)")
     ap.add_argument("--offline-chunks", type=int, default=0, help="offline mode: chunks of the block pipeline (0 = library default)")
-    ap.add_argument("--offline-utterances", type=int, default=1, help="offline mode: independent utterances processed side by side, one handle and stream each (value = their total frames/s)")
+    ap.add_argument("--offline-utterances", type=int, default=1, help="offline mode: independent utterances per call, the batch dimension of ONE handle (value = their total frames/s)")
+    ap.add_argument("--offline-handles", action="store_true", help="offline mode with several utterances: one handle and one stream per utterance instead of one batched handle")
     ap.add_argument("--ctfa-mode", default="frame", choices=["frame", "causal32"],
                     help="causal32: the offline model's 32-frame causal CTFA in the streaming kernel (per-stream attention history kept by the library: "
                          "BASELINE configs[4]'s 'persistent CTFA state'); default: what the reference's streaming graph computes (TA / 32)")

@@ -111,6 +111,13 @@ int nutls_istft_hop(nutls_handle* h, float* pcm_out, int dc_mode, void* stream);
  * streaming CTFA of converter_proposed.py:258-262); the state carries over from block to block inside the handle
  * and is zeroed by nutls_reset(h, -1).  mag_in / mag_out: DEVICE pointers to [n_frames, 256] float32. */
 int nutls_create_offline(const void* weights, size_t n_bytes, int max_frames, int device, nutls_handle** out);
+/* The same with a BATCH dimension -- the offline forward of the reference takes [B, T, ...] (models/proposed.py:284-625): `utterances`
+ * (1 .. 256, utterances x max_frames <= 65536) independent utterances per handle, every call processes the same number of frames of each:
+ * mag_in / mag_out are [utterances, n_frames, 256].  Every conv-like layer is ONE launch over the frames of all utterances, the 13 LSTM
+ * recurrences of the utterances are scanned side by side (one wavefront each).  Each utterance carries its own state from block to block;
+ * nutls_reset(h, u) zeroes utterance u (-1: all), nutls_state_get / _set take [utterances, ...] buffers, nutls_state_get_all(h, u, ...) one
+ * utterance's.  Results per utterance equal those of a one-utterance handle (same kernels, same tilings). */
+int nutls_create_offline_batch(const void* weights, size_t n_bytes, int max_frames, int utterances, int device, nutls_handle** out);
 int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, int n_frames, void* stream);
 /* The frequency-attention branch of CTFA in offline handles:
  *   NUTLS_CTFA_FRAME     (default) what the frame-wise graph computes: the branch sees TA/32 (ctfa_rt with T = 1,

@@ -24,6 +24,7 @@ if os.environ.get("NUTLS_BUILD_G4_PROF") == "1":      # developer knob: the prof
     SOURCES.insert(3, "fused_step_g4_prof.hip")
 # (headers are found by scanning the #include "..." lines of every source: _deps)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+LAST_BUILD = None      # what the last build() call did: {"mode", "rebuilt": [...], "sources", "seconds", "linked"}
 
 
 def _hipcc() -> str:
@@ -81,11 +82,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     only = os.environ.get("NUTLS_BUILD_ONLY")      # developer knob while iterating on one kernel: re-compile just these (stale objects of the others are linked as they are)
     if only:
         todo = [s for s in todo if s in only.split(",")]
+    global LAST_BUILD
     if not todo and not only and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(_obj(s)) for s in SOURCES):
+        LAST_BUILD = {"mode": "force" if force else "incremental", "rebuilt": [], "sources": len(SOURCES), "seconds": 0.0, "linked": False}
+        print("nutls build: rebuilt 0 of %d sources (every object is newer than its source and headers), library up to date" % len(SOURCES), flush=True)
         return LIB
+    import time
+    t0 = time.time()
+    # (the longest compiles first: the 4-stream packed kernel alone is 12 minutes, the pool must not start it last)
+    order = sorted(todo, key=lambda s: {"fused_step_g4.hip": 0, "fused_step_g4_prof.hip": 0, "fused_step_g2.hip": 1}.get(s, 2))
     with ThreadPoolExecutor(max_workers=6) as ex:
-        list(ex.map(lambda s: _run([hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", _obj(s)], verbose), todo))
+        list(ex.map(lambda s: _run([hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", _obj(s)], verbose), order))
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in SOURCES], verbose)
+    LAST_BUILD = {"mode": "force" if force else "incremental", "rebuilt": list(todo), "sources": len(SOURCES), "seconds": round(time.time() - t0, 1), "linked": True}
+    print("nutls build: rebuilt %d of %d sources (%s) and linked in %.0f s" % (len(todo), len(SOURCES), ", ".join(todo) or "-", time.time() - t0), flush=True)
     return LIB
 
 

@@ -139,6 +139,8 @@ struct Engine {
   float *t_inlayer = nullptr, *t_y = nullptr, *t_d = nullptr, *t_up = nullptr;
   float* upcat[6] = {nullptr};
   int offline = 0;       // > 0: offline / block handle for up to this many frames per call (arena slot 0 = carried state)
+  int outt = 1;          // utterances of an offline handle (nutls_create_offline_batch): utterance u owns arena slots [u (offline + 1), (u + 1) (offline + 1)):
+                         // its carried state, then its frames
   std::vector<Launch> plan_off;   // plan[0] with 'previous frame' = one arena slot earlier
   bool off_bf16 = false;          // block mode: convs on the bf16 matrix pipe where the container holds int8 kernels (NUTLS_OFFLINE_FP32=1: the fp32-MFMA kernels)
   float* zx = nullptr;   // [offline + kScanReadAhead][84] LSTM input products of a block
@@ -1174,6 +1176,7 @@ static int create_body(const void* weights, size_t n_bytes, int variant, int bat
   for (int s = 0; s < 6; ++s) e->debug[std::string(kDecoder[s].prefix) + ".upcat"] = {e->upcat[s], static_cast<size_t>(kDecoder[s].f0 / 2) * 128};
   if (offline_frames > 0) {
     e->offline = offline_frames;
+    e->outt = batch / (offline_frames + 1);
     e->mode = 0;
     if ((rc = build_offline_plan(e))) return rc;
   }
@@ -1192,9 +1195,15 @@ int nutls_create_plan(const void* weights, size_t n_bytes, int variant, int batc
 }
 
 int nutls_create_offline(const void* weights, size_t n_bytes, int max_frames, int device, nutls_handle** out) {
+  return nutls_create_offline_batch(weights, n_bytes, max_frames, 1, device, out);
+}
+
+int nutls_create_offline_batch(const void* weights, size_t n_bytes, int max_frames, int utterances, int device, nutls_handle** out) {
   if (max_frames < 1 || max_frames > 4096) return fail(NUTLS_ERR_ARG, "nutls_create_offline: max_frames must be 1..4096");
-  // arena slot 0 holds the state carried in from the previous block, slots 1..max_frames the frames of the block
-  return create_common(weights, n_bytes, NUTLS_VARIANT_LSTM, max_frames + 1, device, max_frames, out);
+  if (utterances < 1 || utterances > 256) return fail(NUTLS_ERR_ARG, "nutls_create_offline_batch: utterances must be 1..256");
+  if (static_cast<long long>(utterances) * max_frames > 65536) return fail(NUTLS_ERR_ARG, "nutls_create_offline_batch: utterances x max_frames must be <= 65536");
+  // per utterance: one arena slot for the state carried in from the previous block, then max_frames slots for the frames of the block
+  return create_common(weights, n_bytes, NUTLS_VARIANT_LSTM, utterances * (max_frames + 1), device, max_frames, out);
 }
 
 // ---- offline / block mode -------------------------------------------------------------------------
@@ -1235,9 +1244,9 @@ static int build_offline_plan(Engine* e) {
   }
   if (g + 2 > Engine::kGroups) return fail(NUTLS_ERR_ARG, "offline plan: more bottlenecks than pipeline groups");      // (the last event of a chunk is its join event)
   // (the chunk streams and their events are created when a block first runs with that many chunks: ensure_chunk_streams)
-  int rc = dev_alloc(e, (static_cast<size_t>(e->offline) + kScanReadAhead) * 84, &e->zx, true);
+  int rc = dev_alloc(e, (static_cast<size_t>(e->outt) * e->offline + kScanReadAhead) * 84, &e->zx, true);
   if (rc) return rc;
-  return dev_alloc(e, static_cast<size_t>(12) * (31 + e->offline) * 64, &e->ta_hist, true);
+  return dev_alloc(e, static_cast<size_t>(e->outt) * 12 * (31 + e->offline) * 64, &e->ta_hist, true);      // [utterance][stage][31 + frame][64]
 }
 
 int nutls_offline_set_pipeline(nutls_handle* h, int chunks) {
@@ -1250,8 +1259,14 @@ int nutls_offline_set_pipeline(nutls_handle* h, int chunks) {
 // Launches [first, last) of the block plan for frames [t0, t0 + n) on stream s: every per-frame tensor (arena slots,
 // magnitudes in / out, LSTM input products, time-attention history) is addressed from frame t0.
 static int launch_block_range(Engine* e, size_t first, size_t last, int t0, int n, bool roll_hist, hipStream_t s) {
+  // (several utterances: the launches run all of them -- dense stream index u * n + t, SlotMap: utterance u's frames start (offline + 1) slots
+  //  after utterance u - 1's; such blocks are not cut into chunks, so t0 = 0 and the magnitudes of the block are dense too)
+  const int U = e->outt;
+  const SlotMap sm = U > 1 ? make_slot_map(n, e->offline + 1 - n) : make_slot_map(0, 0);
+  const long long utt_stride = static_cast<long long>(e->offline + 1) * static_cast<long long>(e->sstride);
+  const long long hist_ustride = static_cast<long long>(12) * (31 + e->offline) * 64;
   const float* a0 = e->arena;
-  const float* a1 = e->arena + (static_cast<size_t>(e->offline) + 1) * e->sstride;
+  const float* a1 = e->arena + static_cast<size_t>(U) * (static_cast<size_t>(e->offline) + 1) * e->sstride;
   const size_t d = static_cast<size_t>(t0) * e->sstride;
   auto shc = [&](const float*& q) { if (q && q >= a0 && q < a1) q += d; };
   auto sh = [&](float*& q) { if (q && q >= a0 && q < a1) q += d; };
@@ -1263,32 +1278,37 @@ static int launch_block_range(Engine* e, size_t first, size_t last, int t0, int 
     switch (L.kind) {
       case Launch::CONV:
         shc(L.conv.src0); shc(L.conv.src1); sh(L.conv.dst0); sh(L.conv.dst1);
-        L.conv.B = n;
+        L.conv.B = U * n;
+        L.conv.sm = sm;
         L.conv.use_bf16 = e->off_bf16 && L.conv.wbf != nullptr;
         err = launch_conv(L.ck, L.conv, s);
         break;
       case Launch::LSTM:
         shc(L.lstm.x); sh(L.lstm.dst); shc(L.lstm.h_in); shc(L.lstm.c_in); sh(L.lstm.h_out); sh(L.lstm.c_out);
-        L.lstm.B = n;
-        err = launch_lstm_block(L.lstm, e->zx + static_cast<size_t>(t0) * 84, n, s);
+        L.lstm.B = U * n;
+        L.lstm.sm = sm;
+        err = launch_lstm_block(L.lstm, e->zx + static_cast<size_t>(U) * t0 * 84, n, s, U, utt_stride);
         break;
       case Launch::CTFA: {
         shc(L.ctfa.x); shc(L.ctfa.e0); sh(L.ctfa.y);
-        L.ctfa.B = n;
+        L.ctfa.B = U * n;
+        L.ctfa.sm = sm;
         float* hist = e->ta_hist + static_cast<size_t>(n_ctfa) * (31 + e->offline) * 64 + static_cast<size_t>(t0) * 64;
-        if (e->ctfa_causal) err = launch_ctfa_causal(L.ctfa, hist, roll_hist, s);
+        if (e->ctfa_causal) err = launch_ctfa_causal(L.ctfa, hist, roll_hist, s, U, hist_ustride);
         else err = launch_ctfa(L.ctfa, s);
         ++n_ctfa;
         break;
       }
       case Launch::INLAYER:
         L.inl.x += static_cast<size_t>(t0) * NUTLS_BINS; sh(L.inl.y);
-        L.inl.n_pos = n * NUTLS_BINS;
+        L.inl.n_pos = U * n * NUTLS_BINS;
+        L.inl.sm = sm;
         err = launch_input_layer(L.inl, s);
         break;
       case Launch::OUTCONV:
         shc(L.outc.x); L.outc.y += static_cast<size_t>(t0) * NUTLS_BINS;
-        L.outc.n_pos = n * NUTLS_BINS;
+        L.outc.n_pos = U * n * NUTLS_BINS;
+        L.outc.sm = sm;
         err = launch_out_conv(L.outc, s);
         break;
       default: err = hipErrorInvalidValue;
@@ -1321,7 +1341,7 @@ int nutls_offline_set_ctfa_mode(nutls_handle* h, int mode) {
   if (e->ctfa_causal == (mode == NUTLS_CTFA_CAUSAL32)) return NUTLS_OK;      // already in effect: the history stays
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(e->ta_hist, 0, static_cast<size_t>(12) * (31 + e->offline) * 64 * sizeof(float)));      // a mode switch starts a new history
+  HIP_TRY(hipMemset(e->ta_hist, 0, static_cast<size_t>(e->outt) * 12 * (31 + e->offline) * 64 * sizeof(float)));      // a mode switch starts a new history
   e->ctfa_causal = mode == NUTLS_CTFA_CAUSAL32;
   return NUTLS_OK;
 }
@@ -1357,11 +1377,15 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
   if (n_frames < 1 || n_frames > e->offline) return fail(NUTLS_ERR_ARG, "nutls_process_block: n_frames out of range");
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t bytes = static_cast<size_t>(n_frames) * NUTLS_BINS * sizeof(float);
+  const int U = e->outt;
+  const size_t bytes = static_cast<size_t>(U) * n_frames * NUTLS_BINS * sizeof(float);
   if (mag_in != e->io_in) HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyDeviceToDevice, s));
   int C = e->ochunks;
   if (C == 0) C = n_frames >= 768 ? 3 : n_frames >= 256 ? 2 : 1;      // (four compute queues are served at a time: chunk 0 rides on the caller's stream, three chunks = three queues)
   C = std::max(1, std::min({C, static_cast<int>(Engine::kMaxChunks), n_frames}));
+  // several utterances: every launch already runs all of them -- their 13 scans side by side on their own wavefronts, the small layers U
+  // times fuller -- and the block is not cut into chunks (the chunk pipeline overlaps ONE utterance's scans with its convs)
+  if (U > 1) C = 1;
   if (C == 1) {
     int rc = launch_block_range(e, 0, e->plan_off.size(), 0, n_frames, true, s);
     if (rc) return rc;
@@ -1417,8 +1441,11 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
       }
   }
   if (mag_out != e->io_out) HIP_TRY(hipMemcpyAsync(mag_out, e->io_out, bytes, hipMemcpyDeviceToDevice, s));
-  // the last frame's slot becomes the carried state of the next block
-  HIP_TRY(hipMemcpyAsync(e->arena, e->arena + static_cast<size_t>(n_frames) * e->sstride, e->sstride * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // the last frame's slot of every utterance becomes its carried state of the next block
+  {
+    const size_t pitch = (static_cast<size_t>(e->offline) + 1) * e->sstride * sizeof(float);
+    HIP_TRY(hipMemcpy2DAsync(e->arena, pitch, e->arena + static_cast<size_t>(n_frames) * e->sstride, pitch, e->sstride * sizeof(float), U, hipMemcpyDeviceToDevice, s));
+  }
   e->steps += n_frames;
   return NUTLS_OK;
 }
@@ -1428,7 +1455,7 @@ int nutls_process_block_host(nutls_handle* h, const float* mag_in, float* mag_ou
   Engine* e = &h->eng;
   if (!e->offline || n_frames < 1 || n_frames > e->offline) return fail(NUTLS_ERR_ARG, "nutls_process_block_host: not an offline handle or n_frames out of range");
   HIP_TRY(hipSetDevice(e->device));
-  const size_t bytes = static_cast<size_t>(n_frames) * NUTLS_BINS * sizeof(float);
+  const size_t bytes = static_cast<size_t>(e->outt) * n_frames * NUTLS_BINS * sizeof(float);
   HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyHostToDevice, e->stream));
   int rc = nutls_process_block(h, e->io_in, e->io_out, n_frames, e->stream);
   if (rc) return rc;
@@ -1615,7 +1642,7 @@ static int state_lookup(Engine* e, const char* name, size_t n_floats, StateTenso
   auto it = e->state_index.find(name);
   if (it == e->state_index.end()) return fail(NUTLS_ERR_ARG, std::string("unknown state tensor: ") + name);
   StateTensor* st = &e->states[it->second];
-  const size_t nb = e->offline ? 1 : static_cast<size_t>(e->B);      // an offline handle is ONE utterance (arena slot 0 = carried state)
+  const size_t nb = e->offline ? static_cast<size_t>(e->outt) : static_cast<size_t>(e->B);      // an offline handle: its utterances (carried state of utterance u in arena slot u (offline + 1))
   if (n_floats != st->per_stream() * nb)
     return fail(NUTLS_ERR_ARG, std::string("size mismatch for ") + name + ": expected " + std::to_string(st->per_stream() * nb) +
                                    " floats, got " + std::to_string(n_floats));
@@ -1632,7 +1659,11 @@ int nutls_state_get(nutls_handle* h, const char* name, float* host_buf, size_t n
   HIP_TRY(hipSetDevice(e->device));
   if (int rcm = states_materialize(e, nullptr)) return rcm;      // (lazily written states: brought up to date before anything outside the kernel looks)
   HIP_TRY(hipDeviceSynchronize());
-  if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), host_buf, true, 0);
+  if (e->offline) {
+    for (int u = 0; u < e->outt; ++u)
+      if (int rcu = copy_stream_tensor(e, st->buf[0], st->per_stream(), host_buf + static_cast<size_t>(u) * st->per_stream(), true, u * (e->offline + 1))) return rcu;
+    return NUTLS_OK;
+  }
   rc = copy_stream_tensor(e, st->buf[1 - e->next_parity], st->per_stream(), host_buf, true);
   if (rc == NUTLS_OK && st->ring_d > 1) rotate_ring(e, *st, host_buf, true);
   return rc;
@@ -1647,7 +1678,11 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
   HIP_TRY(hipSetDevice(e->device));
   if (int rcm = states_materialize(e, nullptr)) return rcm;      // (lazily written states: brought up to date before anything outside the kernel looks)
   HIP_TRY(hipDeviceSynchronize());
-  if (e->offline) return copy_stream_tensor(e, st->buf[0], st->per_stream(), const_cast<float*>(host_buf), false, 0);
+  if (e->offline) {
+    for (int u = 0; u < e->outt; ++u)
+      if (int rcu = copy_stream_tensor(e, st->buf[0], st->per_stream(), const_cast<float*>(host_buf) + static_cast<size_t>(u) * st->per_stream(), false, u * (e->offline + 1))) return rcu;
+    return NUTLS_OK;
+  }
   e->ys_dirty = true;      // a conv-input state changed under the fused kernel's carried partial sums: rebuilt before its next step
   // (causal32 CTFA: the 31-frame time-attention history of a streaming handle is library state outside the ABI's tensors.  It is NOT touched
   //  here: nutls_state_set takes [B, ...] buffers, and the per-stream workflow -- get, change one stream's row, set -- must leave the other
@@ -1665,7 +1700,10 @@ int nutls_state_set(nutls_handle* h, const char* name, const float* host_buf, si
 int nutls_state_get_all(nutls_handle* h, int stream_idx, float* host_buf, size_t n_floats) {
   if (!h || !host_buf) return fail(NUTLS_ERR_ARG, "nutls_state_get_all: null pointer");
   Engine* e = &h->eng;
-  if (e->offline) stream_idx = 0;
+  if (e->offline) {      // (offline handles: stream_idx = utterance; its carried state lives in arena slot u (offline + 1))
+    if (stream_idx < 0 || stream_idx >= e->outt) return fail(NUTLS_ERR_ARG, "nutls_state_get_all: utterance index out of range");
+    stream_idx *= e->offline + 1;
+  }
   if (stream_idx < 0 || stream_idx >= e->B) return fail(NUTLS_ERR_ARG, "nutls_state_get_all: stream index out of range");
   size_t total = 0;
   for (const StateTensor& st : e->states) total += st.per_stream();
@@ -1707,15 +1745,20 @@ int nutls_state_get_all(nutls_handle* h, int stream_idx, float* host_buf, size_t
 int nutls_reset(nutls_handle* h, int stream_idx) {
   if (!h) return fail(NUTLS_ERR_ARG, "null handle");
   Engine* e = &h->eng;
-  if (stream_idx >= e->B) return fail(NUTLS_ERR_ARG, "nutls_reset: stream index out of range");
-  if (e->offline) stream_idx = 0;    // one utterance: the carried state lives in arena slot 0
+  if (stream_idx >= (e->offline ? e->outt : e->B)) return fail(NUTLS_ERR_ARG, "nutls_reset: stream index out of range");
+  const int utt = stream_idx;          // offline handles: the utterance (or -1: all); its carried state lives in arena slot u (offline + 1)
+  if (e->offline && stream_idx >= 0) stream_idx *= e->offline + 1;
   HIP_TRY(hipSetDevice(e->device));
   if (int rcm = states_materialize(e, nullptr)) return rcm;      // (lazily written states: brought up to date before anything outside the kernel looks)
   HIP_TRY(hipDeviceSynchronize());
   // a stream's whole slice of the arena (state of both parities + scratch) is contiguous
   if (stream_idx < 0) HIP_TRY(hipMemset(e->arena, 0, e->sstride * sizeof(float) * e->B));
   else HIP_TRY(hipMemset(e->arena + e->sstride * stream_idx, 0, e->sstride * sizeof(float)));
-  if (e->ta_hist) HIP_TRY(hipMemset(e->ta_hist, 0, static_cast<size_t>(12) * (31 + e->offline) * 64 * sizeof(float)));
+  if (e->ta_hist) {      // offline handles, causal32 CTFA: the utterance's (all utterances') time-attention history
+    const size_t per = static_cast<size_t>(12) * (31 + e->offline) * 64;
+    if (utt < 0) HIP_TRY(hipMemset(e->ta_hist, 0, per * e->outt * sizeof(float)));
+    else HIP_TRY(hipMemset(e->ta_hist + per * utt, 0, per * sizeof(float)));
+  }
   if (e->fz_ta_ring) {      // streaming causal32 CTFA: the stream's (all streams') time-attention history
     const size_t per = static_cast<size_t>(12) * 32 * 64;
     if (stream_idx < 0) HIP_TRY(hipMemset(e->fz_ta_ring, 0, per * e->B * sizeof(float)));

@@ -67,6 +67,8 @@ struct OpD {
   int ex_b;                                // exchange buffer (X16 / X4 paths)
   int w_off, p_off;                        // weight blob (floats): MFMA fragments; bias | gamma | beta | alpha
   int d0_on, d0_src, d0_off, d0_ld, d1_on, d1_src, d1_off, d1_ld;   // HBM destinations (row 0, first channel)
+                                           // (_on 2: a state tensor the kernel itself never reads -- written only when the launch asks for eager states,
+                                           //  else rebuilt by the library from the rows' other copy when somebody looks: engine.cpp states_materialize)
   int row_mul, row_add;                    // output row of position p, sub-row r:  p * row_mul + row_add + r
   Fwd fwd;
   Img img;                                 // geometry of this op's own image + how it is staged

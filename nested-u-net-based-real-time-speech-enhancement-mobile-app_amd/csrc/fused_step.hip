@@ -120,6 +120,7 @@ struct Ctx {
     stb((cx).dbg, static_cast<unsigned>((g) * (cx).dbg_sstride_b) + static_cast<unsigned>(((slot) * kDbgSlotFloats + (row) * (ld) + (c)) * 4), (v)); } } while (0)
 // does the launch write destination 0 of op d?  (d0_on 2: a conv-input state the kernel never reads -- only when the handle wants eager states)
 #define FZ_D0(d, cx) ((d).d0_on == 1 || ((d).d0_on == 2 && (cx).eager != 0))
+#define FZ_D1(d, cx) ((d).d1_on == 1 || ((d).d1_on == 2 && (cx).eager != 0))
 // byte offset of stream slot g's arena slice relative to the workgroup's first stream (added to the 32-bit offset of a load / store)
 __device__ __forceinline__ unsigned gofs(const Ctx& cx, int g) {
   if constexpr (NSTREAMS == 1) return 0u;
@@ -796,7 +797,7 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
       if constexpr (feeds_x(I)) lds4(d.xcopy_b + gi * 1024 + (row * GC + 4 * li) * 4) = v;
       sched_pin();
       if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v); }
-      if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v);
+      if constexpr (d.d1_on) { if (FZ_D1(d, cx)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v); }
     }
   });
   if constexpr (CSUM) {
@@ -868,7 +869,7 @@ __device__ __forceinline__ void x_epilogue1(const Ctx& cx, int tid, const f32x4 
     if constexpr (CSUM) lds1(kOps[I + 1].scr_b + CSUM_OFF_B + tid * 4) = v;      // (every wave holds one output row of 64 channels: the CTFA adds the eight up)
     sched_pin();
     if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb1(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cch) * 4) + go, v); }
-    if constexpr (d.d1_on) stb1(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cch) * 4) + go, v);
+    if constexpr (d.d1_on) { if (FZ_D1(d, cx)) stb1(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cch) * 4) + go, v); }
   }
   if constexpr (d.ys != 0) {
     // next frame's partial sums W[tap 0] x_t: K slices summed, stored raw ([pos][packed channel]) as float4 items dealt from the top of the workgroup
@@ -1163,7 +1164,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
           if constexpr (UP) FZ_TRACE4(cx, d.g0 + gi, 13 + d.bidx, row, 128, cc, v);
           if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, cc, v); }
           if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v); }
-          if constexpr (d.d1_on) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4) + go, v);
+          if constexpr (d.d1_on) { if (FZ_D1(d, cx)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4) + go, v); }
         }
       }
     }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(const ConvParams p) 
         const int gr = STRIDE * f0 - PADL + lr;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (b < p.B && gr >= 0 && gr < p.F_in)
-          v = *reinterpret_cast<const f32x4*>(src + static_cast<size_t>(b) * p.sstride + static_cast<size_t>(gr) * p.src_ld + ch * CC + 4 * c4);
+          v = *reinterpret_cast<const f32x4*>(src + slot_of(b, p.sm) * p.sstride + static_cast<size_t>(gr) * p.src_ld + ch * CC + 4 * c4);
         const int la = (STRIDE == 1) ? ((sg * RS + lr) * PITCH + 4 * c4)
                                      : ((sg * RS + (lr >> 1)) * PITCH + (lr & 1) * CC + 4 * c4);
         *reinterpret_cast<f32x4*>(lds + la) = v;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(const ConvParams p) 
   const int P = P0 + ploc;
   const bool valid = P < total_pos;
   const int b = P >> log2f, f = P & (F_out - 1);
-  const size_t soff = static_cast<size_t>(b) * p.sstride;
+  const size_t soff = slot_of(b, p.sm) * p.sstride;
   const size_t row0 = static_cast<size_t>(f) * p.row_mul + p.row_add;
 #pragma unroll
   for (int gi = 0; gi < R; ++gi) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64 * NW) void conv_bf16x3_kernel(const ConvParams p
         const int gr = STRIDE * f0 - PADL + lr;
         v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (q < n_items && b < p.B && gr >= 0 && gr < p.F_in)
-          v[u] = *reinterpret_cast<const f32x4*>(src + static_cast<size_t>(b) * p.sstride + static_cast<size_t>(gr) * p.src_ld + ch * CC + 4 * c4);
+          v[u] = *reinterpret_cast<const f32x4*>(src + slot_of(b, p.sm) * p.sstride + static_cast<size_t>(gr) * p.src_ld + ch * CC + 4 * c4);
         la[u] = q < n_items ? lo + ((STRIDE == 1) ? ((sg * RS + lr) * PITCH_B + 8 * c4)
                                                   : ((sg * RS + (lr >> 1)) * PITCH_B + (lr & 1) * (CC * 2) + 8 * c4))
                             : -1;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * NW) void conv_bf16x3_kernel(const ConvParams p
   const int P = P0 + ploc;
   const bool valid = P < total_pos;
   const int b = P >> log2f, f = P & (F_out - 1);
-  const size_t soff = static_cast<size_t>(b) * p.sstride;
+  const size_t soff = slot_of(b, p.sm) * p.sstride;
   const size_t row0 = static_cast<size_t>(f) * p.row_mul + p.row_add;
 #pragma unroll
   for (int gi = 0; gi < R; ++gi) {
@@ -602,9 +602,9 @@ __global__ __launch_bounds__(128) void lstm_dense_kernel(const LstmParams p) {
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int k = tid; k < p.Din; k += 128) {
     const int f = k / p.x_cols, c = k - f * p.x_cols;
-    v[k] = p.x[static_cast<size_t>(b) * p.sstride + static_cast<size_t>(f) * p.x_ld + c];
+    v[k] = p.x[slot_of(b, p.sm) * p.sstride + static_cast<size_t>(f) * p.x_ld + c];
   }
-  if (tid < LSTM_UNITS) hs[tid] = p.h_in[static_cast<size_t>(b) * p.sstride + tid];
+  if (tid < LSTM_UNITS) hs[tid] = p.h_in[slot_of(b, p.sm) * p.sstride + tid];
   __syncthreads();
   if (tid < LSTM_GATES) {
     float a = p.bias[tid];
@@ -619,11 +619,11 @@ __global__ __launch_bounds__(128) void lstm_dense_kernel(const LstmParams p) {
     const float gf = sigmoid_f(z[LSTM_UNITS + tid]);
     const float gg = tanhf(z[2 * LSTM_UNITS + tid]);
     const float go = sigmoid_f(z[3 * LSTM_UNITS + tid]);
-    const float c_old = p.c_in[static_cast<size_t>(b) * p.sstride + tid];
+    const float c_old = p.c_in[slot_of(b, p.sm) * p.sstride + tid];
     const float c_new = gf * c_old + gi * gg;
     const float h_new = go * tanhf(c_new);
-    p.c_out[static_cast<size_t>(b) * p.sstride + tid] = c_new;
-    p.h_out[static_cast<size_t>(b) * p.sstride + tid] = h_new;
+    p.c_out[slot_of(b, p.sm) * p.sstride + tid] = c_new;
+    p.h_out[slot_of(b, p.sm) * p.sstride + tid] = h_new;
     hn[tid] = h_new;
   }
   __syncthreads();
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(128) void lstm_dense_kernel(const LstmParams p) {
 #pragma unroll
     for (int u = 0; u < LSTM_UNITS; ++u) a = fmaf(p.wdT[u * p.Dout + m], hn[u], a);
     const int f = m / p.dst_cols, c = m - f * p.dst_cols;
-    p.dst[static_cast<size_t>(b) * p.sstride + static_cast<size_t>(f) * p.dst_ld + c] = a;
+    p.dst[slot_of(b, p.sm) * p.sstride + static_cast<size_t>(f) * p.dst_ld + c] = a;
   }
 }
 
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void ctfa_kernel(const CtfaParams p) {
   __shared__ __attribute__((aligned(16))) float gate[64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int c4 = tid & 15, rg = tid >> 4;
-  const float* xb = p.x + static_cast<size_t>(b) * p.sstride;
+  const float* xb = p.x + slot_of(b, p.sm) * p.sstride;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int f = rg; f < p.F; f += 16) s += *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
   *reinterpret_cast<f32x4*>(&part[rg][4 * c4]) = s;
@@ -698,8 +698,8 @@ __global__ __launch_bounds__(256) void ctfa_kernel(const CtfaParams p) {
   }
   __syncthreads();
   const f32x4 g4 = *reinterpret_cast<const f32x4*>(&gate[4 * c4]);
-  const float* eb = p.e0 + static_cast<size_t>(b) * p.sstride;
-  float* yb = p.y + static_cast<size_t>(b) * p.sstride;
+  const float* eb = p.e0 + slot_of(b, p.sm) * p.sstride;
+  float* yb = p.y + slot_of(b, p.sm) * p.sstride;
   for (int f = rg; f < p.F; f += 16) {
     const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
     const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
@@ -712,13 +712,19 @@ __global__ __launch_bounds__(256) void ctfa_kernel(const CtfaParams p) {
 // mode only.  hist [31 + frames][64]: rows 0..30 = TA of the 31 frames before this block (zeros at the start of an
 // utterance), row 31 + t = TA of block frame t.  Pass 1 (parallel over frames): TA.  Pass 2: FA from the mean of the last
 // 32 TA rows, gate, residual.  Pass 3: the last 31 rows move to the front for the next block.
-__global__ __launch_bounds__(256) void ctfa_ta_kernel(const CtfaParams p, float* __restrict__ hist) {
+// (several utterances per handle: frame b = u * n + t of the launch -- p.sm -- keeps its time attention in utterance u's history, hist_ustride floats further)
+__device__ __forceinline__ size_t hist_row(int b, const SlotMap& m, long long ustride) {
+  if (!m.n) return static_cast<size_t>(31 + b) * 64;
+  const unsigned u = utt_of(b, m);
+  return static_cast<size_t>(u) * ustride + static_cast<size_t>(31 + b - static_cast<int>(u) * m.n) * 64;
+}
+__global__ __launch_bounds__(256) void ctfa_ta_kernel(const CtfaParams p, float* __restrict__ hist, long long hist_ustride) {
   __shared__ __attribute__((aligned(16))) float part[16][64];
   __shared__ float m[64];
   __shared__ float hid[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int c4 = tid & 15, rg = tid >> 4;
-  const float* xb = p.x + static_cast<size_t>(b) * p.sstride;
+  const float* xb = p.x + slot_of(b, p.sm) * p.sstride;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int f = rg; f < p.F; f += 16) s += *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
   *reinterpret_cast<f32x4*>(&part[rg][4 * c4]) = s;
@@ -740,11 +746,11 @@ __global__ __launch_bounds__(256) void ctfa_ta_kernel(const CtfaParams p, float*
     float a = p.ta_b2[tid];
 #pragma unroll
     for (int u = 0; u < 16; ++u) a = fmaf(p.ta_w2T[u * 64 + tid], hid[u], a);
-    hist[static_cast<size_t>(31 + b) * 64 + tid] = sigmoid_f(a);
+    hist[hist_row(b, p.sm, hist_ustride) + tid] = sigmoid_f(a);
   }
 }
 
-__global__ __launch_bounds__(256) void ctfa_apply_causal_kernel(const CtfaParams p, const float* __restrict__ hist) {
+__global__ __launch_bounds__(256) void ctfa_apply_causal_kernel(const CtfaParams p, const float* __restrict__ hist, long long hist_ustride) {
   __shared__ float avg[64];
   __shared__ float hid[16];
   __shared__ __attribute__((aligned(16))) float gate[64];
@@ -753,9 +759,10 @@ __global__ __launch_bounds__(256) void ctfa_apply_causal_kernel(const CtfaParams
   float ta = 0.f;
   if (tid < 64) {
     float a = 0.f;
-    for (int k = 0; k < 32; ++k) a += hist[static_cast<size_t>(31 + b - k) * 64 + tid];      // oldest rows are zeros before the utterance starts
+    const size_t hr = hist_row(b, p.sm, hist_ustride);
+    for (int k = 0; k < 32; ++k) a += hist[hr - static_cast<size_t>(k) * 64 + tid];      // oldest rows are zeros before the utterance starts
     avg[tid] = a * (1.0f / 32.0f);
-    ta = hist[static_cast<size_t>(31 + b) * 64 + tid];
+    ta = hist[hr + tid];
   }
   __syncthreads();
   if (tid < 16) {
@@ -772,9 +779,9 @@ __global__ __launch_bounds__(256) void ctfa_apply_causal_kernel(const CtfaParams
   }
   __syncthreads();
   const f32x4 g4 = *reinterpret_cast<const f32x4*>(&gate[4 * c4]);
-  const float* xb = p.x + static_cast<size_t>(b) * p.sstride;
-  const float* eb = p.e0 + static_cast<size_t>(b) * p.sstride;
-  float* yb = p.y + static_cast<size_t>(b) * p.sstride;
+  const float* xb = p.x + slot_of(b, p.sm) * p.sstride;
+  const float* eb = p.e0 + slot_of(b, p.sm) * p.sstride;
+  float* yb = p.y + slot_of(b, p.sm) * p.sstride;
   for (int f = rg; f < p.F; f += 16) {
     const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + static_cast<size_t>(f) * p.x_ld + 4 * c4);
     const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + static_cast<size_t>(f) * p.e0_ld + 4 * c4);
@@ -782,7 +789,8 @@ __global__ __launch_bounds__(256) void ctfa_apply_causal_kernel(const CtfaParams
   }
 }
 
-__global__ __launch_bounds__(1024) void ctfa_hist_roll_kernel(float* __restrict__ hist, int frames) {
+__global__ __launch_bounds__(1024) void ctfa_hist_roll_kernel(float* __restrict__ hist, int frames, long long hist_ustride) {
+  hist += static_cast<size_t>(blockIdx.x) * hist_ustride;      // (one workgroup per utterance)
   const int tid = threadIdx.x;          // 31 x 64 = 1984 values, two per thread: read everything, then write (the ranges overlap when frames < 31)
   float v[2];
 #pragma unroll
@@ -798,16 +806,16 @@ __global__ __launch_bounds__(1024) void ctfa_hist_roll_kernel(float* __restrict_
   }
 }
 
-hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, bool roll, hipStream_t s) {
-  hipLaunchKernelGGL(ctfa_ta_kernel, dim3(p.B), dim3(256), 0, s, p, hist);
-  hipLaunchKernelGGL(ctfa_apply_causal_kernel, dim3(p.B), dim3(256), 0, s, p, hist);
-  if (roll) hipLaunchKernelGGL(ctfa_hist_roll_kernel, dim3(1), dim3(1024), 0, s, hist, p.B);
+hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, bool roll, hipStream_t s, int utts, long long hist_ustride) {
+  hipLaunchKernelGGL(ctfa_ta_kernel, dim3(p.B), dim3(256), 0, s, p, hist, hist_ustride);
+  hipLaunchKernelGGL(ctfa_apply_causal_kernel, dim3(p.B), dim3(256), 0, s, p, hist, hist_ustride);
+  if (roll) hipLaunchKernelGGL(ctfa_hist_roll_kernel, dim3(utts), dim3(1024), 0, s, hist, p.B / utts, hist_ustride);
   return hipGetLastError();
 }
 
 // the last 31 rows of a block of `frames` frames become rows 0..30 of the next block's history
-hipError_t launch_ctfa_hist_roll(float* hist, int frames, hipStream_t s) {
-  hipLaunchKernelGGL(ctfa_hist_roll_kernel, dim3(1), dim3(1024), 0, s, hist, frames);
+hipError_t launch_ctfa_hist_roll(float* hist, int frames, hipStream_t s, int utts, long long hist_ustride) {
+  hipLaunchKernelGGL(ctfa_hist_roll_kernel, dim3(utts), dim3(1024), 0, s, hist, frames, hist_ustride);
   return hipGetLastError();
 }
 
@@ -845,7 +853,7 @@ __global__ __launch_bounds__(256) void input_layer_kernel(const InLayerParams p)
     const float t = y[i] * rstd * gm[i] + bt[i];
     o[i] = t >= 0.f ? t : p.alpha * t;
   }
-  if (valid) *reinterpret_cast<f32x4*>(p.y + static_cast<size_t>(pos >> 8) * p.sstride + static_cast<size_t>(pos & 255) * 64 + 4 * c4) = o;
+  if (valid) *reinterpret_cast<f32x4*>(p.y + slot_of(pos >> 8, p.sm) * p.sstride + static_cast<size_t>(pos & 255) * 64 + 4 * c4) = o;
 }
 
 hipError_t launch_input_layer(const InLayerParams& p, hipStream_t s) {
@@ -863,7 +871,7 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvParams p) {
   const bool valid = pos < p.n_pos;
   float s = 0.f;
   if (valid) {
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + static_cast<size_t>(pos >> 8) * p.sstride + static_cast<size_t>(pos & 255) * p.x_ld + 4 * c4);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + slot_of(pos >> 8, p.sm) * p.sstride + static_cast<size_t>(pos & 255) * p.x_ld + 4 * c4);
     const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + 4 * c4);
     s = xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
   }

@@ -32,6 +32,25 @@ bool parse_weight_blob(const void* blob, size_t n, WeightMap* out, std::string* 
 // element (stream b, row r, channel c) of a tensor at  base + b*sstride + r*ld + c.  A stream's
 // whole working set (~2.6 MB) is contiguous, so the workgroup that owns the stream stays inside a
 // couple of 2 MiB pages.
+// Block mode with several utterances per handle (nutls_create_offline_batch): the launch's "streams" are the frames of all utterances, dense
+// index b = u * n + t (utterance u, frame t of the n frames of this launch), but an utterance's frames live in ITS run of arena slots -- the
+// slot in front of its first frame holds its carried state, the tap "one frame earlier" of every layer -- so consecutive utterances are
+// `gap` slots further apart than their frames: slot(b) = b + (b / n) * gap.  n = 0: dense (every streaming launch, one-utterance blocks).
+struct SlotMap {
+  int n; unsigned mul; int gap;      // mul = floor(2^32 / n) + 1: b / n = umulhi(b, mul), exact for b * n < 2^32 (n = 1: mul = 0, the quotient is b)
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ size_t slot_of(int b, const SlotMap& m) {
+  return m.n ? static_cast<size_t>(b) + static_cast<size_t>(m.mul ? __umulhi(static_cast<unsigned>(b), m.mul) : static_cast<unsigned>(b)) * m.gap : static_cast<size_t>(b);
+}
+// (utterance of stream b)
+__device__ __forceinline__ unsigned utt_of(int b, const SlotMap& m) { return m.n ? (m.mul ? __umulhi(static_cast<unsigned>(b), m.mul) : static_cast<unsigned>(b)) : 0u; }
+#endif
+inline SlotMap make_slot_map(int n, int gap) {
+  if (n <= 0 || gap <= 0) return SlotMap{0, 0u, 0};
+  return SlotMap{n, n == 1 ? 0u : static_cast<unsigned>((1ull << 32) / static_cast<unsigned>(n)) + 1u, gap};
+}
+
 // Generic "tap-GEMM" convolution over channels-last rows (see kernels.hip for the tiling).
 struct ConvParams {
   const float* src0;   // time tap 0 (previous frame) -- or the only input when TT == 1
@@ -52,6 +71,7 @@ struct ConvParams {
   int row_mul, row_add;  // output row of position f, group g:  f*row_mul + row_add + g
   float alpha;           // PReLU slope
   long long sstride;     // floats between consecutive streams (all per-stream tensors share one arena stride)
+  SlotMap sm;            // stream index -> arena slot (block mode with several utterances; {0, 0, 0}: slot = stream)
 };
 
 enum ConvKind : int {
@@ -88,11 +108,15 @@ struct LstmParams {
   float* dst; int dst_ld, dst_rows, dst_cols;  // y[f*dst_cols+c] -> dst[(b*dst_rows+f)*dst_ld + c]
   int Din, Dout, B;
   long long sstride;
+  SlotMap sm;
 };
 hipError_t launch_lstm(const LstmParams& p, hipStream_t s);
 // offline / block mode (offline.hip): the same cell over `frames` consecutive frames of one utterance
 constexpr int kScanReadAhead = 16;   // rows the scan's prefetch reads past the frames it was given (values never used): slack rows of the zx buffer
-hipError_t launch_lstm_block(const LstmParams& p, float* zx /* [frames + kScanReadAhead][84] scratch */, int frames, hipStream_t s);
+// several utterances: `frames` frames of each of `utts` utterances (dense index u * frames + t, p.sm maps it to slots); `utt_stride` floats between the
+// slot runs of consecutive utterances (h / c of utterance u start there)
+hipError_t launch_lstm_block(const LstmParams& p, float* zx /* [utts * frames + kScanReadAhead][84] scratch */, int frames, hipStream_t s, int utts = 1,
+                             long long utt_stride = 0);
 
 // Dilated-dense bottleneck of the baseline variant (see ddb_device.hpp).  Weights transposed so the
 // output channel is the fastest index (consecutive threads read consecutive floats).
@@ -138,12 +162,14 @@ struct CtfaParams {
   const float* ta_w2; const float* fa_w2;   // [64][16] (output channel major), as stored
   int B, F;
   long long sstride;
+  SlotMap sm;
 };
 hipError_t launch_ctfa(const CtfaParams& p, hipStream_t s);
 // offline / block mode, true 32-frame causal average of the time attention (models/proposed.py:143-147); hist [31 + p.B][64]
 // `hist` = the history row of the first frame's predecessor-window start; `roll`: the block ends here (see launch_ctfa_hist_roll)
-hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, bool roll, hipStream_t s);
-hipError_t launch_ctfa_hist_roll(float* hist, int frames, hipStream_t s);
+// (several utterances: p.B = utts * frames, p.sm maps frames to slots, utterance u's history hist_ustride floats after utterance u - 1's)
+hipError_t launch_ctfa_causal(const CtfaParams& p, float* hist, bool roll, hipStream_t s, int utts = 1, long long hist_ustride = 0);
+hipError_t launch_ctfa_hist_roll(float* hist, int frames, hipStream_t s, int utts = 1, long long hist_ustride = 0);
 
 struct InLayerParams {   // input_layer: 1x1 conv 1->64 + LN + PReLU
   const float* x;        // [B,256]
@@ -151,6 +177,7 @@ struct InLayerParams {   // input_layer: 1x1 conv 1->64 + LN + PReLU
   const float* w; const float* b; const float* gamma; const float* beta; float alpha;
   int n_pos;             // B*256
   long long sstride;     // stream stride of y (x is the plain [B,256] input)
+  SlotMap sm;
 };
 hipError_t launch_input_layer(const InLayerParams& p, hipStream_t s);
 
@@ -160,6 +187,7 @@ struct OutConvParams {   // 1x1 conv 64->1
   const float* w; float bias;
   int n_pos;
   long long sstride;          // stream stride of x (y is the plain [B,256] output)
+  SlotMap sm;
 };
 hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
 

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(128) void lstm_zx_kernel(const LstmParams p, float*
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int k = tid; k < p.Din; k += 128) {
     const int f = k / p.x_cols, c = k - f * p.x_cols;
-    v[k] = p.x[static_cast<size_t>(b) * p.sstride + static_cast<size_t>(f) * p.x_ld + c];
+    v[k] = p.x[slot_of(b, p.sm) * p.sstride + static_cast<size_t>(f) * p.x_ld + c];
   }
   __syncthreads();
   if (tid < G4) {
@@ -55,7 +55,11 @@ template <int CTRL>
 __device__ __forceinline__ float scan_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-__global__ __launch_bounds__(64) void lstm_scan_kernel(const LstmParams p, const float* __restrict__ zx, int frames) {
+__global__ __launch_bounds__(64) void lstm_scan_kernel(const LstmParams p0, const float* __restrict__ zx0, int frames, long long utt_stride) {
+  // one wavefront per utterance (blockIdx.x): its h / c slots start utt_stride floats after the previous utterance's, its rows of zx `frames` rows further
+  LstmParams p = p0;
+  p.h_in += blockIdx.x * utt_stride; p.c_in += blockIdx.x * utt_stride; p.h_out += blockIdx.x * utt_stride; p.c_out += blockIdx.x * utt_stride;
+  const float* __restrict__ zx = zx0 + static_cast<size_t>(blockIdx.x) * frames * G4;
   constexpr int PF = 8;                         // frames of zx in flight
   const int lane = threadIdx.x;
   const int u = (lane >> 1) < U ? (lane >> 1) : U - 1, pr = lane & 1;
@@ -129,22 +133,22 @@ __global__ __launch_bounds__(64) void lstm_scan_kernel(const LstmParams p, const
 __global__ __launch_bounds__(128) void lstm_dense_kernel2(const LstmParams p) {
   __shared__ float hn[32];
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid < U) hn[tid] = p.h_out[static_cast<size_t>(b) * p.sstride + tid];
+  if (tid < U) hn[tid] = p.h_out[slot_of(b, p.sm) * p.sstride + tid];
   __syncthreads();
   for (int m = tid; m < p.Dout; m += 128) {
     float a = p.bd[m];
 #pragma unroll
     for (int u = 0; u < U; ++u) a = fmaf(p.wdT[u * p.Dout + m], hn[u], a);
     const int f = m / p.dst_cols, c = m - f * p.dst_cols;
-    p.dst[static_cast<size_t>(b) * p.sstride + static_cast<size_t>(f) * p.dst_ld + c] = a;
+    p.dst[slot_of(b, p.sm) * p.sstride + static_cast<size_t>(f) * p.dst_ld + c] = a;
   }
 }
 
-hipError_t launch_lstm_block(const LstmParams& p, float* zx, int frames, hipStream_t s) {
+hipError_t launch_lstm_block(const LstmParams& p, float* zx, int frames, hipStream_t s, int utts, long long utt_stride) {
   if (p.Din > 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(lstm_zx_kernel, dim3(frames), dim3(128), 0, s, p, zx);
-  hipLaunchKernelGGL(lstm_scan_kernel, dim3(1), dim3(64), 0, s, p, zx, frames);
-  hipLaunchKernelGGL(lstm_dense_kernel2, dim3(frames), dim3(128), 0, s, p);
+  hipLaunchKernelGGL(lstm_zx_kernel, dim3(utts * frames), dim3(128), 0, s, p, zx);
+  hipLaunchKernelGGL(lstm_scan_kernel, dim3(utts), dim3(64), 0, s, p, zx, frames, utt_stride);
+  hipLaunchKernelGGL(lstm_dense_kernel2, dim3(utts * frames), dim3(128), 0, s, p);
   return hipGetLastError();
 }
 

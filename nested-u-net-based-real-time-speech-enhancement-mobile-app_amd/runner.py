@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "nutls_last_error",
     "nutls_version",
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
-    "nutls_create_offline", "nutls_process_block", "nutls_process_block_host",
+    "nutls_create_offline", "nutls_create_offline_batch", "nutls_process_block", "nutls_process_block_host",
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
     "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all", "nutls_offline_set_ctfa_mode",
     "nutls_offline_set_pipeline", "nutls_streams_per_workgroup", "nutls_fused_plan_blob_floats", "nutls_fused_pack_blob_plan",
@@ -66,6 +66,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         raise RuntimeError("%s reports %r, this wrapper binds %r: rebuild the library (python -m nunet_amd.build)"
                            % (p, ver, ABI_VERSION_PREFIX))
     fp = c.POINTER(c.c_float)
+    dev_lib = p != _HERE_LIB      # (NUTLS_DEV=1 NUTLS_LIB=...: an experimental or OLDER build for an A/B run may lack the newest entry points)
     lib.nutls_create.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
     lib.nutls_create_plan.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
     lib.nutls_destroy.argtypes = [c.c_void_p]
@@ -81,7 +82,6 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_state_info.argtypes = [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_int), c.POINTER(c.c_int)]
     lib.nutls_reset.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_debug_get.argtypes = [c.c_void_p, c.c_char_p, fp, c.c_size_t]
-    dev_lib = p != _HERE_LIB      # (NUTLS_DEV=1 NUTLS_LIB=...: an experimental or OLDER build for an A/B run may lack the newest entry points)
     if not dev_lib or hasattr(lib, "nutls_debug_trace"):
         lib.nutls_debug_trace.argtypes = [c.c_void_p, c.c_int]
     if not dev_lib or hasattr(lib, "nutls_debug_knob"):
@@ -97,6 +97,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_stft_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
     lib.nutls_istft_hop.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_create_offline.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
+    if not dev_lib or hasattr(lib, "nutls_create_offline_batch"):
+        lib.nutls_create_offline_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
     lib.nutls_process_block.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p]
     lib.nutls_process_block_host.argtypes = [c.c_void_p, fp, fp, c.c_int]
     lib.nutls_offline_set_ctfa_mode.argtypes = [c.c_void_p, c.c_int]
@@ -460,25 +462,28 @@ class NutlsRunner:
 
 
 class NutlsOffline:
-    """Offline / block mode: one utterance, up to ``max_frames`` consecutive frames per
-    call -- every conv-like layer runs once per block over all frames (the frame index takes the place of
-    the stream index), only the LSTM recurrences are scanned.  Same function as a batch-1 streaming engine
-    fed frame by frame; the state carries over between calls until :meth:`reset`."""
+    """Offline / block mode: ``utterances`` independent utterances, up to ``max_frames`` consecutive frames of each
+    per call -- every conv-like layer runs once per block over all frames of all utterances (the frame index takes the place of
+    the stream index), only the LSTM recurrences are scanned (side by side for the utterances).  Same function as a streaming
+    engine fed frame by frame (the offline forward of the reference, models/proposed.py:284-625, takes ``[B, T, ...]``); every
+    utterance's state carries over between calls until :meth:`reset`."""
 
     CTFA_MODES = {"frame": 0, "causal32": 1}
 
-    def __init__(self, weights=None, max_frames: int = 256, device: int = 0, ctfa_mode: str = "frame", pipeline: int = 0):
+    def __init__(self, weights=None, max_frames: int = 256, device: int = 0, ctfa_mode: str = "frame", pipeline: int = 0, utterances: int = 1):
         """``ctfa_mode``: "frame" (default; the frame-wise graph's TA/32, equal to the streaming result) or "causal32"
         (the offline model's true 32-frame causal average of the time attention, models/proposed.py:143-147).
-        ``pipeline``: chunks of consecutive frames a block is cut into, each on its own HIP stream one bottleneck behind
-        the chunk before it (1..16; 0 = chosen from the block length).  The result does not depend on it."""
+        ``pipeline``: chunks of consecutive frames a block of ONE utterance is cut into, each on its own HIP stream one bottleneck
+        behind the chunk before it (1..16; 0 = chosen from the block length).  The result does not depend on it.
+        ``utterances``: the batch dimension (``nutls_create_offline_batch``); ``process`` then takes ``[utterances, N, 256]``."""
         if ctfa_mode not in self.CTFA_MODES:
             raise ValueError("ctfa_mode must be one of %s" % sorted(self.CTFA_MODES))
         self._lib = load_library()
         blob = read_blob(weights if weights is not None else DEFAULT_WEIGHTS)
         self._h = ctypes.c_void_p()
         self.max_frames = int(max_frames)
-        _check(self._lib, self._lib.nutls_create_offline(blob, len(blob), self.max_frames, int(device), ctypes.byref(self._h)))
+        self.utterances = int(utterances)
+        _check(self._lib, self._lib.nutls_create_offline_batch(blob, len(blob), self.max_frames, self.utterances, int(device), ctypes.byref(self._h)))
         if ctfa_mode != "frame":
             _check(self._lib, self._lib.nutls_offline_set_ctfa_mode(self._h, self.CTFA_MODES[ctfa_mode]))
         self.ctfa_mode = ctfa_mode
@@ -489,31 +494,54 @@ class NutlsOffline:
         _check(self._lib, self._lib.nutls_offline_set_pipeline(self._h, int(chunks)))
 
     def process(self, mags) -> np.ndarray:
-        """``mags [N,256]`` float32 (any N) -> enhanced magnitudes ``[N,256]``; blocks of ``max_frames``."""
+        """``mags [N,256]`` (one utterance) or ``[utterances,N,256]`` float32 (any N) -> enhanced magnitudes of the same shape; blocks of
+        ``max_frames`` frames of every utterance."""
         m = np.ascontiguousarray(mags, dtype=np.float32)
-        if m.ndim != 2 or m.shape[1] != T.N_BINS:
-            raise ValueError("mags must be [N,%d], got %s" % (T.N_BINS, m.shape))
+        batched = m.ndim == 3
+        if self.utterances == 1 and m.ndim == 2:
+            m = m[None]
+        if m.ndim != 3 or m.shape[0] != self.utterances or m.shape[2] != T.N_BINS:
+            raise ValueError("mags must be [%s N,%d], got %s" % ("%d," % self.utterances if self.utterances > 1 else "", T.N_BINS, np.shape(mags)))
         out = np.empty_like(m)
-        for a in range(0, m.shape[0], self.max_frames):
-            blk = np.ascontiguousarray(m[a:a + self.max_frames])
+        for a in range(0, m.shape[1], self.max_frames):
+            blk = np.ascontiguousarray(m[:, a:a + self.max_frames])
             o = np.empty_like(blk)
-            _check(self._lib, self._lib.nutls_process_block_host(self._h, _fptr(blk), _fptr(o), blk.shape[0]))
-            out[a:a + blk.shape[0]] = o
-        return out
+            _check(self._lib, self._lib.nutls_process_block_host(self._h, _fptr(blk), _fptr(o), blk.shape[1]))
+            out[:, a:a + blk.shape[1]] = o
+        return out if batched else out[0]
 
     def process_block_device(self, mag, out=None):
-        """One block on device tensors: ``mag [n,256]`` float32 CUDA tensor, n <= max_frames; asynchronous on the
-        current torch stream."""
+        """One block on device tensors: ``mag [n,256]`` (one utterance) or ``[utterances,n,256]`` float32 CUDA tensor, n <= max_frames;
+        asynchronous on the current torch stream."""
         import torch
         if not (torch.is_tensor(mag) and mag.is_cuda and mag.dtype == torch.float32 and mag.is_contiguous()):
             raise ValueError("mag must be a contiguous float32 CUDA tensor")
-        if mag.dim() != 2 or mag.shape[1] != T.N_BINS or mag.shape[0] > self.max_frames:
-            raise ValueError("mag must be [n<=%d,%d], got %s" % (self.max_frames, T.N_BINS, tuple(mag.shape)))
+        shape = tuple(mag.shape)
+        want3 = mag.dim() == 3
+        ok = (want3 and shape[0] == self.utterances) or (mag.dim() == 2 and self.utterances == 1)
+        if not ok or shape[-1] != T.N_BINS or shape[-2] > self.max_frames:
+            raise ValueError("mag must be [%sn<=%d,%d], got %s" % ("%d," % self.utterances if self.utterances > 1 else "", self.max_frames, T.N_BINS, shape))
         if out is None:
             out = torch.empty_like(mag)
         stream = torch.cuda.current_stream(mag.device).cuda_stream
-        _check(self._lib, self._lib.nutls_process_block(self._h, mag.data_ptr(), out.data_ptr(), int(mag.shape[0]), stream))
+        _check(self._lib, self._lib.nutls_process_block(self._h, mag.data_ptr(), out.data_ptr(), int(shape[-2]), stream))
         return out
+
+    def state_get(self, name: str) -> np.ndarray:
+        """Carried state tensor ``name`` of every utterance, ``[utterances, F, C]`` (``[utterances, 21]`` for h / c)."""
+        d0, d1 = ctypes.c_int(), ctypes.c_int()
+        for i in range(self._lib.nutls_state_count(self._h)):
+            nm = ctypes.c_char_p()
+            _check(self._lib, self._lib.nutls_state_info(self._h, i, ctypes.byref(nm), ctypes.byref(d0), ctypes.byref(d1)))
+            if nm.value.decode() == name:
+                a = np.empty((self.utterances, d0.value, d1.value), np.float32)
+                _check(self._lib, self._lib.nutls_state_get(self._h, name.encode(), _fptr(a), a.size))
+                return a.reshape(self.utterances, d0.value) if d1.value == 1 else a
+        raise ValueError("unknown state tensor: %s" % name)
+
+    def reset_utterance(self, u: int):
+        """Zero the carried state (and the causal32 attention history) of utterance ``u``: a new utterance starts in that slot."""
+        _check(self._lib, self._lib.nutls_reset(self._h, int(u)))
 
     def reset(self):
         _check(self._lib, self._lib.nutls_reset(self._h, -1))

@@ -180,3 +180,49 @@ def test_block_pipeline_default_for_long_blocks(clip):
     off.close(); one.close()
     assert rms(got, ref) < 1e-6
     assert rms(got[:249], clip["mags_out"]) < 2e-5
+
+
+@pytest.mark.parametrize("ctfa_mode", ["frame", "causal32"])
+def test_batched_block_mode_equals_one_utterance_handles_and_the_oracle(clip, ctfa_mode):
+    """`nutls_create_offline_batch`: the offline forward with a batch dimension (the reference's takes [B, T, ...],
+    /root/reference/dnn_model/models/proposed.py:284-625).  Three utterances (different parts of the clip) in ONE handle, ragged block
+    lengths with the state of every utterance carried from block to block: each utterance's output equals that of a one-utterance
+    handle (same kernels and tilings: <= 1e-6) and the oracle's, in both CTFA modes (causal32 = the training model's 32-frame
+    attention, whose history is per utterance); carried states are per utterance; resetting one utterance leaves the others alone."""
+    from oracle.nutls_ref import NutlsRef
+    frames = clip["mags_in"]
+    U, T_max = 3, 24
+    starts = [0, 60, 131]
+    sizes = [24, 7, 24, 1, 17]          # (sum 73 > 64: the causal32 history wraps; blocks shorter than the 31-frame window, a one-frame block)
+    n_total = sum(sizes)
+    x = np.stack([frames[s:s + n_total] for s in starts])          # [U, N, 256]
+    off = NutlsOffline(max_frames=T_max, utterances=U, ctfa_mode=ctfa_mode)
+    outs, t = [], 0
+    for n in sizes:
+        outs.append(off.process(x[:, t:t + n]))
+        assert outs[-1].shape == (U, n, 256)
+        t += n
+    got = np.concatenate(outs, axis=1)
+    ref = NutlsRef(batch=U, ctfa_mode=ctfa_mode)
+    want = np.stack([ref.step(x[:, i]).numpy() for i in range(n_total)], axis=1)
+    assert rms(got, want) < 2e-5
+    for u in range(U):
+        one = NutlsOffline(max_frames=T_max, ctfa_mode=ctfa_mode)
+        assert rms(got[u], one.process(x[u])) < 1e-6, u
+        one.close()
+    # carried state: per utterance, equal to the oracle's after the same frames
+    h = off.state_get("msfe4_en_h")
+    assert h.shape == (U, 21) and rms(h, ref.state["msfe4_en_h"].numpy().reshape(U, 21)) < 2e-5
+    p1 = off.state_get("msfe6_ee_prev1")
+    assert p1.shape == (U, 256, 64) and rms(p1, ref.state["msfe6_ee_prev1"].numpy()) < 2e-5
+    # a new utterance moves into slot 1: the other two continue as if nothing happened
+    off.reset_utterance(1)
+    y = off.process(np.stack([frames[starts[0] + n_total:starts[0] + n_total + 9], frames[:9], frames[starts[2] + n_total:starts[2] + n_total + 9]]))
+    fresh = NutlsOffline(max_frames=T_max, ctfa_mode=ctfa_mode)
+    assert rms(y[1], fresh.process(frames[:9])) < 1e-6
+    fresh.close()
+    cont = np.stack([ref.step(np.stack([frames[starts[0] + n_total + i], frames[i], frames[starts[2] + n_total + i]])).numpy() for i in range(9)], axis=1)
+    assert rms(y[0], cont[0]) < 2e-5 and rms(y[2], cont[2]) < 2e-5
+    with pytest.raises(ValueError):
+        off.process(x[:2, :5])          # (the batch dimension is the handle's)
+    off.close()

@@ -624,7 +624,16 @@ def build_for(variant, G, cls):
                 o["xs_off"], o["xs_ld"] = st_off(ct, i), cin         # the conv's input state tensor [rows][cin] (nutls_state_set -> partial sums)
                 if side:
                     sk = 64 if i == 1 else 32
-                    parts.append(part(S_CUR, st_off(ct, i) + sk, cin, rows, sk // 4, g["tap_b"] + sk * esz(g), g["row0"], la_of(rows, sk // 4, o["gs"])))
+                    src_off, src_ld = st_off(ct, i) + sk, cin
+                    if G == 1 and LAZY and i >= 2:
+                        # The skip rows of decoder conv i >= 2 are the paired encoder stage's d_{D-i+1}, and its sub-pixel conv D-i+1 writes them
+                        # to TWO state tensors: the input state of its own next sub-pixel conv (channels 0..31 of `<ed>_prev{D-i+2}`) and the
+                        # skip half of this conv's input state (converter_proposed.py:467-473).  The kernel reads the FIRST copy here too --
+                        # same rows, same 32 channels at ld 64 -- so that the second is written only when somebody outside the kernel looks
+                        # (OpD::d1_on = 2, marked below; engine.cpp states_materialize): 63 KB per frame and stream less to write.
+                        enc_stg = ENC[5 - s][4]
+                        src_off, src_ld = st_off(enc_stg, D - i + 2), 64
+                    parts.append(part(S_CUR, src_off, src_ld, rows, sk // 4, g["tap_b"] + sk * esz(g), g["row0"], la_of(rows, sk // 4, o["gs"])))
                 o["parts"] = parts
             for j in range(1, D + 1):
                 o = lst[D + 1 + j]
@@ -899,6 +908,7 @@ def build_for(variant, G, cls):
     # otherwise the library rebuilds it from the d1 copy when somebody outside the kernel looks (engine.cpp states_materialize).
     for o in ops:
         o["lazy0"] = 0
+        o["lazy1"] = 0
     if G == 1 and LAZY:
         def overlap(a, b):      # (off, rows, ld, width): row-strided regions of floats
             (ao, ar, al, aw), (bo, br, bl, bw) = a, b
@@ -923,6 +933,13 @@ def build_for(variant, G, cls):
                 a = (o["d0"][1], o["P"], o["d0"][2], o["N"])
                 if not any(overlap(a, b) for b in readers):
                     o["lazy0"] = 1
+        # ... and the second copy of an encoder sub-pixel conv's rows (d1: the skip half of the paired decoder conv's input state): nothing in
+        # the kernel reads it any more (the decoder's staged part above takes the rows from d0)
+        for o in ops:
+            if o["type"] == T_CONV and o["kind"] == K_DL and o["d0"] and o["d1"] and o["d0"][0] == S_CUR and o["d1"][0] == S_CUR:
+                a = (o["d1"][1], o["P"] * o["R"], o["d1"][2], o["gc"])
+                if not any(overlap(a, b) for b in readers):
+                    o["lazy1"] = 1
     return A, W, ops
 
 
@@ -982,7 +999,7 @@ def emit(A, W, ops, G=1):
                "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d, /*epl*/ %d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
-            o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"], o["lazy0"]), c_dst(o["d1"]), o["row_mul"], o["row_add"],
+            o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"], o["lazy0"]), c_dst(o["d1"], o["lazy1"]), o["row_mul"], o["row_add"],
             c_fwd(o["fwd"]), c_img(o), o["nxt"],
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
             1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["x_fmt"], o["x_plane_b"], o["lw_off"],
