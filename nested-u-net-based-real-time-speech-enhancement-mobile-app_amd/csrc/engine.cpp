@@ -865,12 +865,14 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   // Which plan: one stream per workgroup, or a packed plan (two / four streams per workgroup: one weight fetch / conversion and one latency
   // chain for all of them in the layers whose images fit LDS that often).  NUTLS_FUSED_STREAMS=1 / 2 / 4 overrides (the stream count must be
   // a multiple).
-  // Choice by a two-number cost model: a step takes ceil(workgroups / CUs) rounds of the plan's step time, and those are 1 : 1.58 : 2.82 for
-  // 1 / 2 / 4 streams per workgroup (0.37 / 0.585 / 1.04 ms, profiles/r04_*).  256 streams: one per workgroup (one round); 300 .. 512: two
-  // (one round instead of two); 768: four (192 workgroups, one round); 1024, 2048: four; 1536: two (three rounds of 0.585 ms < two of 1.04).
+  // Choice by a two-number cost model: a step takes ceil(workgroups / CUs) rounds of the plan's step time, and those are 1 : 1.67 : 3.03 for
+  // 1 / 2 / 4 streams per workgroup (0.347 / 0.580 / 1.052 ms, round 6: profiles/plan_cost_model.json, tools/gpu_plan_cost.py -- the one-stream
+  // kernel got faster, the packed plans did not: round 4 measured 1 : 1.58 : 2.82).  256 streams: one per workgroup (one round); 300 .. 512:
+  // two (one round instead of two); 768: one (three rounds of 1.0 = one round of fours at 3.03: a tie goes to the smaller group); 1024, 2048:
+  // four; 1536: two (three rounds of 1.67 < two of 3.03).
   int streams = 1;
   {
-    const double t_plan[5] = {0.0, 1.0, 1.58, 0.0, 2.82};
+    const double t_plan[5] = {0.0, 1.0, 1.67, 0.0, 3.03};
     double best = 0.0;
     for (int g : {1, 2, 4}) {
       if (e->B % g != 0 || !fused_has_plan(v, g)) continue;
