@@ -173,7 +173,7 @@ def bench_offline(args, rank, world, local_rank):
     batched = U > 1 and not args.offline_handles
     if batched:
         # ONE handle with a batch dimension (nutls_create_offline_batch): every layer one launch over the frames of all utterances
-        offs = [nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, utterances=U)]
+        offs = [nunet_amd.NutlsOffline(max_frames=T_, device=local_rank, utterances=U, pipeline=args.offline_chunks)]
         pool = torch.from_numpy(np.stack([synthetic_pool(T_, 4, 1234 + rank + 7 * u) for u in range(U)], axis=1)).cuda()      # [4, U, T, 256]
         outs = [torch.empty(U, T_, 256, device="cuda")]
         streams = [torch.cuda.current_stream()]
@@ -226,7 +226,7 @@ def bench_offline(args, rank, world, local_rank):
                           "config": {"workload": "offline / block mode: %s, %d consecutive frames per call (SURVEY 8f.2)" % (
                                          "ONE utterance" if U == 1 else ("%d utterances in one handle ([U, T, 256] per call)" % U if batched else "%d utterances, one handle and stream each" % U), T_),
                                      "frames_per_block": T_, "utterances": U, "batched_handle": batched,
-                                     "pipeline_chunks": "none (several utterances per launch)" if batched else (args.offline_chunks or "auto (2 from 256 frames, 3 from 768)"),
+                                     "pipeline_chunks": args.offline_chunks or "auto (2 from 256 frames, 3 from 768)",
                                      "mode": "per-layer kernels, frame index as stream index, single-wavefront LSTM scan, block pipeline"},
                           "rtf_per_stream": round(dt / args.steps / T_ / 0.016, 6),
                           "host_enqueue_ms_per_block": round(1e3 * t_enq / args.steps, 4)}))

@@ -1260,10 +1260,11 @@ int nutls_offline_set_pipeline(nutls_handle* h, int chunks) {
 
 // Launches [first, last) of the block plan for frames [t0, t0 + n) on stream s: every per-frame tensor (arena slots,
 // magnitudes in / out, LSTM input products, time-attention history) is addressed from frame t0.
-static int launch_block_range(Engine* e, size_t first, size_t last, int t0, int n, bool roll_hist, hipStream_t s) {
+static int launch_block_range(Engine* e, size_t first, size_t last, int t0, int n, bool roll_hist, hipStream_t s, int n_block = 0) {
   // (several utterances: the launches run all of them -- dense stream index u * n + t, SlotMap: utterance u's frames start (offline + 1) slots
-  //  after utterance u - 1's; such blocks are not cut into chunks, so t0 = 0 and the magnitudes of the block are dense too)
+  //  after utterance u - 1's; the magnitudes [U, n_block, 256] of the block: a chunk's n frames of utterance u sit n_block rows after those of u - 1)
   const int U = e->outt;
+  const SlotMap sm_io = U > 1 ? make_slot_map(n, (n_block > 0 ? n_block : n) - n) : make_slot_map(0, 0);
   const SlotMap sm = U > 1 ? make_slot_map(n, e->offline + 1 - n) : make_slot_map(0, 0);
   const long long utt_stride = static_cast<long long>(e->offline + 1) * static_cast<long long>(e->sstride);
   const long long hist_ustride = static_cast<long long>(12) * (31 + e->offline) * 64;
@@ -1305,12 +1306,14 @@ static int launch_block_range(Engine* e, size_t first, size_t last, int t0, int 
         L.inl.x += static_cast<size_t>(t0) * NUTLS_BINS; sh(L.inl.y);
         L.inl.n_pos = U * n * NUTLS_BINS;
         L.inl.sm = sm;
+        L.inl.sm_io = sm_io;
         err = launch_input_layer(L.inl, s);
         break;
       case Launch::OUTCONV:
         shc(L.outc.x); L.outc.y += static_cast<size_t>(t0) * NUTLS_BINS;
         L.outc.n_pos = U * n * NUTLS_BINS;
         L.outc.sm = sm;
+        L.outc.sm_io = sm_io;
         err = launch_out_conv(L.outc, s);
         break;
       default: err = hipErrorInvalidValue;
@@ -1385,9 +1388,8 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
   int C = e->ochunks;
   if (C == 0) C = n_frames >= 768 ? 3 : n_frames >= 256 ? 2 : 1;      // (four compute queues are served at a time: chunk 0 rides on the caller's stream, three chunks = three queues)
   C = std::max(1, std::min({C, static_cast<int>(Engine::kMaxChunks), n_frames}));
-  // several utterances: every launch already runs all of them -- their 13 scans side by side on their own wavefronts, the small layers U
-  // times fuller -- and the block is not cut into chunks (the chunk pipeline overlaps ONE utterance's scans with its convs)
-  if (U > 1) C = 1;
+  // (several utterances: every launch runs all of them -- their 13 scans side by side on their own wavefronts, the small layers U times fuller;
+  //  the chunks cut the frames of every utterance alike)
   if (C == 1) {
     int rc = launch_block_range(e, 0, e->plan_off.size(), 0, n_frames, true, s);
     if (rc) return rc;
@@ -1423,7 +1425,7 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
           if (a == b) continue;
           const int slot = half * Engine::kGroups + g;
           if (c > 0 && hipStreamWaitEvent(cs(c), e->oev[(c - 1) * EV + slot], 0) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipStreamWaitEvent");
-          if (rc == NUTLS_OK) rc = launch_block_range(e, a, b, t0, n, false, cs(c));
+          if (rc == NUTLS_OK) rc = launch_block_range(e, a, b, t0, n, false, cs(c), n_frames);
           if (rc == NUTLS_OK && c + 1 < C && hipEventRecord(e->oev[c * EV + slot], cs(c)) != hipSuccess) rc = fail(NUTLS_ERR_HIP, "block pipeline: hipEventRecord");
         }
       }
@@ -1438,7 +1440,7 @@ int nutls_process_block(nutls_handle* h, const float* mag_in, float* mag_out, in
     if (rc) return rc;
     if (e->ctfa_causal)
       for (int k = 0; k < 12; ++k) {
-        hipError_t err = launch_ctfa_hist_roll(e->ta_hist + static_cast<size_t>(k) * (31 + e->offline) * 64, n_frames, s);
+        hipError_t err = launch_ctfa_hist_roll(e->ta_hist + static_cast<size_t>(k) * (31 + e->offline) * 64, n_frames, s, U, static_cast<long long>(12) * (31 + e->offline) * 64);
         if (err != hipSuccess) return fail(NUTLS_ERR_HIP, std::string("time-attention history roll: ") + hipGetErrorString(err));
       }
   }

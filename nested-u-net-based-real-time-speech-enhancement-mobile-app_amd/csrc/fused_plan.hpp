@@ -106,6 +106,9 @@ struct OpD {
   // outputs: the K-slice sums, LayerNorm, PReLU and the three-plane split are ~50 dependent VALU instructions per wave instead of ~110
   // on the one or two waves that hold all rows as float4 (epl 4) -- the epilogue is the critical path of a small op
   int epl;
+  // nt0 / nt1: nothing in THIS launch reads destination 0 / 1 again (its rows are the next frame's previous-frame tap): stored with the non-temporal hint
+  // (fused_step.hip "Cache policy"); LSTM ops: nt0 for the Dense rows written to the state tensor
+  int nt0, nt1;
 };
 // ---- blob layout of an LSTM + Dense op (OpD::lw_off; kernel: prefetch_w / lstm_op, host: fused_host_impl.inc, planner: gen_fused_plan.py) --
 // The reference's .tflite stores the LSTM kernels int8 with one scale per tensor (FULLY_CONNECTED, hybrid) and so does the blob: four

@@ -143,6 +143,20 @@ __device__ __forceinline__ f32x4 ldb(gcb_t base, unsigned boff) { return *(gc4_t
 __device__ __forceinline__ float ldb1(gcb_t base, unsigned boff) { return *(gcf_t)(base + static_cast<unsigned long long>(boff)); }
 __device__ __forceinline__ void stb(gcb_t base, unsigned boff, f32x4 v) { *(g4_t)((gb_t)(unsigned long long)base + static_cast<unsigned long long>(boff)) = v; }
 __device__ __forceinline__ void stb1(gcb_t base, unsigned boff, float v) { *(gf_t)((gb_t)(unsigned long long)base + static_cast<unsigned long long>(boff)) = v; }
+// Cache policy (round 6; profiles/r06_dev_log.txt "nt"): every ACTIVATION is read exactly once per launch, by the one workgroup that owns the stream -- the
+// previous frame's state rows and carried sums (written a whole launch ago), this frame's skip / residual / up-sampling rows -- while the WEIGHTS are read by
+// all 32 workgroups of an XCD within microseconds of each other and again next launch.  With plain loads the 2 MB of activations a stream pulls through the
+// 4 MB L2 of its XCD per frame (x 32 streams) evict the 3.4 MB of weights and each other; with the non-temporal hint on the activation loads (and on the
+// stores whose rows only the NEXT launch reads: the carried sums, OpD::nt0 / nt1 destinations) the step at 256 streams fell from 0.348 to 0.301 ms on one box
+// -- most of what the memory system cost between 160 and 256 streams.  NOT on the stores that are re-read in the same frame (skip copies, residual rows):
+// with those non-temporal too the step is 0.330.
+__device__ __forceinline__ f32x4 ld_once(gcb_t base, unsigned boff) { return __builtin_nontemporal_load((gc4_t)(base + static_cast<unsigned long long>(boff))); }
+__device__ __forceinline__ float ld_once1(gcb_t base, unsigned boff) { return __builtin_nontemporal_load((gcf_t)(base + static_cast<unsigned long long>(boff))); }
+__device__ __forceinline__ void st_next(gcb_t base, unsigned boff, f32x4 v) { __builtin_nontemporal_store(v, (g4_t)((gb_t)(unsigned long long)base + static_cast<unsigned long long>(boff))); }
+__device__ __forceinline__ void st_next1(gcb_t base, unsigned boff, float v) { __builtin_nontemporal_store(v, (gf_t)((gb_t)(unsigned long long)base + static_cast<unsigned long long>(boff))); }
+// a state store: non-temporal when nothing in this launch reads the rows again (OpD::nt0 / nt1)
+template <bool NT> __device__ __forceinline__ void st_state(gcb_t base, unsigned boff, f32x4 v) { if constexpr (NT) st_next(base, boff, v); else stb(base, boff, v); }
+template <bool NT> __device__ __forceinline__ void st_state1(gcb_t base, unsigned boff, float v) { if constexpr (NT) st_next1(base, boff, v); else stb1(base, boff, v); }
 extern __shared__ __attribute__((aligned(16))) float lds[];
 __device__ __forceinline__ f32x4& lds4(int boff) { return *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + boff); }
 __device__ __forceinline__ float& lds1(int boff) { return *reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + boff); }
@@ -414,7 +428,7 @@ __device__ __forceinline__ void stage_load(const Ctx& cx, int tid, f32x4 (&r)[NR
           const int gi = NG > 1 ? q >> clog2(per) : 0;                     // stream of the item (packed plans)
           if constexpr (NG > 1) q &= per - 1;
           const int row = q >> cs, c4 = q & (p.c4s - 1);
-          r[base + i] = ldb(src, static_cast<unsigned>(p.off * 4 + row * (p.ld * 4) + c4 * 16) + gofs(cx, PG0 + gi));
+          r[base + i] = ld_once(src, static_cast<unsigned>(p.off * 4 + row * (p.ld * 4) + c4 * 16) + gofs(cx, PG0 + gi));
         });
       }
     });
@@ -583,7 +597,7 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
       const int h0 = xs ? 0 : 6 * hs;
       sfor<6 * d.gs>([&](auto jj) {
         constexpr int j = decltype(jj)::value % 6, gi = decltype(jj)::value / 6, SH = gi == 0 ? S0 : S0 + 10 + 2 * (gi - 1);
-        w[SH + j / 4][j % 4] = ldb1(cx.sbp, static_cast<unsigned>((d.h_off + h0 + j) * 4) + gofs(cx, d.g0 + gi));      // (h[21..23]: slot padding, zero)
+        w[SH + j / 4][j % 4] = ld_once1(cx.sbp, static_cast<unsigned>((d.h_off + h0 + j) * 4) + gofs(cx, d.g0 + gi));      // (h[21..23]: slot padding, zero)
       });
       // (packed plans: gates and Dense outputs are dealt to threads as (stream, unit) / (stream, output): thread tid owns unit tid % 21 of
       //  stream tid / 21 and output tid % dout -- of stream (tid + 512 pass) / dout)
@@ -595,7 +609,7 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
       const int u21 = d.gs > 1 ? (tid < 21 * d.gs ? tid % 21 : 20) : (tid < 21 ? tid : 20);
       const int g21 = d.gs > 1 ? (tid < 21 * d.gs ? tid / 21 : d.gs - 1) : 0;          // the stream slot whose cell state this thread updates
       w[S0 + 8] = ldb(cx.wb, static_cast<unsigned>((REC + 4 * u21) * 4));
-      w[S0 + 9][0] = ldb1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4) + gofs(cx, d.g0 + g21));
+      w[S0 + 9][0] = ld_once1(cx.sbp, static_cast<unsigned>((d.c_off + u21) * 4) + gofs(cx, d.g0 + g21));
       w[S0 + 9][1] = ldb1(cx.wb, static_cast<unsigned>((REC + 84) * 4));      // s_x
       w[S0 + 9][2] = ldb1(cx.wb, static_cast<unsigned>((REC + 85) * 4));      // s_h
 #if FZ_BASE
@@ -609,7 +623,7 @@ __device__ __forceinline__ void prefetch_w(const Ctx& cx, int tid, f32x4 (&w)[NW
         constexpr int i = decltype(ii)::value % NI, gi = decltype(ii)::value / NI;
         int f = rg + 32 * i;
         if (f > d.F - 1) f = d.F - 1;
-        w[gi * NI + i] = ldb(cx.sbc, static_cast<unsigned>((d.e0_off + f * d.e0_ld + 4 * c4) * 4) + gofs(cx, d.g0 + gi));
+        w[gi * NI + i] = ld_once(cx.sbc, static_cast<unsigned>((d.e0_off + f * d.e0_ld + 4 * c4) * 4) + gofs(cx, d.g0 + gi));
       });
       if constexpr (d.last) {
         w[NI * d.gs] = ldb(cx.wb, static_cast<unsigned>((d.cw_off + 4256 + 4 * c4) * 4));                     // output conv weights
@@ -654,20 +668,20 @@ __device__ __forceinline__ void prefetch_y(const Ctx& cx, int tid, f32x4 (&yp)[N
         constexpr int i = decltype(ii)::value, q = i & 3, n = (i >> 2) % d.NT, pt = (i >> 2) / d.NT;
         // (32x32 tiles: the sums live in HBM in accumulator order -- [wave task][pt][n][q][lane] float4 -- so that a wave's load /
         //  store is 1 KB contiguous; a [pos][channel] layout costs 32 partial lines per instruction)
-        yp[i] = ldb(cx.ysr, r32_ys_off<I>(cx, t, pt, n, q) + static_cast<unsigned>(lane * 16));
+        yp[i] = ld_once(cx.ysr, r32_ys_off<I>(cx, t, pt, n, q) + static_cast<unsigned>(lane * 16));
       });
     } else if constexpr (d.epl == 1) {
       // one output element per lane (x_epilogue1): element e = [virtual position][packed channel], the thread's own
       constexpr int total = d.gs * d.P * ntot(d);
       const int e = tid < total ? tid : total - 1;
-      yp[0][0] = ldb1(cx.ysr, x16_ys_off<I>(cx, e >> 2) + static_cast<unsigned>((e & 3) * 4));
+      yp[0][0] = ld_once1(cx.ysr, x16_ys_off<I>(cx, e >> 2) + static_cast<unsigned>((e & 3) * 4));
     } else {
       constexpr int per = d.P * ntot(d) / 4, total = d.gs * per;
       sfor<yp_regs(I)>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         int item = tid + THREADS * i;
         if ((i + 1) * THREADS > total) item = item < total ? item : total - 1;
-        yp[i] = ldb(cx.ysr, x16_ys_off<I>(cx, item));
+        yp[i] = ld_once(cx.ysr, x16_ys_off<I>(cx, item));
       });
     }
   }
@@ -796,8 +810,8 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
       if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, 4 * li, v); }
       if constexpr (feeds_x(I)) lds4(d.xcopy_b + gi * 1024 + (row * GC + 4 * li) * 4) = v;
       sched_pin();
-      if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v); }
-      if constexpr (d.d1_on) { if (FZ_D1(d, cx)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v); }
+      if constexpr (d.d0_on) { if (FZ_D0(d, cx)) st_state<d.nt0 != 0>(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + 4 * li) * 4) + go, v); }
+      if constexpr (d.d1_on) { if (FZ_D1(d, cx)) st_state<d.nt1 != 0>(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + 4 * li) * 4) + go, v); }
     }
   });
   if constexpr (CSUM) {
@@ -817,7 +831,7 @@ __device__ __forceinline__ void x_epilogue(const Ctx& cx, int tid, const f32x4 (
         const int eb = d.ex_b + (u >> clog2(R)) * OPB + ((u & (R - 1)) * GC + 4 * l2) * 4;
         f32x4 y = {0.f, 0.f, 0.f, 0.f};
         sfor<KS>([&](auto kk) { y += lds4(eb + decltype(kk)::value * (VP * OPB)); });
-        stb(cx.ysw, x16_ys_off<I>(cx, item), y);
+        st_next(cx.ysw, x16_ys_off<I>(cx, item), y);
       }
     });
   }
@@ -868,8 +882,8 @@ __device__ __forceinline__ void x_epilogue1(const Ctx& cx, int tid, const f32x4 
     if constexpr (feeds_x(I)) lds1(d.xcopy_b + gi * 1024 + (row * GC + cch) * 4) = v;
     if constexpr (CSUM) lds1(kOps[I + 1].scr_b + CSUM_OFF_B + tid * 4) = v;      // (every wave holds one output row of 64 channels: the CTFA adds the eight up)
     sched_pin();
-    if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb1(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cch) * 4) + go, v); }
-    if constexpr (d.d1_on) { if (FZ_D1(d, cx)) stb1(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cch) * 4) + go, v); }
+    if constexpr (d.d0_on) { if (FZ_D0(d, cx)) st_state1<d.nt0 != 0>(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cch) * 4) + go, v); }
+    if constexpr (d.d1_on) { if (FZ_D1(d, cx)) st_state1<d.nt1 != 0>(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cch) * 4) + go, v); }
   }
   if constexpr (d.ys != 0) {
     // next frame's partial sums W[tap 0] x_t: K slices summed, stored raw ([pos][packed channel]) as float4 items dealt from the top of the workgroup
@@ -880,7 +894,7 @@ __device__ __forceinline__ void x_epilogue1(const Ctx& cx, int tid, const f32x4 
       const int eb = d.ex_b + (uu >> clog2(R)) * OPB + ((uu & (R - 1)) * GC + 4 * l2) * 4;
       f32x4 y = {0.f, 0.f, 0.f, 0.f};
       sfor<KS>([&](auto kk) { y += lds4(eb + decltype(kk)::value * (VP * OPB)); });
-      stb(cx.ysw, x16_ys_off<I>(cx, item), y);
+      st_next(cx.ysw, x16_ys_off<I>(cx, item), y);
     }
   }
 }
@@ -1079,7 +1093,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 v = {acc[pt][n][4 * q], acc[pt][n][4 * q + 1], acc[pt][n][4 * q + 2], acc[pt][n][4 * q + 3]};
-            stb(cx.ysw, r32_ys_off<I>(cx, t, pt, n, q) + static_cast<unsigned>(lane * 16), v);
+            st_next(cx.ysw, r32_ys_off<I>(cx, t, pt, n, q) + static_cast<unsigned>(lane * 16), v);
           }
     } else {
       // waves 4..7: this frame's sums start from what the op handed over one frame ago
@@ -1163,8 +1177,8 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
           const int cc = c0 + 8 * q + 4 * h;
           if constexpr (UP) FZ_TRACE4(cx, d.g0 + gi, 13 + d.bidx, row, 128, cc, v);
           if constexpr (d.fwd.on) { if (fwd_has<I>(gi)) fwd_st4g<I>(gi, row, cc, v); }
-          if constexpr (d.d0_on) { if (FZ_D0(d, cx)) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v); }
-          if constexpr (d.d1_on) { if (FZ_D1(d, cx)) stb(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4) + go, v); }
+          if constexpr (d.d0_on) { if (FZ_D0(d, cx)) st_state<d.nt0 != 0>(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + row * d.d0_ld + cc) * 4) + go, v); }
+          if constexpr (d.d1_on) { if (FZ_D1(d, cx)) st_state<d.nt1 != 0>(d.d1_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d1_off + row * d.d1_ld + cc) * 4) + go, v); }
         }
       }
     }
@@ -1298,8 +1312,8 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
     const float c_new = gf * c_old + gi_ * gg;
     const float h_new = go * fast_tanh(c_new);
     const unsigned so = gofs(cx, d.g0 + gi);
-    stb1(cx.sbc, static_cast<unsigned>((d.c_off + uu) * 4) + so, c_new);
-    stb1(cx.sbc, static_cast<unsigned>((d.h_off + uu) * 4) + so, h_new);
+    st_next1(cx.sbc, static_cast<unsigned>((d.c_off + uu) * 4) + so, c_new);      // (h, c: the next frame's)
+    st_next1(cx.sbc, static_cast<unsigned>((d.h_off + uu) * 4) + so, h_new);
     lds1(HN + gi * SGB + uu * 4) = h_new;
   }
   FZ_WSTAMP(I, 5);
@@ -1324,7 +1338,7 @@ __device__ __forceinline__ void lstm_op(const Ctx& cx, int tid, Carry<I>& c, Car
       const float a = DI8 ? fmaf(a0 + a1, sd, bd) : (a0 + a1) + bd;
       const int f = n >> XS, cc = n & (d.x_cols - 1);
       img_st1<d.x_fmt>(d.y_b + gi * d.x_gstride_b + f * d.x_pitch_b + cc * esz_of(d.x_fmt), d.x_plane_b, a);
-      if constexpr (d.ldst_on) stb1(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4) + gofs(cx, d.g0 + gi), a);
+      if constexpr (d.ldst_on) st_state1<d.nt0 != 0>(cx.sbc, static_cast<unsigned>((d.ldst_off + f * d.ldst_ld + cc) * 4) + gofs(cx, d.g0 + gi), a);
     }
   }
 }
@@ -1488,7 +1502,7 @@ __device__ __forceinline__ void ctfa_op(const Ctx& cx, int tid, Carry<I>& c, Car
         } else {
           fwd_st4g<I>(gi, f, 4 * c4, y);
           // (packed plans: a consumer that is not the next op of this stream reads the rows from HBM)
-          if constexpr (d.d0_on) stb(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + f * d.d0_ld + 4 * c4) * 4) + gofs(cx, d.g0 + gi), y);
+          if constexpr (d.d0_on) st_state<d.nt0 != 0>(d.d0_src == S_CUR ? cx.sbc : cx.sbs, static_cast<unsigned>((d.d0_off + f * d.d0_ld + 4 * c4) * 4) + gofs(cx, d.g0 + gi), y);
         }
       }
     }

@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void input_layer_kernel(const InLayerParams p)
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int pos = gid >> 4, c4 = gid & 15;
   const bool valid = pos < p.n_pos;
-  const float x = valid ? p.x[pos] : 0.f;
+  const float x = valid ? p.x[slot_of(pos >> 8, p.sm_io) * 256 + (pos & 255)] : 0.f;
   const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + 4 * c4);
   const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b + 4 * c4);
   f32x4 y = w * x + bb;
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const OutConvParams p) {
   }
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
-  if (valid && c4 == 0) p.y[pos] = s + p.bias;
+  if (valid && c4 == 0) p.y[slot_of(pos >> 8, p.sm_io) * 256 + (pos & 255)] = s + p.bias;
 }
 
 hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s) {

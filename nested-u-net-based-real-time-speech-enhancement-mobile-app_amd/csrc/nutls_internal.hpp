@@ -178,6 +178,7 @@ struct InLayerParams {   // input_layer: 1x1 conv 1->64 + LN + PReLU
   int n_pos;             // B*256
   long long sstride;     // stream stride of y (x is the plain [B,256] input)
   SlotMap sm;
+  SlotMap sm_io;         // frame index -> row of x (a chunk of a block of several utterances: its frames of utterance u sit n_frames rows after those of u - 1)
 };
 hipError_t launch_input_layer(const InLayerParams& p, hipStream_t s);
 
@@ -188,6 +189,7 @@ struct OutConvParams {   // 1x1 conv 64->1
   int n_pos;
   long long sstride;          // stream stride of x (y is the plain [B,256] output)
   SlotMap sm;
+  SlotMap sm_io;              // frame index -> row of y (see InLayerParams)
 };
 hipError_t launch_out_conv(const OutConvParams& p, hipStream_t s);
 

@@ -344,6 +344,20 @@ def make_img(kind, P, cin, rounds=1, fmt=1, csplit=1, cps=0):
     return g
 
 
+def region_overlap(a, b):
+    """Do two row-strided regions of floats (off, rows, ld, width) share an element?"""
+    (ao, ar, al, aw), (bo, br, bl, bw) = a, b
+    if ao + (ar - 1) * al + aw <= bo or bo + (br - 1) * bl + bw <= ao:
+        return False
+    if al != bl:
+        return True          # (different pitches: the coarse answer)
+    d = bo - ao              # b's first element relative to a's, in a's row grid
+    r, c = d // al, d % al   # (floor: c in [0, ld))
+    cols = c < aw or c + bw > al          # b's columns [c, c + bw) meet a's [0, aw) -- directly or wrapped into the next row
+    rows = r < ar and r + br > 0 if c < aw else r + 1 < ar and r + 1 + br > 0
+    return cols and rows
+
+
 def ddb_flops(F, c):
     """Dilated-dense block (nunet_tls.py:277-359) on F positions of c channels: (2,3) conv c -> c/2, six times
     [grouped dilated (2,3) conv over k channels per filter + 1x1 conv], (2,3) conv c/2 -> c."""
@@ -465,7 +479,7 @@ def build_for(variant, G, cls):
                  d0=None, d1=None, row_mul=1, row_add=0, fwd=None, img=None, nxt=-1, parts=[],
                  din=0, dout=0, x_b=0, x_pitch_b=0, x_cols=0, y_b=0, h_off=0, c_off=0, ldst=None, lw_off=0,
                  F=0, e0_off=0, e0_ld=0, last=0, cw_off=0, drain=0, bidx=0, wkey="", flops=0, x_fmt=0, x_plane_b=0, ys=0, ys_off=0, xs_off=0, xs_ld=0,
-                 gs=1, g0=0, scr_b=SCR_B, scr_gstride_b=0, xcopy_b=XCOPY_B, x_gstride_b=0, layer=-1, epl=4)
+                 gs=1, g0=0, scr_b=SCR_B, scr_gstride_b=0, xcopy_b=XCOPY_B, x_gstride_b=0, layer=-1, epl=4, nt0=0, nt1=0)
         d.update(kw)
         d["gs"] = gs_of(d["name"])
         ops.append(d)
@@ -910,17 +924,7 @@ def build_for(variant, G, cls):
         o["lazy0"] = 0
         o["lazy1"] = 0
     if G == 1 and LAZY:
-        def overlap(a, b):      # (off, rows, ld, width): row-strided regions of floats
-            (ao, ar, al, aw), (bo, br, bl, bw) = a, b
-            if ao + (ar - 1) * al + aw <= bo or bo + (br - 1) * bl + bw <= ao:
-                return False
-            if al != bl:
-                return True          # (different pitches: the coarse answer)
-            d = bo - ao              # b's first element relative to a's, in a's row grid
-            r, c = d // al, d % al   # (floor: c in [0, ld))
-            cols = c < aw or c + bw > al          # b's columns [c, c + bw) meet a's [0, aw) -- directly or wrapped into the next row
-            rows = r < ar and r + br > 0 if c < aw else r + 1 < ar and r + 1 + br > 0
-            return cols and rows
+        overlap = region_overlap
         readers = []
         for q in ops:
             for pp in q.get("parts", []):
@@ -940,6 +944,29 @@ def build_for(variant, G, cls):
                 a = (o["d1"][1], o["P"] * o["R"], o["d1"][2], o["gc"])
                 if not any(overlap(a, b) for b in readers):
                     o["lazy1"] = 1
+    # ---- cache policy of the state stores (OpD::nt0 / nt1): a destination nothing in THIS launch reads again -- no same-frame staged part (skip rows,
+    # up-sampling inputs, packed plans' hand-offs), no CTFA residual -- holds rows that only the next frame needs (its previous-frame taps): such stores get
+    # the non-temporal hint, so that they do not push the rows that ARE re-read, and the weights, out of the L2
+    overlap2 = region_overlap
+    same_frame = {}
+    for q in ops:
+        for pp in q.get("parts", []):
+            if pp["src"] in (S_CUR, S_SCRATCH):
+                same_frame.setdefault(pp["src"], []).append((pp["off"], pp["rows"], pp["ld"], 4 * pp["c4s"]))
+        if q["type"] == T_CTFA:
+            same_frame.setdefault(S_CUR, []).append((q["e0_off"], q["F"], q["e0_ld"], 64))
+    for o in ops:
+        if o["type"] == T_CONV:
+            for k, dk in (("nt0", o["d0"]), ("nt1", o["d1"])):
+                if dk:
+                    reg = (dk[1], o["P"] * o["R"], dk[2], o["gc"])
+                    o[k] = 0 if any(overlap2(reg, b) for b in same_frame.get(dk[0], [])) else 1
+        elif o["type"] == T_LSTM and o["ldst"]:
+            reg = (o["ldst"][1], o["dout"] // o["x_cols"], o["ldst"][2], o["x_cols"])
+            o["nt0"] = 0 if any(overlap2(reg, b) for b in same_frame.get(o["ldst"][0], [])) else 1
+        elif o["type"] == T_CTFA and o["d0"]:
+            reg = (o["d0"][1], o["F"], o["d0"][2], 64)
+            o["nt0"] = 0 if any(overlap2(reg, b) for b in same_frame.get(o["d0"][0], [])) else 1
     return A, W, ops
 
 
@@ -996,7 +1023,7 @@ def emit(A, W, ops, G=1):
         seg_b = ",".join(str(x) for x in pad(o["seg_b"], MAX_SEG))
         ldst = o["ldst"]
         row = ("{%d, /*conv*/ %d,%d,%d,%d,%d,%d,%d, %d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d, %d,{%s}, %d, %d,%d, %s, %s, %d,%d, %s, %s, %d, "
-               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d, /*epl*/ %d},   // %d %s") % (
+               "/*lstm*/ %d,%d,%d,%d,%d,%d,%d,%d, %d,%d,%d, %d,%d, %d, /*ctfa*/ %d,%d,%d,%d,%d, %d, %d, /*ys*/ %d,%d,%d,%d, /*streams*/ %d,%d, %d,%d, %d, %d, %d, /*epl, nt0, nt1*/ %d, %d,%d},   // %d %s") % (
             o["type"], o["kind"], o["P"], o["cin"], o["N"], o["taps"], o["kf"], o["stride"],
             o["path"], o["PT"], o["NT"], o["PG"], o["CG"], o["KSt"], o["KSg"], o["ln"], o["R"], o["gc"], o["rounds"],
             o["nseg"], seg_b, o["ex_b"], o["w_off"], o["p_off"], c_dst(o["d0"], o["lazy0"]), c_dst(o["d1"], o["lazy1"]), o["row_mul"], o["row_add"],
@@ -1004,7 +1031,7 @@ def emit(A, W, ops, G=1):
             o["din"], o["dout"], o["x_b"], o["x_pitch_b"], o["x_cols"], o["y_b"], o["h_off"], o["c_off"],
             1 if ldst else 0, ldst[1] if ldst else 0, ldst[2] if ldst else 0, o["x_fmt"], o["x_plane_b"], o["lw_off"],
             o["F"], o["e0_off"], o["e0_ld"], o["last"], o["cw_off"], o["drain"], o["bidx"], o["ys"], o["ys_off"], o["xs_off"], o["xs_ld"],
-            o["gs"], o["g0"], o["scr_b"], o["scr_gstride_b"], o["xcopy_b"], o["x_gstride_b"], o["layer"], o["epl"], o["idx"], op_label(o))
+            o["gs"], o["g0"], o["scr_b"], o["scr_gstride_b"], o["xcopy_b"], o["x_gstride_b"], o["layer"], o["epl"], o["nt0"], o["nt1"], o["idx"], op_label(o))
         L.append("  " + row)
     L.append("};")
     # what the host needs to pack the blob / check the arena
