@@ -207,7 +207,7 @@ int nutls_batch(nutls_handle* h);
 /* Streams one workgroup of the fused kernel steps (mode 3): 1, or -- LSTM variant, more streams than CUs -- 2 or 4: a packed plan
  * (csrc/fused_step_g2.hip / _g4.hip: the layers whose LDS images fit that often run the streams side by side on one position axis, sharing
  * the weight fetch and conversion; chosen by nutls_create so that rounds of workgroups x step time of the plan is smallest -- with 256 CUs:
- * 256 streams 1, 300 .. 512 2, 768 1 (a tie with 4), 1024 and 2048 4, 1536 2).  A stream's results do not depend on its slot or partners.
+ * 256 streams 1, 300 .. 512 2, 768 1, 1024, 1536 and 2048 2; the four-stream plan on request).  A stream's results do not depend on its slot or partners.
  * NUTLS_FUSED_STREAMS=1 at creation keeps the one-stream plan; nutls_create_plan chooses explicitly.  No reference counterpart (the reference steps one stream: interpreter_proposed.py:215). */
 int nutls_streams_per_workgroup(nutls_handle* h);
 int nutls_launches_per_step(nutls_handle* h);
