@@ -80,8 +80,17 @@ int nutls_destroy(nutls_handle* h);
  * was given it. */
 int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* stream);
 
-/* Same with HOST buffers: H2D copy, step, D2H copy, synchronises before returning. */
+/* Same with HOST buffers: H2D copy, step, D2H copy, synchronises before returning.  With pageable memory (malloc, numpy) the two copies go
+ * through the runtime's staging buffers; with buffers from nutls_host_alloc they are plain DMA transfers, and in the fused mode there are no
+ * copies at all: the kernel reads the frame from and writes the result to the pinned host buffers over the link (PCIe) itself. */
 int nutls_step_host(nutls_handle* h, const float* mag_in, float* mag_out);
+
+/* Page-locked, device-visible host memory for the buffers handed to nutls_step_host / nutls_enhance_hop_host / nutls_process_block_host
+ * (what TF-Lite's interpreter.tensor(i) zero-copy view is to set_tensor / get_tensor in the reference's loop, interpreter_proposed.py:215-350:
+ * the caller produces its frames in, and consumes its results from, memory the device can reach).  NULL on failure (nutls_last_error).
+ * A handle is not needed; the memory is visible to every device. */
+void* nutls_host_alloc(size_t bytes);
+void nutls_host_free(void* p);
 
 /* ---- STFT front end / inverse-STFT back end on the device -----------------
  * Replaces the numpy part of the reference's real_time_speech_enhancer loop

@@ -7,6 +7,6 @@ arithmetic runs in the HIP library built from ``csrc/`` behind the C ABI of
 creating an engine without the built library or without a GPU raises.
 """
 from . import topology, weights, stream_enhance  # noqa: F401
-from .runner import NutlsEngine, NutlsOffline, NutlsRunner, load_library  # noqa: F401
+from .runner import NutlsEngine, NutlsOffline, NutlsRunner, host_alloc, load_library  # noqa: F401
 
-__all__ = ["topology", "weights", "stream_enhance", "NutlsEngine", "NutlsRunner", "NutlsOffline", "load_library"]
+__all__ = ["topology", "weights", "stream_enhance", "NutlsEngine", "NutlsRunner", "NutlsOffline", "load_library", "host_alloc"]

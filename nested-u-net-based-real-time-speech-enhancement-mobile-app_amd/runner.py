@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "nutls_state_info", "nutls_reset", "nutls_debug_get", "nutls_debug_trace", "nutls_debug_knob", "nutls_batch",
     "nutls_launches_per_step", "nutls_launch_info", "nutls_profile_step",
     "nutls_last_error",
-    "nutls_version",
+    "nutls_version", "nutls_host_alloc", "nutls_host_free",
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
     "nutls_create_offline", "nutls_create_offline_batch", "nutls_process_block", "nutls_process_block_host",
     "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
@@ -72,6 +72,11 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_destroy.argtypes = [c.c_void_p]
     lib.nutls_step.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     lib.nutls_step_host.argtypes = [c.c_void_p, fp, fp]
+    if not dev_lib or hasattr(lib, "nutls_host_alloc"):
+        lib.nutls_host_alloc.argtypes = [c.c_size_t]
+        lib.nutls_host_alloc.restype = c.c_void_p
+        lib.nutls_host_free.argtypes = [c.c_void_p]
+        lib.nutls_host_free.restype = None
     lib.nutls_io_buffers.argtypes = [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p)]
     lib.nutls_use_graph.argtypes = [c.c_void_p, c.c_int]
     lib.nutls_set_mode.argtypes = [c.c_void_p, c.c_int]
@@ -137,6 +142,23 @@ def _check(lib, rc: int):
 
 def _fptr(a: np.ndarray):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def host_alloc(shape, lib: Optional[ctypes.CDLL] = None) -> np.ndarray:
+    """A float32 numpy array in page-locked, device-visible host memory (``nutls_host_alloc``): frames handed to ``NutlsEngine.step``
+    / results received in its ``out=`` from such arrays cross the link without the runtime's staging copies, and the fused kernel
+    reads / writes them directly.  The memory is released when the array (and every view of it) is gone."""
+    import weakref
+    lib = lib or load_library()
+    n = int(np.prod(shape))
+    p = lib.nutls_host_alloc(n * 4)
+    if not p:
+        raise RuntimeError("nutls_host_alloc: " + lib.nutls_last_error().decode())
+    buf = (ctypes.c_float * n).from_address(p)
+    arr = np.frombuffer(buf, dtype=np.float32).reshape(shape)
+    weakref.finalize(buf, lib.nutls_host_free, p)      # (the array keeps `buf` alive through its base chain)
+    arr[...] = 0.0
+    return arr
 
 
 class NutlsEngine:
@@ -224,12 +246,18 @@ class NutlsEngine:
     def step(self, mag, out=None):
         """One frame for all B streams.  ``mag``: ``[B,256]`` float32, either a torch tensor on
         this engine's GPU (zero-copy, asynchronous on the current torch stream; ``out`` may be
-        a preallocated tensor) or a numpy array (H2D + step + D2H, synchronous)."""
+        a preallocated tensor) or a numpy array (H2D + step + D2H, synchronous; ``out`` may be a preallocated
+        array -- with arrays from ``host_alloc`` for both there are no copies, the kernel works on them over the link)."""
         if isinstance(mag, np.ndarray):
             m = np.ascontiguousarray(mag, dtype=np.float32)
             if m.shape != (self.batch, T.N_BINS):
                 raise ValueError("mag must be [%d,%d], got %s" % (self.batch, T.N_BINS, m.shape))
-            o = np.empty_like(m)
+            if out is None:
+                o = np.empty_like(m)
+            else:
+                o = out
+                if not (isinstance(o, np.ndarray) and o.dtype == np.float32 and o.flags.c_contiguous and o.shape == m.shape):
+                    raise ValueError("out must be a contiguous float32 numpy array of mag's shape")
             _check(self._lib, self._lib.nutls_step_host(self._h, _fptr(m), _fptr(o)))
             return o
         import torch

@@ -513,3 +513,29 @@ def test_fused_timeline_api(variant, request):
         assert rms(a.state_get(name), b.state_get(name)) < 1e-6, name
     assert np.isfinite(want).all()
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fused", "graph"])
+def test_step_on_pinned_host_buffers_equals_pageable_ones(mode, clip):
+    """nutls_host_alloc: frames handed over in page-locked host memory (fused mode: the kernel reads / writes them over the link, no
+    copies; other modes: DMA copies) give bit-identical results to pageable numpy arrays; a buffer that is only partly inside a pinned
+    allocation, or only one pinned side, takes the copy path."""
+    B = 3
+    x = np.stack([np.roll(clip["mags_in"][:8], s, axis=0) for s in range(B)], axis=1).astype(np.float32)      # [8, B, 256]
+    a = nunet_amd.NutlsEngine(batch=B, mode=mode)
+    want = [a.step(x[i]).copy() for i in range(8)]
+    a.close()
+    b = nunet_amd.NutlsEngine(batch=B, mode=mode)
+    pin_in, pin_out = nunet_amd.host_alloc((B, 256)), nunet_amd.host_alloc((B, 256))
+    page_out = np.empty((B, 256), np.float32)
+    for i in range(8):
+        pin_in[...] = x[i]
+        if i % 3 == 2:
+            got = b.step(pin_in, out=page_out)            # one side pinned only
+        else:
+            got = b.step(pin_in, out=pin_out)
+            assert got is pin_out
+        assert np.array_equal(got, want[i]), i
+    b.close()
+    del pin_in, pin_out
