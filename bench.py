@@ -725,6 +725,26 @@ def kernel_report(args, eng, pool, out, B, mode):
         rep["encoder_conv_stack"]["level1_layers"] = {"n": len(lv1), "us": round(1e3 * float(sum(lv1)), 2)}
         rep["encoder_conv_stack"]["deep_layers"] = {"n": len(deep), "us": round(1e3 * float(sum(deep)), 2),
                                                    "us_each": round(1e3 * float(sum(deep)) / max(1, len(deep)), 3)}
+    if one_launch and mode == "fused" and args.variant == "lstm" and getattr(eng, "streams_per_workgroup", 1) == 1 and args.ctfa_mode == "frame":
+        # the same stack on the UN-instrumented instruction stream: launches of the library's stop twin (production code + one scalar compare
+        # per op) that end in front of op N, differenced (nutls_profile_production).  The profiling build above stamps the critical wave of
+        # every op eight times and its workgroup 0 runs in the wake of the others; this is what the ops cost the kernel `value` is measured on.
+        # (timing only: the handle's streams are reset afterwards -- nothing after this point uses their state)
+        pu = eng.profile_production()
+        pnames = names      # (eng.fused_plan(): the op order nutls_profile_production reports in)
+        penc = [u for n, u in zip(pnames, pu[1:]) if re.search(r"_en\d?_conv\d$", n.split("#")[0])]
+        pdeep = [u for n, u in zip(pnames, pu[1:]) if re.search(r"_en\d?_conv[2-9]$", n.split("#")[0])]
+        p_ms = 1e-3 * float(sum(penc))
+        p_gbs = enc_bytes / (p_ms * 1e-3) / 1e9
+        rep["encoder_conv_stack"]["production"] = {
+            "ms_per_step": round(p_ms, 4), "achieved": round(p_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(p_gbs / PEAK_HBM_GBS, 4),
+            "deep_layers_us_each": round(float(sum(pdeep)) / max(1, len(pdeep)), 3), "whole_step_us": round(float(pu[1:].sum()), 1),
+            "launch_floor_us": round(float(pu[0]), 2),
+            "kind": "the same algorithmic bytes / per-op time of the un-instrumented kernel: T(launch ending in front of op N + 1) - T(... op N), "
+                    "best of 3 windows of 60 launches per N (nutls_profile_production)"}
+        rep["production_timeline_us"] = {n: round(float(u), 3) for n, u in zip(pnames, pu[1:])} if args.profile_json else None
+        if rep["production_timeline_us"] is None:
+            del rep["production_timeline_us"]
     if args.profile_json:
         with open(args.profile_json, "w") as f:
             json.dump({"batch": B, "mode": mode, "timeline_step_ms": float(ms.sum()),

@@ -208,7 +208,8 @@ int nutls_debug_trace(nutls_handle* h, int enable);
 /* Developer knobs of a handle (timing experiments; no effect on results).  "skew": start skew of the fused kernel's workgroups -- workgroup w
  * sleeps (w mod 4) * value * 64 clocks before its first op (0 = off, the default; NUTLS_FUSED_SKEW sets it at creation).  Experiment builds
  * of the step kernel (tools/exp/build_plan_lib.sh ... -DFZ_STOPAT=1) read the same field as "stop after this many ops", which is how
- * tools/exp/prod_timeline.py times the UN-instrumented kernel op by op.  Unknown names: NUTLS_ERR_ARG. */
+ * tools/exp/prod_timeline.py times variants of the UN-instrumented kernel op by op (the library's own kernel: nutls_profile_production).
+ * Unknown names: NUTLS_ERR_ARG. */
 int nutls_debug_knob(nutls_handle* h, const char* name, int value);
 int nutls_debug_get(nutls_handle* h, const char* name, float* host_buf, size_t n_floats);
 
@@ -239,6 +240,13 @@ int nutls_profile_step(nutls_handle* h, float* ms, int n);
 int nutls_fused_num_ops(int variant);
 int nutls_fused_op_info(int variant, int index, const char** name, double* flops);
 int nutls_profile_fused(nutls_handle* h, double* us, int n);
+/* The same timeline from the UN-instrumented instruction stream (one-stream plan of the LSTM variant): the library's "stop twin" of the step
+ * kernel -- the production code plus one scalar compare per op -- ends a launch in front of op N; cum_us[N], N = 0 .. nutls_fused_num_ops (= the
+ * whole step), is the time per launch of `steps` back-to-back launches that end there (best of `reps` windows, HIP events), so
+ * cum_us[N + 1] - cum_us[N] is what op N adds to the production kernel: no stamps on the critical wave, and every workgroup under the load of all the
+ * others (the profiling build's workgroup 0 runs in their wake).  cum_us[0] is the launch floor.  n must be nutls_fused_num_ops + 1.  Timing
+ * only: the truncated launches leave the streams between two frames, every stream is reset afterwards (input: the library's mag_in buffer). */
+int nutls_profile_production(nutls_handle* h, double* cum_us, int n, int reps, int steps);
 /* Host-only (works without a GPU): the fused kernel's weight blob for a container -- conv kernels int8 in MFMA fragment
  * order, everything else fp32, in the order of the variant's static schedule.  n_floats must equal
  * nutls_fused_blob_floats(variant). */

@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnutls_hip.so")
-SOURCES = ["fused_step.hip", "fused_step_g2.hip", "fused_step_g4.hip", "fused_step_prof.hip", "fused_base.hip", "fused_base_prof.hip", "kernels.hip", "stft.hip", "offline.hip", "weights.cpp", "fused_host.cpp", "engine.cpp"]
+SOURCES = ["fused_step.hip", "fused_step_g2.hip", "fused_step_g4.hip", "fused_step_prof.hip", "fused_step_stop.hip", "fused_base.hip", "fused_base_prof.hip", "kernels.hip", "stft.hip", "offline.hip", "weights.cpp", "fused_host.cpp", "engine.cpp"]
 if os.environ.get("NUTLS_BUILD_G4_PROF") == "1":      # developer knob: the profiling twin of the 4-stream packed kernel (12 more minutes)
     SOURCES.insert(3, "fused_step_g4_prof.hip")
 # (headers are found by scanning the #include "..." lines of every source: _deps)

@@ -166,6 +166,7 @@ struct Engine {
   // streaming handle (nutls_set_ctfa_mode): history ring [B][12][32][64] and the per-step sums [B][12][64]
   float *fz_ta_zero = nullptr, *fz_ta_ring = nullptr, *fz_ta_sum = nullptr;
   float* fz_dbg_buf = nullptr;
+  int fz_stop_at = -1;         // >= 0: fused launches run the stop twin and end in front of this op (nutls_profile_production)
   int fz_skew = 0;             // FzTa::skew of the fused launches (start skew of the workgroups; experiment builds of the kernel: see nutls_debug_knob)
   float* fz_dbg = nullptr;     // activation trace [B][kDbgSlots][kDbgSlotFloats] (nutls_debug_trace): steps then run on the profiling build, which fills it
   std::string fz_reason;                 // why there is none (what the packer said), for nutls_set_mode(3)
@@ -984,7 +985,11 @@ static int run_fused(Engine* e, int par, hipStream_t s, bool prof, const float* 
   const bool base = e->variant == NUTLS_VARIANT_BASELINE;
   if (int rc = ysum_refresh(e, par, s)) return rc;
   auto launch = base ? launch_fused_base_step : (e->fz_streams == 4 ? launch_fused_step_g4 : (e->fz_streams == 2 ? launch_fused_step_g2 : launch_fused_step));
-  const int skew = e->fz_skew;      // (NUTLS_FUSED_SKEW at creation, nutls_debug_knob(h, "skew", v) later)
+  int skew = e->fz_skew;            // (NUTLS_FUSED_SKEW at creation, nutls_debug_knob(h, "skew", v) later)
+  if (e->fz_stop_at >= 0) {         // (nutls_profile_production: one-stream LSTM plan only, checked there)
+    launch = launch_fused_step_stop;
+    skew = e->fz_stop_at;
+  }
   const int eager = (e->eager_states || !e->n_lazy) ? 1 : 0;
   float* const dbg = prof ? e->fz_dbg : nullptr;      // (activation trace: the profiling builds only)
   const long long dbg_ss = static_cast<long long>(kDbgSlots) * kDbgSlotFloats;
@@ -2042,6 +2047,50 @@ int nutls_fused_op_info(int variant, int index, const char** name, double* flops
   if (name) *name = fused_op_name(variant, index);
   if (flops) *flops = fused_op_flops(variant, index);
   return NUTLS_OK;
+}
+
+int nutls_profile_production(nutls_handle* h, double* cum_us, int n, int reps, int steps) {
+  if (!h || !cum_us) return fail(NUTLS_ERR_ARG, "nutls_profile_production: null pointer");
+  Engine* e = &h->eng;
+  if (e->offline || e->mode != 3 || !e->fz_blob || e->variant != NUTLS_VARIANT_LSTM || e->fz_streams != 1 || e->ctfa_causal)
+    return fail(NUTLS_ERR_ARG, "nutls_profile_production: a streaming handle of the LSTM variant in the fused mode on the one-stream plan, per-frame CTFA "
+                               "(the stop twin exists for that kernel only)");
+  const int nops = fused_plan_num_ops(e->variant, 1);
+  if (n != nops + 1) return fail(NUTLS_ERR_ARG, "nutls_profile_production: n must equal nutls_fused_num_ops(variant) + 1");
+  if (reps < 1 || steps < 1) return fail(NUTLS_ERR_ARG, "nutls_profile_production: reps and steps must be positive");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(fused_step_stop_set_attributes());
+  hipEvent_t ev[2];
+  HIP_TRY(hipEventCreate(&ev[0]));
+  HIP_TRY(hipEventCreate(&ev[1]));
+  int rc = NUTLS_OK;
+  auto run = [&](int stop, int count) {
+    e->fz_stop_at = stop;
+    for (int i = 0; i < count && !rc; ++i) {
+      rc = run_fused(e, e->next_parity, e->stream, false);
+      e->next_parity = 1 - e->next_parity;
+      e->steps += 1;
+    }
+  };
+  run(nops, 300);      // (clocks; op index nops is never reached: the whole step)
+  for (int stop = 0; stop <= nops && !rc; ++stop) {
+    double best = 1e30;
+    run(stop, 8);
+    for (int r = 0; r < reps && !rc; ++r) {
+      if (hipEventRecord(ev[0], e->stream) != hipSuccess) { rc = fail(NUTLS_ERR_HIP, "nutls_profile_production: hipEventRecord"); break; }
+      run(stop, steps);
+      float ms = 0.f;
+      if (rc || hipEventRecord(ev[1], e->stream) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess ||
+          hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess) { if (!rc) rc = fail(NUTLS_ERR_HIP, "nutls_profile_production: event timing"); break; }
+      best = std::min(best, 1e3 * static_cast<double>(ms) / steps);
+    }
+    cum_us[stop] = best;
+  }
+  e->fz_stop_at = -1;
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  if (rc) return rc;
+  return nutls_reset(h, -1);      // (the truncated launches left every stream's state between two frames)
 }
 
 int nutls_profile_fused(nutls_handle* h, double* us, int n) {

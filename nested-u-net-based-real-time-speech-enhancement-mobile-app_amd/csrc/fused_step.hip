@@ -45,8 +45,9 @@
 #ifndef FZ_PROF
 #define FZ_PROF 0
 #endif
-// FZ_STOPAT (experiment builds only): FzTa::skew is read as "end the launch in front of op <skew>" -- the production instruction stream plus one
-// scalar compare per op: launches of growing length time the UN-instrumented kernel op by op (tools/exp/prod_timeline.py)
+// FZ_STOPAT (fused_step_stop.hip, the library's "stop twin" of the one-stream kernel; experiment builds of tools/exp): FzTa::skew is read as "end the
+// launch in front of op <skew>" -- the production instruction stream plus one scalar compare per op, no stamps: the launch time as a function of that op
+// index, differenced, is what each op costs the UN-instrumented kernel (nutls_profile_production; DESIGN.md section 4 "Round 6").
 #ifndef FZ_STOPAT
 #define FZ_STOPAT 0
 #endif
@@ -112,7 +113,7 @@ struct Ctx {
   int eager;                   // write the state tensors nothing here reads too (OpD::d0_on = 2; FzTa::eager)
   gcb_t dbg;                   // profiling builds: activation trace of this workgroup's first stream (FzTa::dbg), null = off
   unsigned dbg_sstride_b;
-  int stop_at;                 // experiment builds (-DFZ_STOPAT=1, tools/exp/prod_timeline.py): the launch ends in front of this op
+  int stop_at;                 // FZ_STOPAT builds (the stop twin, tools/exp/prod_timeline.py): the launch ends in front of this op
 };
 // Activation trace (profiling builds, nutls_debug_trace): the tensors the fused kernel keeps in LDS -- input layer, CTFA outputs, up-sampling
 // outputs -- are also copied to the trace buffer, slot `slot`, row-major [row][ld floats].  Compiled out of the production kernels.
@@ -1615,6 +1616,11 @@ struct FzArgs {
 #define FZ_NO_PROF_TWIN 1
 #define FZ_OPT_PROF_LAUNCH launch_fused_step_g4_prof
 #define FZ_OPT_PROF_ATTR fused_step_g4_prof_set_attributes
+#elif defined(FZ_STOP_TWIN)
+#define FZ_KERNEL nutls_fused_step_stop_kernel
+#define FZ_LAUNCH launch_fused_step_stop
+#define FZ_ATTR fused_step_stop_set_attributes
+#define FZ_NO_PROF_TWIN 1
 #elif FZ_PROF && FZ_BASE
 #define FZ_KERNEL nutls_fused_base_step_prof_kernel
 #define FZ_LAUNCH launch_fused_base_step_prof

@@ -249,6 +249,10 @@ hipError_t launch_fused_step(float* arena, long long sstride, const float* blob,
 hipError_t launch_fused_base_step(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
                                   unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
 hipError_t fused_step_set_attributes();
+// stop twin (fused_step_stop.hip): ta.skew = the op in front of which the launch ends; `prof` must be null
+hipError_t launch_fused_step_stop(float* arena, long long sstride, const float* blob, const float* io_in, float* io_out, int B, int par,
+                                  unsigned long long* prof, const DdbParams* ddb, int step, int grid, hipStream_t s, const FzTa& ta);
+hipError_t fused_step_stop_set_attributes();
 hipError_t fused_base_step_set_attributes();
 void fused_lazy_table(int variant, std::vector<LazyCopy>* tab);      // (one-stream plans; empty when the plan writes every state)
 enum FusedPack : int { FZ_PACK_OK = 0, FZ_PACK_NOT_INT8 = 1, FZ_PACK_MALFORMED = 2 };

@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "nutls_version", "nutls_host_alloc", "nutls_host_free",
     "nutls_enhance_hop", "nutls_enhance_hop_host", "nutls_stft_hop", "nutls_istft_hop",
     "nutls_create_offline", "nutls_create_offline_batch", "nutls_process_block", "nutls_process_block_host",
-    "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused",
+    "nutls_fused_num_ops", "nutls_fused_op_info", "nutls_profile_fused", "nutls_profile_production",
     "nutls_fused_blob_floats", "nutls_fused_pack_blob", "nutls_state_get_all", "nutls_offline_set_ctfa_mode",
     "nutls_offline_set_pipeline", "nutls_streams_per_workgroup", "nutls_fused_plan_blob_floats", "nutls_fused_pack_blob_plan",
     "nutls_set_ctfa_mode", "nutls_fused_plan_num_ops", "nutls_fused_plan_op_info", "nutls_create_plan",
@@ -112,6 +112,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.nutls_fused_num_ops.argtypes = [c.c_int]
     lib.nutls_fused_op_info.argtypes = [c.c_int, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_double)]
     lib.nutls_profile_fused.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int]
+    if not dev_lib or hasattr(lib, "nutls_profile_production"):
+        lib.nutls_profile_production.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.c_int, c.c_int, c.c_int]
     lib.nutls_fused_blob_floats.argtypes = [c.c_int]
     lib.nutls_fused_pack_blob.argtypes = [c.c_void_p, c.c_size_t, c.c_int, fp, c.c_size_t]
     lib.nutls_fused_plan_blob_floats.argtypes = [c.c_int, c.c_int]
@@ -412,6 +414,15 @@ class NutlsEngine:
         _check(self._lib, self._lib.nutls_profile_fused(
             self._h, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), us.size))
         return us
+
+    def profile_production(self, reps: int = 3, steps: int = 60) -> np.ndarray:
+        """Per-op microseconds of the UN-instrumented step kernel (``nutls_profile_production``: launches of the library's stop twin that end
+        in front of op N, differenced; one-stream plan of the LSTM variant).  Returns ``[n_ops + 1]``: element 0 is the launch floor, element
+        ``i + 1`` what op ``i`` of ``fused_plan()`` adds.  Timing only -- every stream is reset afterwards."""
+        n = self._lib.nutls_fused_plan_num_ops(self.VARIANTS[self.variant], 1) + 1
+        cum = np.zeros(n, np.float64)
+        _check(self._lib, self._lib.nutls_profile_production(self._h, cum.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n, reps, steps))
+        return np.concatenate([cum[:1], np.diff(cum)])
 
     def profile_step(self) -> np.ndarray:
         """One step with every launch bracketed by HIP events on the library's stream; returns

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
+import nunet_amd
 from nunet_amd import NutlsEngine
 from nunet_amd import topology as T
 from nunet_amd.weights import parse_blob, synthetic_weights, write_blob
@@ -76,3 +77,48 @@ def test_ctfa_upsampling_and_input_layer_outputs_match_the_oracle_trace(variant)
     x = np.stack([clip[n], clip[(n + 97) % 249]])
     assert rel_rms(eng.step(x), ref.step(x).numpy()) < 2e-5
     eng.close()
+
+
+@pytest.mark.gpu
+def test_production_timeline_adds_up_and_leaves_fresh_streams():
+    """nutls_profile_production: the per-op times of the un-instrumented kernel (launches of the stop twin that end in front of op N,
+    differenced) add up to the whole step as the production kernel runs it, a truncated launch is never slower than the whole step, and the
+    handle's streams are as new afterwards."""
+    import torch
+    B = 8
+    rng = np.random.default_rng(5)
+    x = (0.25 * np.abs(rng.standard_normal((4, B, 256)))).astype(np.float32)
+    eng = nunet_amd.NutlsEngine(batch=B, mode="fused")
+    for i in range(3):
+        eng.step(x[i])                       # (some history for the profile to wipe)
+    us = eng.profile_production(reps=2, steps=30)
+    n_ops = len(eng.fused_plan())
+    assert us.shape == (n_ops + 1,) and np.isfinite(us).all()
+    cum = np.cumsum(us)
+    assert cum[-1] < 1000.0 and cum[-1] > 100.0            # a step takes 0.25-0.3 ms
+    assert (cum[:-1] <= cum[-1] * 1.02).all()
+    assert us[1:].sum() > 0.9 * (cum[-1] - us[0])
+    # whole step of the stop twin against the production kernel, same handle
+    xt = torch.from_numpy(x).cuda(); out = torch.empty(B, 256, device="cuda")
+    for i in range(50): eng.step(xt[i % 4], out)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for i in range(200): eng.step(xt[i % 4], out)
+    ev[1].record(); torch.cuda.synchronize()
+    step_us = 1e3 * ev[0].elapsed_time(ev[1]) / 200
+    assert abs(cum[-1] - step_us) < 0.06 * step_us, (cum[-1], step_us)
+    # fresh streams afterwards
+    eng.reset()
+    fresh = nunet_amd.NutlsEngine(batch=B, mode="fused")
+    eng2 = nunet_amd.NutlsEngine(batch=B, mode="fused")
+    eng2.step(x[0]); eng2.profile_production(reps=1, steps=4)
+    for i in range(3):
+        assert np.array_equal(eng2.step(x[i]), fresh.step(x[i])), i
+    for e in (eng, eng2, fresh):
+        e.close()
+    with pytest.raises(ValueError, match="stop twin"):
+        b = nunet_amd.NutlsEngine(batch=2, mode="graph")
+        try:
+            b.profile_production()
+        finally:
+            b.close()
