@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B experiments on the one-stream step kernel: a library variant built BESIDE the tree from a copy of csrc/ -- with other planner knobs
-# (tools/gen_fused_plan.py: NUTLS_PLAN_EPL1=0, NUTLS_PLAN_BPRE=0, NUTLS_PLAN_KFIRST=0, NUTLS_PLAN_LAZY=0 ...) and / or extra hipcc flags:
+# (tools/gen_fused_plan.py: NUTLS_PLAN_EPL1=0, NUTLS_PLAN_KFIRST=0, NUTLS_PLAN_LAZY=0 ...) and / or extra hipcc flags:
 #   tools/exp/build_plan_lib.sh <name> "<VAR=value ...>" "<extra hipcc flags>"   -> nested-.../build/exp/libnutls_<name>.so
 # Run it with NUTLS_DEV=1 NUTLS_LIB=<path> (tools/exp/run_variants.sh does).  Only the one-stream LSTM kernel, its profiling twin and
 # fused_host.cpp (which packs the blob by the plan) are compiled from the copy; the other objects are the in-tree build's (build first).
@@ -18,7 +18,7 @@ for f in fused_step fused_step_prof; do $CC -c $S/$f.hip -o $S/$f.o & done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -c $S/fused_host.cpp -o $S/fused_host.o &
 wait
 OBJS="$S/fused_step.o $S/fused_step_prof.o $S/fused_host.o"
-for s in fused_step_g2 fused_step_g4 fused_base fused_base_prof kernels stft offline weights engine; do OBJS="$OBJS $P/build/$s.o"; done
+for s in fused_step_stop fused_step_g2 fused_step_g4 fused_base fused_base_prof kernels stft offline weights engine; do OBJS="$OBJS $P/build/$s.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/build/exp/libnutls_$NAME.so $OBJS
 rm -rf $S
 echo built $P/build/exp/libnutls_$NAME.so

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: step time of the fused kernel at B = 256 for each experimental build of the library (tools/exp/build_abl.sh).
+"""GPU box: step time of the fused kernel at B = 256 for each experimental build of the library (tools/exp/build_plan_lib.sh).
     python tools/exp/time_libs.py name1 name2 ...        ("main" = the in-tree library)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
