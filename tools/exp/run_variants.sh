@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: for each library variant of tools/exp/build_variant.sh -- parity of the one-stream kernel (golden / oracle tests), step time at
+# GPU box: for each library variant of tools/exp/build_plan_lib.sh -- parity of the one-stream kernel (golden / oracle tests), step time at
 # B = 256 (two passes over all variants, alternating, so that clock drift of the box shows), phase table of the profiling twin.
 #   tools/exp/run_variants.sh <tag> <name1> <name2> ...        ("main" = the in-tree library)     env: NOPARITY=1, NOPHASES=1
 TAG=$1; shift

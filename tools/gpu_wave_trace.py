@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: per-wave shader-clock trace of the fused step kernel (library built with -DFZ_WTRACE=1, tools/exp/build_variant.sh): every wave
+"""GPU box: per-wave shader-clock trace of the fused step kernel (library built with -DFZ_WTRACE=1, tools/exp/build_plan_lib.sh): every wave
 of workgroup 0 stamps s_memtime at the phase boundaries of every op.  Shows, per op and wave, WHEN each wave reaches each boundary relative
 to the first wave entering the op -- i.e. who waits for whom at the two barriers of a small conv op.
 
