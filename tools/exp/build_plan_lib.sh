@@ -14,11 +14,16 @@ cp $P/csrc/* $S/
 sed -i "s#\"../../include/nutls.h\"#\"$R/include/nutls.h\"#" $S/*.cpp $S/*.hpp $S/*.hip 2>/dev/null || true
 env $PLANENV NUTLS_PLAN_OUT=$S python $R/tools/gen_fused_plan.py > /dev/null
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $FLAGS"
-for f in fused_step fused_step_prof; do $CC -c $S/$f.hip -o $S/$f.o & done
+# EXP_TUS: the kernel translation units compiled from the copy (default: the one-stream kernel and its profiling twin; "fused_step_g2" for the
+# two-stream packed kernel, ...); every other object is the in-tree build's
+TUS=${EXP_TUS:-"fused_step fused_step_prof"}
+for f in $TUS; do $CC -c $S/$f.hip -o $S/$f.o & done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -c $S/fused_host.cpp -o $S/fused_host.o &
 wait
-OBJS="$S/fused_step.o $S/fused_step_prof.o $S/fused_host.o"
-for s in fused_step_stop fused_step_g2 fused_step_g4 fused_base fused_base_prof kernels stft offline weights engine; do OBJS="$OBJS $P/build/$s.o"; done
+OBJS="$S/fused_host.o"
+for s in fused_step fused_step_prof fused_step_stop fused_step_g2 fused_step_g4 fused_base fused_base_prof kernels stft offline weights engine; do
+  case " $TUS " in *" $s "*) OBJS="$OBJS $S/$s.o";; *) OBJS="$OBJS $P/build/$s.o";; esac
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/build/exp/libnutls_$NAME.so $OBJS
 rm -rf $S
 echo built $P/build/exp/libnutls_$NAME.so

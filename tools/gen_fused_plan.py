@@ -181,7 +181,11 @@ def conv_geom(kind, side, i_or_j, D):
 R32_TABLE = {   # (kind, N, P) -> (PT, NT, PG, CG)
     (K_IN, 64, 256): (1, 2, 8, 1), (K_IN, 64, 128): (1, 2, 4, 1),
     (K_EL, 32, 128): (1, 1, 4, 1),
-    (K_DL, 128, 128): (2, 2, 2, 2),
+    # (the 128-channel sub-pixel conv at 128 positions: EIGHT wave tasks of one position tile x one LayerNorm group (two channel tiles) -- with
+    #  (2, 2, 2, 2), four tasks of twice the size, every SIMD had one wave to hide its own B reads and weight widening behind its own MFMAs, and
+    #  four waves sat out the epilogue: 0.2934 -> 0.2890 ms per step, profiles/r06_dev_log.txt "dl128".  The same layers at 64 positions stay on
+    #  16x16 tiles: on 32x32 tiles -- four tasks -- they are 0.2 % slower)
+    (K_DL, 128, 128): (1, 2, 4, 2),
     (K_DOWN, 64, 128): (1, 1, 4, 2), (K_DOWN, 64, 64): (1, 1, 2, 2),
     (K_UP, 128, 128): (2, 1, 2, 4), (K_UP, 128, 64): (1, 1, 2, 4), (K_UP, 128, 32): (1, 1, 1, 4),
 }
@@ -255,6 +259,23 @@ def tiling(kind, N, P, cin, taps, rounds=1, gs=1, waves=8, fits=None, ys=0):
                             best = (key, dict(path=P_X16B, PT=pt, NT=nt, PG=pg, CG=cg, KSt=kst, KSg=ksg))
         if best is not None:
             return best[1]
+    # (one-stream instances only: on the side-by-side ops of the two-stream plan the same tilings are +0.6 % at 1 024 streams and -2.2 % at 512)
+    if gs == 1 and kind == K_DL and CT == 8 and ptiles % 2 == 0 and rounds == 1:
+        # the 128-channel sub-pixel convs at 32 / 64 positions (one-stream plans): two position groups x four channel groups of TWO tiles -- a wave
+        # reads half the B fragments (with eight channel groups every wave read all of them: 1 152 ds_read_b128 per op at 64 positions, 3.8 us of
+        # LDS time under 1 us of MFMAs) for twice the weight widening: 0.2866 -> 0.2845 ms per step (profiles/r06_dev_log.txt "nt2")
+        return dict(path=P_X16B, PT=ptiles // 2, NT=2, PG=2, CG=4, KSt=1, KSg=1)
+    if gs == 1 and kind == K_DL and CT == 4 and ptiles % 2 == 0 and rounds == 1 and taps == 2:
+        # the same for the 64-channel sub-pixel convs at 32 / 64 positions (six ops): -1.2 % ("nt2b")
+        return dict(path=P_X16B, PT=ptiles // 2, NT=2, PG=2, CG=2, KSt=2, KSg=1)
+    if gs == 1 and kind == K_EL and CT == 2 and ptiles % 2 == 0 and rounds == 1 and taps == 2:
+        # ... and for the strided convs at 32 / 64 positions (eight ops): both channel tiles on one wave, the positions dealt to two or four
+        # groups instead: -1.0 % ("nt2c")
+        ksg = 2 if (cin // 32) % 2 == 0 else 1
+        pg = 8 // (2 * ksg)
+        if ptiles % pg == 0:
+            return dict(path=P_X16B, PT=ptiles // pg, NT=2, PG=pg, CG=1, KSt=2, KSg=ksg)
+    # (the in-convs and down-sampling convs at 32 / 64 positions the same way: -0.25 %, inside the noise of a box -- left as they are)
     rem = max(1, waves // CT)
     KSt = 1 if (rounds == 2 or kind == K_UP) else min(taps, rem)
     rem //= KSt
