@@ -868,15 +868,15 @@ static int fused_setup(Engine* e, const WeightMap& wm) {
   // Which plan: one stream per workgroup, or a packed plan (two / four streams per workgroup: one weight fetch / conversion and one latency
   // chain for all of them in the layers whose images fit LDS that often).  NUTLS_FUSED_STREAMS=1 / 2 / 4 overrides (the stream count must be
   // a multiple).
-  // Choice by a two-number cost model: a step takes ceil(workgroups / CUs) rounds of the plan's step time, and those are 1 : 1.66 : 3.56 for
-  // 1 / 2 / 4 streams per workgroup (0.295 / 0.489 / 1.049 ms, round 6: profiles/plan_cost_model.json, tools/gpu_plan_cost.py -- the cache policy
+  // Choice by a two-number cost model: a step takes ceil(workgroups / CUs) rounds of the plan's step time, and those are 1 : 1.65 : 3.44 for
+  // 1 / 2 / 4 streams per workgroup (0.284 / 0.467 / 0.976 ms, round 6: profiles/plan_cost_model.json, tools/gpu_plan_cost.py -- the cache policy
   // of round 6 took 15 % off the one- and two-stream kernels and nothing off the four-stream one; round 4 measured 1 : 1.58 : 2.82).  256 streams:
-  // one per workgroup (one round); 300 .. 512: two (one round instead of two); 768: one (three rounds of 1.0 < one round of fours at 3.56);
-  // 1024, 1536, 2048: two (2 / 3 / 4 rounds of 1.66 < 1 / 2 / 2 rounds of 3.56 -- measured: 1 048 k against 996 k frames/s at 1024 streams,
+  // one per workgroup (one round); 300 .. 512: two (one round instead of two); 768: one (three rounds of 1.0 < one round of fours at 3.44);
+  // 1024, 1536, 2048: two (2 / 3 / 4 rounds of 1.65 < 1 / 2 / 2 rounds of 3.44 -- measured: 1 048 k against 996 k frames/s at 1024 streams,
   // 1 073 k against 1 018 k at 2048, tools/exp/plan_ab.py).  The four-stream plan is still built and selectable (nutls_create_plan).
   int streams = 1;
   {
-    const double t_plan[5] = {0.0, 1.0, 1.66, 0.0, 3.56};
+    const double t_plan[5] = {0.0, 1.0, 1.65, 0.0, 3.44};
     double best = 0.0;
     for (int g : {1, 2, 4}) {
       if (e->B % g != 0 || !fused_has_plan(v, g)) continue;
