@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
   constexpr OpD d = kOps[I];
   constexpr bool UP = is_up(d);
   constexpr int PT = d.PT, NT = d.NT, G = kgroups(d), NF = conv_nf(d), NSF = conv_nsf(d), CW = carry_w(I), NTOT = ntot(d), EXT = ext_sf(I);
-  constexpr int NA = UP ? 2 : NT;                    // accumulator tiles per position tile (UP: even row, odd row)
+  constexpr int NA = UP ? 2 * NT : NT;               // accumulator tiles per position tile (UP: NT for the even output row, NT for the odd one)
   constexpr int FMT = d.img.fmt;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Task t = conv_task<I>(wave);
@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
       sfor<hi - lo>([&](auto ff) {
         constexpr int f = lo + decltype(ff)::value;
         constexpr int nt = f % NT, sg = f / NT, s = sg / G, g = sg % G;
-        constexpr int na = UP ? (s == 2 ? 1 : 0) : nt;
+        constexpr int na = UP ? (s == 2 ? NT : 0) + nt : nt;
         if constexpr (nt == 0) {
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) {
@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
       } else {
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
-          const int nb = UP ? (n * d.N + 32 * t.b) : 32 * (t.b * NT + n);
+          const int nb = UP ? ((n / NT) * d.N + 32 * (t.b * NT + n % NT)) : 32 * (t.b * NT + n);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 bi = lds4(SCR_B + (nb + 8 * q + 4 * h) * 4), sc = lds4(SCR_B + (NTOT + nb + 8 * q + 4 * h) * 4);
@@ -1169,7 +1169,7 @@ __device__ __forceinline__ void conv_r32b(const Ctx& cx, int tid, Carry<I>& c, c
       // stores: tile n covers channels c0 .. c0+31 of output row  pos * row_mul + row_add + r
 #pragma unroll
       for (int n = 0; n < NA; ++n) {
-        const int nb = UP ? (n * d.N + 32 * t.b) : 32 * (t.b * NT + n);
+        const int nb = UP ? ((n / NT) * d.N + 32 * (t.b * NT + n % NT)) : 32 * (t.b * NT + n);
         const int r = nb / d.gc, c0 = nb & (d.gc - 1);
         const int row = pos * d.row_mul + d.row_add + r;
 #pragma unroll

@@ -187,7 +187,10 @@ R32_TABLE = {   # (kind, N, P) -> (PT, NT, PG, CG)
     #  16x16 tiles: on 32x32 tiles -- four tasks -- they are 0.2 % slower)
     (K_DL, 128, 128): (1, 2, 4, 2),
     (K_DOWN, 64, 128): (1, 1, 4, 2), (K_DOWN, 64, 64): (1, 1, 2, 2),
-    (K_UP, 128, 128): (2, 1, 2, 4), (K_UP, 128, 64): (1, 1, 2, 4), (K_UP, 128, 32): (1, 1, 1, 4),
+    # (msfe6_upsampling: one position tile x two channel tiles per wave task -- half the B reads of (2, 1, 2, 4), LDS time 6 144 -> 3 072 cycles
+    #  against 6 144 of MFMAs: -1.0 % of the step with "sp8"; tilings with FOUR wave tasks for the 64-position up-sampling / the 128-position
+    #  down-sampling conv lose 0.7 %, profiles/r06_dev_log.txt)
+    (K_UP, 128, 128): (1, 2, 4, 2), (K_UP, 128, 64): (1, 1, 2, 4), (K_UP, 128, 32): (1, 1, 1, 4),
 }
 # packed plans only: virtual position counts (streams side by side) no single stream has
 R32_TABLE_PACKED = {
@@ -276,6 +279,10 @@ def tiling(kind, N, P, cin, taps, rounds=1, gs=1, waves=8, fits=None, ys=0):
         if ptiles % pg == 0:
             return dict(path=P_X16B, PT=ptiles // pg, NT=2, PG=pg, CG=1, KSt=2, KSg=ksg)
     # (the in-convs and down-sampling convs at 32 / 64 positions the same way: -0.25 %, inside the noise of a box -- left as they are)
+    if gs == 1 and kind == K_DL and CT == 8 and ptiles == 1 and rounds == 1 and taps == 2:
+        # the 128-channel sub-pixel convs of ONE position tile (six ops; eight channel tiles, so the K-first search above does not see them): two tiles
+        # per wave task and the time taps dealt to two waves instead of eight tasks of one tile over the whole K range: -0.4 % ("sp8")
+        return dict(path=P_X16B, PT=1, NT=2, PG=1, CG=4, KSt=2, KSg=1)
     rem = max(1, waves // CT)
     KSt = 1 if (rounds == 2 or kind == K_UP) else min(taps, rem)
     rem //= KSt
