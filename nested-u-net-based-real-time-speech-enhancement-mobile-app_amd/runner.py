@@ -155,7 +155,7 @@ def host_alloc(shape, lib: Optional[ctypes.CDLL] = None) -> np.ndarray:
     n = int(np.prod(shape))
     p = lib.nutls_host_alloc(n * 4)
     if not p:
-        raise RuntimeError("nutls_host_alloc: " + lib.nutls_last_error().decode())
+        raise RuntimeError(lib.nutls_last_error().decode())
     buf = (ctypes.c_float * n).from_address(p)
     arr = np.frombuffer(buf, dtype=np.float32).reshape(shape)
     weakref.finalize(buf, lib.nutls_host_free, p)      # (the array keeps `buf` alive through its base chain)

@@ -40,6 +40,13 @@ def test_bad_arguments_are_reported(lib):
     assert lib.nutls_process_block_host(None, None, None, 1) == -1
     assert lib.nutls_enhance_hop_host(None, None, None, 0) == -1
     assert lib.nutls_stft_hop(None, None, None) == -1
+    # page-locked host buffers: zero bytes is an error, freeing NULL or a pointer the library did not hand out is a no-op
+    assert lib.nutls_host_alloc(0) is None
+    assert b"nutls_host_alloc" in lib.nutls_last_error()
+    lib.nutls_host_free(None)
+    buf = (ctypes.c_float * 4)()
+    lib.nutls_host_free(ctypes.addressof(buf))
+    assert lib.nutls_profile_production(None, None, 0, 1, 1) == -1
 
 
 def test_no_cpu_fallback(lib):
@@ -50,6 +57,8 @@ def test_no_cpu_fallback(lib):
         nunet_amd.NutlsEngine(batch=1)
     with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
         nunet_amd.NutlsOffline(max_frames=8)
+    with pytest.raises(RuntimeError, match="hipHostMalloc"):      # (and page-locked memory needs the HIP runtime's device too)
+        nunet_amd.host_alloc((2, 256))
 
 
 def test_product_path_does_not_import_oracle():
